@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from HuggingFace transformers (fp32, eager attention).
+
+Why HF and not the reference: the reference (Rust + candle ^0.8.2, un-vendored) cannot be
+built or imported in this image (no cargo/rustc) and its tests hold no
+golden logits.  HF transformers is an independent public implementation of the same three
+architectures; these vectors pin the CPU restatement (oracle/ref_forward.c), which in
+turn is the checker for the HIP path.  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+Each fixture holds inputs + expected outputs only (no weights: they are re-derived from
+the seed by tests/synth.py and guarded by a sha256 digest).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import synth  # noqa: E402
+
+from transformers import (LlamaConfig, LlamaForCausalLM, MistralConfig, MistralForCausalLM,  # noqa: E402
+                          Qwen2Config, Qwen2ForCausalLM)
+
+
+def hf_model(cfg, weights_f32):
+    fam = cfg["family"]
+    common = dict(hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
+                  num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],
+                  num_key_value_heads=cfg.get("num_key_value_heads") or cfg["num_attention_heads"],
+                  vocab_size=cfg["vocab_size"], rms_norm_eps=cfg["rms_norm_eps"], rope_theta=cfg["rope_theta"],
+                  max_position_embeddings=cfg["max_position_embeddings"], tie_word_embeddings=False,
+                  attn_implementation="eager")
+    if fam == "llama":
+        m = LlamaForCausalLM(LlamaConfig(attention_bias=False, mlp_bias=False, **common))
+    elif fam == "mistral":
+        # candle window (j + W < i masked => W+1 keys)  ==  HF window W+1
+        m = MistralForCausalLM(MistralConfig(sliding_window=cfg["sliding_window"] + 1, **common))
+    else:
+        m = Qwen2ForCausalLM(Qwen2Config(sliding_window=cfg["sliding_window"] + 1, use_sliding_window=True,
+                                         max_window_layers=0, **common))
+    sd = {k: torch.from_numpy(v.copy()) for k, v in weights_f32.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("rotary" in k or "inv_freq" in k for k in missing), missing
+    return m.float().eval()
+
+
+@torch.no_grad()
+def run_case(name, T, n_gen, ref_calls=0):
+    cfg = synth.CONFIGS[name]
+    w = synth.synth_weights(cfg)
+    m = hf_model(cfg, synth.as_f32(w))
+    ids = synth.prompt_ids(cfg, T)
+    inp = torch.from_numpy(ids.astype(np.int64))[None]
+    out = m(inp, use_cache=True)
+    rec = dict(prefill_logits=out.logits[0, -1].numpy().astype(np.float32))
+    # a shorter prefix as a second prefill vector (T//2 tokens)
+    out_h = m(inp[:, : max(1, T // 2)], use_cache=False)
+    rec["prefill_half_logits"] = out_h.logits[0, -1].numpy().astype(np.float32)
+
+    # greedy decode, "tokens" positions (HF default = true token positions)
+    if n_gen:
+        past = out.past_key_values
+        logits = out.logits[0, -1]
+        toks, step_logits = [], []
+        for _ in range(n_gen):
+            tok = int(torch.argmax(logits))
+            toks.append(tok)
+            step_logits.append(logits.numpy().astype(np.float32))
+            o = m(torch.tensor([[tok]]), past_key_values=past, use_cache=True)
+            past = o.past_key_values
+            logits = o.logits[0, -1]
+        rec["gen_tokens"] = np.array(toks, dtype=np.uint32)
+        rec["gen_logits"] = np.stack(step_logits)
+
+    # "reference" positions (quirk C.1): decode call n is rotated as position n
+    if ref_calls:
+        out = m(inp, use_cache=True)
+        past = out.past_key_values
+        logits = out.logits[0, -1]
+        toks, step_logits = [], []
+        for n in range(1, ref_calls + 1):
+            tok = int(torch.argmax(logits))
+            toks.append(tok)
+            step_logits.append(logits.numpy().astype(np.float32))
+            o = m(torch.tensor([[tok]]), past_key_values=past, use_cache=True,
+                  position_ids=torch.tensor([[n]]))
+            past = o.past_key_values
+            logits = o.logits[0, -1]
+        rec["ref_tokens"] = np.array(toks, dtype=np.uint32)
+        rec["ref_logits"] = np.stack(step_logits)
+
+    meta = dict(name=name, config=cfg, T=T, n_gen=n_gen, ref_calls=ref_calls, seed=0xFA57,
+                weights_sha256=synth.weights_digest(w), transformers=__import__("transformers").__version__,
+                torch=torch.__version__)
+    rec["prompt"] = ids
+    rec["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+    print(name, "T", T, "gen", n_gen, "->", {k: v.shape for k, v in rec.items() if k != "meta"})
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    run_case("llama_a", T=8, n_gen=16)
+    run_case("llama_mha", T=5, n_gen=8)
+    run_case("mistral_a", T=8, n_gen=16, ref_calls=8)
+    run_case("mistral_win", T=16, n_gen=0)      # prefill longer than the window; no decode
+    run_case("qwen2_a", T=8, n_gen=16, ref_calls=8)
