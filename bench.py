@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- decode tokens/s of the MI355X forward-pass backend on BASELINE.json's workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model mistral-7b] [--prompt 512]
+
+One "step" = one pass of the hot path = ONE greedy decode forward (1 token, KV-cached).  The
+default workload is BASELINE.json configs[2], the configuration the metric is quoted on:
+Mistral-7B-v0.1 bf16, 512-token prompt, 256 generated tokens (K = 256 timed decode steps that
+start right after the prompt).  N > 1 (launched by torch.distributed.run, one rank per GPU)
+runs the same single sequence tensor-parallel over N GPUs (row/column weight shards + RCCL
+all-reduce): total work is fixed, so scaling is "strong".
+
+Timed region: inputs resident in HBM (weights, KV cache, prompt already prefilled); barrier +
+device sync on both sides; max over ranks.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def synth_device_weights(torch, cfg, device, seed=1234, n_layers=None):
+    """bf16 N(0, 0.02^2) weights generated directly in HBM (the reference loads safetensors straight
+    onto the device, huggingface.rs:88,125).  Same seed on every rank => identical tensors."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = {}
+    cfg_l = dict(cfg)
+    if n_layers is not None:
+        cfg_l["num_hidden_layers"] = n_layers
+    for name, shape in synth.tensor_shapes(cfg_l):
+        t = torch.randn(shape, device=device, dtype=torch.float32, generator=g)
+        if name.endswith("layernorm.weight") or name == "model.norm.weight":
+            t = 1.0 + 0.02 * t
+        elif name == "lm_head.weight":
+            t = 0.16 * t              # x8: decisive argmax on random weights
+        else:
+            t = 0.02 * t
+        out[name] = t.to(torch.bfloat16).contiguous()
+    return out
+
+
+def as_fl_tensors(tensors, dev_index):
+    return {k: (v.data_ptr(), 1, tuple(v.shape), dev_index) for k, v in tensors.items()}   # 1 = FL_DTYPE_BF16
+
+
+def cpu_baseline(torch, cfg, dev_tensors, kv_prompt=16, n_decode=8):
+    """The reference's CPU path cannot be built here (Rust + candle, no toolchain); its stand-in is
+    the C restatement in oracle/ ("port").  Bounded sample: the same weights, L_s = 2 and 8 of the
+    model's layers + full lm_head, n_decode greedy steps each; per-layer and head cost are separated
+    and extrapolated to the full depth."""
+    from oracle import oracle
+    L = cfg["num_hidden_layers"]
+    res = {}
+    threads = os.cpu_count() or 1
+    prompt = np.arange(1, kv_prompt + 1, dtype=np.uint32)
+    for ls in (2, 8):
+        ls = min(ls, L)
+        c = dict(cfg, num_hidden_layers=ls)
+        host = {}
+        for k, v in dev_tensors.items():
+            if k.startswith("model.layers."):
+                if int(k.split(".")[2]) >= ls:
+                    continue
+            host[k] = v.view(torch.int16).cpu().numpy().view(np.uint16)
+        om = oracle.OracleModel(c, host, threads=threads)
+        oc = om.new_cache(kv_prompt + n_decode + 2)
+        lg = om.forward(oc, prompt, 0)
+        tok = oracle.argmax(lg)
+        t0 = time.perf_counter()
+        for i in range(n_decode):
+            lg = om.forward(oc, [tok], kv_prompt + i)
+            tok = oracle.argmax(lg)
+        res[ls] = (time.perf_counter() - t0) / n_decode
+        om.close()
+        del host
+    ls_a, ls_b = sorted(res)
+    per_layer = (res[ls_b] - res[ls_a]) / max(1, ls_b - ls_a) if ls_b > ls_a else res[ls_a] / ls_a
+    head = max(0.0, res[ls_a] - ls_a * per_layer)
+    t_tok = head + L * per_layer
+    return {"value": round(1.0 / t_tok, 3), "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": "oracle/ref_forward.c (fp32 math on the same bf16 weights), %d greedy decode steps after a "
+                      "%d-token prompt on %d and %d of %d layers + lm_head; per-layer %.1f ms, head %.1f ms, "
+                      "extrapolated to %d layers" % (n_decode, kv_prompt, ls_a, ls_b, L, per_layer * 1e3, head * 1e3, L)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default=os.environ.get("FL_BENCH_MODEL", "mistral-7b"))
+    ap.add_argument("--prompt", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    import fastllm_amd as fa
+    from fastllm_amd import binding
+    from fastllm_amd.configs import MODEL_CONFIGS, decode_bytes_per_token, prefill_flops
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU path in the product)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # control plane only (unique-id broadcast, barriers, max-reduce of the time); the data path's
+        # collectives are the library's own RCCL communicator over xGMI
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    cfg = MODEL_CONFIGS[args.model]
+    T, K, W = args.prompt, args.steps, args.warmup
+    log("model", args.model, "prompt", T, "steps", K, "warmup", W, "gpus", world)
+    t0 = time.perf_counter()
+    wts = synth_device_weights(torch, cfg, device)
+    torch.cuda.synchronize()
+    log("synthetic weights in HBM: %.1f GB in %.1fs" % (sum(v.numel() for v in wts.values()) * 2 / 1e9, time.perf_counter() - t0))
+
+    uid = None
+    if world > 1:
+        box = [fa.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    t0 = time.perf_counter()
+    model = fa.Model(cfg, as_fl_tensors(wts, local_rank), dtype="bf16",
+                     tp_mode=binding.TP_MULTI_PROCESS if world > 1 else binding.TP_NONE, tp_size=world, tp_rank=rank,
+                     device_ids=[local_rank], unique_id=uid)
+    log("model built in %.1fs" % (time.perf_counter() - t0))
+    info = model.info()
+
+    do_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    cpu = None
+    if do_cpu:
+        t0 = time.perf_counter()
+        cpu = cpu_baseline(torch, cfg, wts)
+        log("cpu baseline: %s tok/s on %d threads (%.1fs)" % (cpu["value"], cpu["cores"], time.perf_counter() - t0))
+    del wts
+    torch.cuda.empty_cache()
+
+    rs = np.random.RandomState(1234)
+    prompt = rs.randint(0, cfg["vocab_size"], size=T).astype(np.uint32)
+    prompt[0] = 1
+    cache = model.new_cache(T + max(K, W) + 16)
+
+    # ---- warm-up: prefill + W decode steps (also captures the decode graph) ----
+    first = model.forward_argmax(cache, prompt, 0)
+    if W:
+        model.decode_greedy(cache, first, T, W)
+    # ---- prefill timing (reported beside the headline) ----
+    cache.reset()
+    barrier(); model.synchronize()
+    t0 = time.perf_counter()
+    first = model.forward_argmax(cache, prompt, 0)
+    model.synchronize(); barrier()
+    t_prefill = time.perf_counter() - t0
+
+    # ---- timed region: exactly K decode steps ----
+    barrier(); model.synchronize(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    toks = model.decode_greedy(cache, first, T, K)
+    model.synchronize(); torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed, t_prefill], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, t_prefill = float(tt[0]), float(tt[1])
+    assert len(toks) == K
+
+    # ---- per-kernel HIP-event timing of the same decode steps (eager, event pair per launch) ----
+    n_prof = 8
+    model.profile_begin()
+    model.decode_greedy(cache, int(toks[-1]), T + K, n_prof)
+    stats = model.profile_end()
+    barrier()
+
+    if rank == 0:
+        tok_s = K / elapsed
+        kv_mid = T + K // 2
+        b_tok = decode_bytes_per_token(cfg, kv_mid)
+        gemv = next((s for s in stats if s["name"] == "gemv"), None)
+        roof = None
+        if gemv and gemv["launches"]:
+            avg_ms = gemv["total_ms"] / gemv["launches"]
+            ach = gemv["bytes"] / gemv["launches"] / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "gemv_kernel<bf16> (QKV/O/gate-up/down/lm_head weight stream)",
+                    "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                    "traffic": None, "launches_per_step": gemv["launches"] // n_prof,
+                    "bytes_per_launch": round(gemv["bytes"] / gemv["launches"]), "avg_launch_us": round(avg_ms * 1e3, 2)}
+        total_prof_ms = sum(s["total_ms"] for s in stats)
+        out = {
+            "metric": "decode_tokens_per_sec", "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "%s bf16 greedy decode, %d-token prompt, %d generated tokens, batch 1, TP=%d"
+                                   % (args.model, T, K, world), "kv_len": "%d..%d" % (T, T + K),
+                       "parallelism": "tp%d" % world},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "e2e_hbm": {"bytes_per_token": b_tok, "achieved_GBps": round(tok_s * b_tok / world / 1e9, 1),
+                        "frac_of_8TBps_per_gpu": round(tok_s * b_tok / world / 8e12, 4)},
+            "prefill": {"tokens": T, "tokens_per_sec": round(T / t_prefill, 1), "ms": round(t_prefill * 1e3, 2),
+                        "mfma_frac_of_2.5PF": round(prefill_flops(cfg, T) / t_prefill / world / 2.5e15, 4)},
+            "kernels": [{"name": s["name"], "launches_per_step": s["launches"] / n_prof,
+                         "us_per_step": round(s["total_ms"] * 1e3 / n_prof, 2),
+                         "share": round(s["total_ms"] / total_prof_ms, 4) if total_prof_ms else None} for s in stats],
+            "hbm_allocated_gb": round(info.hbm_bytes_allocated / 1e9, 2),
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,122 @@
+// common.h -- shared host/device helpers for the MI355X (gfx950) forward-pass library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/fastllm_mi355x.h"
+
+namespace fl {
+
+// ---- errors -------------------------------------------------------------------------------
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+const char *last_error();
+
+#define FL_FAIL(code, ...) do { ::fl::set_error(__VA_ARGS__); return (code); } while (0)
+#define FL_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    ::fl::set_error("HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #expr); \
+    return (e_ == hipErrorOutOfMemory) ? FL_ERR_OOM : FL_ERR_HIP; } } while (0)
+#define FL_TRY(expr) do { int rc_ = (expr); if (rc_ != FL_OK) return rc_; } while (0)
+
+// ---- element types ------------------------------------------------------------------------
+typedef uint16_t bf16_t;   // raw bf16 bits in memory
+
+__host__ __device__ inline float bf16_bits_to_float(bf16_t b) {
+    union { uint32_t u; float f; } v; v.u = (uint32_t)b << 16; return v.f;
+}
+__device__ inline bf16_t float_to_bf16_bits(float f) {
+    // plain cast: hipcc emits v_cvt_pk_bf16_f32 on gfx950 (RNE, NaN stays NaN)
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+__host__ inline bf16_t float_to_bf16_bits_host(float f) {
+    union { uint32_t u; float f; } v; v.f = f;
+    if ((v.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((v.u >> 16) | 0x40);
+    return (bf16_t)((v.u + 0x7fffu + ((v.u >> 16) & 1u)) >> 16);
+}
+
+template <typename T> struct elem;
+template <> struct elem<float> {
+    static constexpr int kDtype = FL_DTYPE_F32;
+    __device__ static float ld(const float *p) { return *p; }
+    __device__ static void st(float *p, float v) { *p = v; }
+};
+template <> struct elem<bf16_t> {
+    static constexpr int kDtype = FL_DTYPE_BF16;
+    __device__ static float ld(const bf16_t *p) { return bf16_bits_to_float(*p); }
+    __device__ static void st(bf16_t *p, float v) { *p = float_to_bf16_bits(v); }
+};
+
+// 8 consecutive elements as floats; p must be 16-byte aligned (bf16) / 32-byte (f32: two 16-B loads)
+typedef float float8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
+
+__device__ inline void unpack8(const uint4v r, float (&o)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        o[2 * i] = __uint_as_float(r[i] << 16);
+        o[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+    }
+}
+__device__ inline void load8(const bf16_t *p, float (&o)[8]) {
+    uint4v r = *reinterpret_cast<const uint4v *>(p);
+    unpack8(r, o);
+}
+__device__ inline void load8(const float *p, float (&o)[8]) {
+    float4v a = *reinterpret_cast<const float4v *>(p);
+    float4v b = *reinterpret_cast<const float4v *>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { o[i] = a[i]; o[4 + i] = b[i]; }
+}
+// streaming (read-once) variants for weights: non-temporal so they do not displace L2/MALL lines
+__device__ inline void load8_nt(const bf16_t *p, float (&o)[8]) {
+    uint4v r = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(p));
+    unpack8(r, o);
+}
+__device__ inline void load8_nt(const float *p, float (&o)[8]) {
+    float4v a = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(p));
+    float4v b = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(p + 4));
+#pragma unroll
+    for (int i = 0; i < 4; i++) { o[i] = a[i]; o[4 + i] = b[i]; }
+}
+__device__ inline void store8(bf16_t *p, const float (&v)[8]) {
+    uint4v r;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        r[i] = (uint32_t)float_to_bf16_bits(v[2 * i]) | ((uint32_t)float_to_bf16_bits(v[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4v *>(p) = r;
+}
+__device__ inline void store8(float *p, const float (&v)[8]) {
+    float4v a, b;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { a[i] = v[i]; b[i] = v[4 + i]; }
+    *reinterpret_cast<float4v *>(p) = a;
+    *reinterpret_cast<float4v *>(p + 4) = b;
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Per-request step state kept on the device so a captured decode graph can be replayed with
+// no argument update: kernels read token / RoPE offset / KV length from here.
+struct StepState {
+    uint32_t token;      // id fed to the next forward (decode)
+    uint32_t pos;        // RoPE offset of the first token of this call
+    uint32_t len;        // KV entries already cached before this call
+    uint32_t step;       // decode steps done in the current fl_decode_greedy call
+    int32_t  eos;        // -1: none
+    uint32_t done;       // set once eos was sampled
+    uint32_t _pad[2];
+};
+
+}  // namespace fl

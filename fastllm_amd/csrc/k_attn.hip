@@ -1,0 +1,297 @@
+// k_attn.hip -- single-sequence KV-cached attention.
+//
+// Cache layout per layer: K and V as [Hkv][max_seq][d] (rotated K, App. A.4/A.8).  GQA is done
+// by indexing kv_head = q_head / (H/Hkv) (App. A.6) -- K/V are never replicated, and one
+// workgroup serves all G = H/Hkv query heads of its kv head so each K/V byte is read once.
+//
+// Key rows are read straight to VGPRs, 16 B per lane: d/8 lanes cover one key row, so a wave
+// instruction fetches 64/(d/8) keys.  Each (wave, key-slot) keeps its own online-softmax state
+// (running max m, sum l, output o) -- no cross-lane traffic in the loop except the d/8-lane
+// dot-product reduce (wavefront shuffles) -- and the states are merged once at the end:
+// key-slots by shuffles, waves through LDS, split-S workgroups through a small fp32 partial
+// buffer + combine kernel.
+#include "kernels.h"
+
+namespace fl {
+
+template <int GMAX>
+struct AttnState {
+    float m[GMAX], l[GMAX], o[GMAX][8];
+    __device__ void init() {
+#pragma unroll
+        for (int g = 0; g < GMAX; g++) {
+            m[g] = -INFINITY; l[g] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[g][j] = 0.f;
+        }
+    }
+};
+
+__device__ inline void merge_state(float &m, float &l, float (&o)[8], float m2, float l2, const float (&o2)[8]) {
+    const float M = fmaxf(m, m2);
+    if (M == -INFINITY) return;                       // both empty
+    const float a = __expf(m - M), b = __expf(m2 - M);
+    l = l * a + l2 * b;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = o[j] * a + o2[j] * b;
+    m = M;
+}
+
+// Accumulate keys [lo, hi) of one kv head into this lane's state.  Uniform trip count per wave.
+template <typename CT, int D, int GMAX>
+__device__ inline void attend_range(AttnState<GMAX> &s, const float (&q)[GMAX][8], int G, const CT *__restrict__ kc,
+                                    const CT *__restrict__ vc, int lo, int hi, int wave, int lane) {
+    constexpr int LPK = D / 8, KPI = 64 / LPK;
+    const int li = lane % LPK, ks = lane / LPK;
+    for (int base = lo + wave * KPI; base < hi; base += 4 * KPI) {
+        const int key = base + ks;
+        const bool valid = key < hi;
+        const int kk = valid ? key : hi - 1;
+        float kv[8], vv[8];
+        load8(kc + (size_t)kk * D + li * 8, kv);
+        load8(vc + (size_t)kk * D + li * 8, vv);
+#pragma unroll
+        for (int g = 0; g < GMAX; g++) {
+            if (g < G) {
+                float dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; j++) dot = fmaf(q[g][j], kv[j], dot);
+#pragma unroll
+                for (int off = 1; off < LPK; off <<= 1) dot += __shfl_xor(dot, off, 64);
+                if (valid) {
+                    const float mn = fmaxf(s.m[g], dot);
+                    const float alpha = __expf(s.m[g] - mn), p = __expf(dot - mn);
+                    s.l[g] = s.l[g] * alpha + p;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) s.o[g][j] = s.o[g][j] * alpha + p * vv[j];
+                    s.m[g] = mn;
+                }
+            }
+        }
+    }
+}
+
+// merge the KPI key-slot states of a wave into lanes [0, LPK), then the 4 waves through LDS into
+// wave 0.  lds: [4 waves][GMAX][D + 2] floats.  Returns with the block result in wave 0, lanes < LPK.
+template <int D, int GMAX>
+__device__ inline void merge_block(AttnState<GMAX> &s, int G, float *lds, int wave, int lane) {
+    constexpr int LPK = D / 8;
+    const int li = lane % LPK;
+#pragma unroll
+    for (int g = 0; g < GMAX; g++) {
+        if (g < G) {
+#pragma unroll
+            for (int off = LPK; off < 64; off <<= 1) {
+                float m2 = __shfl_xor(s.m[g], off, 64), l2 = __shfl_xor(s.l[g], off, 64), o2[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) o2[j] = __shfl_xor(s.o[g][j], off, 64);
+                merge_state(s.m[g], s.l[g], s.o[g], m2, l2, o2);
+            }
+        }
+    }
+    constexpr int STR = D + 2;
+    if (lane < LPK) {
+#pragma unroll
+        for (int g = 0; g < GMAX; g++) {
+            if (g < G) {
+                float *p = lds + ((size_t)wave * GMAX + g) * STR;
+#pragma unroll
+                for (int j = 0; j < 8; j++) p[li * 8 + j] = s.o[g][j];
+                if (li == 0) { p[D] = s.m[g]; p[D + 1] = s.l[g]; }
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < LPK) {
+#pragma unroll
+        for (int g = 0; g < GMAX; g++) {
+            if (g < G) {
+                for (int w = 1; w < 4; w++) {
+                    const float *p = lds + ((size_t)w * GMAX + g) * STR;
+                    float o2[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) o2[j] = p[li * 8 + j];
+                    merge_state(s.m[g], s.l[g], s.o[g], p[D], p[D + 1], o2);
+                }
+            }
+        }
+    }
+}
+
+template <typename CT, int D, int GMAX>
+__device__ inline void load_q(float (&q)[GMAX][8], const CT *__restrict__ qrow, int hq0, int G, int lane, float scale) {
+    constexpr int LPK = D / 8;
+    const int li = lane % LPK;
+#pragma unroll
+    for (int g = 0; g < GMAX; g++) {
+        if (g < G) {
+            load8(qrow + (size_t)(hq0 + g) * D + li * 8, q[g]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) q[g][j] *= scale;       // (q.k) * 1/sqrt(d), App. A.3
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) q[g][j] = 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- decode (T = 1)
+// grid (Hkv, nsplit, ceil(G/GMAX)); T == 1: no mask, no window -- the whole cache is visible.
+template <typename CT, int D, int GMAX>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const CT *__restrict__ q, const CT *__restrict__ kc,
+                                                          const CT *__restrict__ vc, const StepState *__restrict__ st,
+                                                          float *__restrict__ part_m, float *__restrict__ part_l,
+                                                          float *__restrict__ part_o, int H, int Hkv, int max_seq,
+                                                          float scale, int nsplit) {
+    __shared__ float lds[4 * GMAX * (D + 2)];
+    constexpr int LPK = D / 8, KPI = 64 / LPK;
+    const int hk = blockIdx.x, split = blockIdx.y;
+    const int Gall = H / Hkv, g0 = blockIdx.z * GMAX;
+    const int G = min(GMAX, Gall - g0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = (int)st->len + 1;
+    int per = (S + nsplit - 1) / nsplit;
+    per = (per + 4 * KPI - 1) / (4 * KPI) * (4 * KPI);
+    const int lo = split * per, hi = min(S, lo + per);
+    const int hq0 = hk * Gall + g0;
+
+    float qv[GMAX][8];
+    load_q<CT, D, GMAX>(qv, q, hq0, G, lane, scale);
+    AttnState<GMAX> s; s.init();
+    if (lo < hi)
+        attend_range<CT, D, GMAX>(s, qv, G, kc + (size_t)hk * max_seq * D, vc + (size_t)hk * max_seq * D, lo, hi, wave, lane);
+    merge_block<D, GMAX>(s, G, lds, wave, lane);
+    if (wave == 0 && lane < LPK) {
+#pragma unroll
+        for (int g = 0; g < GMAX; g++) {
+            if (g < G) {
+                const size_t idx = (size_t)(hq0 + g) * nsplit + split;
+                float *po = part_o + idx * D + lane * 8;
+#pragma unroll
+                for (int j = 0; j < 8; j++) po[j] = s.o[g][j];
+                if (lane == 0) { part_m[idx] = s.m[g]; part_l[idx] = s.l[g]; }
+            }
+        }
+    }
+}
+
+// grid H, block D threads: merge the split-S partials and normalise
+template <typename CT>
+__global__ void attn_combine_kernel(const float *__restrict__ part_m, const float *__restrict__ part_l,
+                                    const float *__restrict__ part_o, CT *__restrict__ out, int D, int nsplit) {
+    const int h = blockIdx.x, j = threadIdx.x;
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; s++) M = fmaxf(M, part_m[(size_t)h * nsplit + s]);
+    float L = 0.f, O = 0.f;
+    for (int s = 0; s < nsplit; s++) {
+        const size_t idx = (size_t)h * nsplit + s;
+        const float w = __expf(part_m[idx] - M);
+        L += part_l[idx] * w;
+        O += part_o[idx * D + j] * w;
+    }
+    elem<CT>::st(out + (size_t)h * D + j, O / L);
+}
+
+template <typename CT, int D, int GMAX>
+static int launch_decode_t(Launcher &L, const void *q, const void *kc, const void *vc, const StepState *st,
+                           void *out, const AttnScratch &sc, int64_t H, int64_t Hkv, int64_t max_seq, float scale) {
+    const int G = (int)(H / Hkv);
+    dim3 grid((unsigned)Hkv, (unsigned)sc.nsplit, (unsigned)((G + GMAX - 1) / GMAX));
+    // the KV length lives on the device; the caller passes its host copy for the byte accounting
+    double kvbytes = 2.0 * (double)sc.kv_len_hint * Hkv * D * sizeof(CT);
+    FL_TRY(L.launch(KC_ATTN_DECODE, kvbytes, 0, attn_decode_kernel<CT, D, GMAX>, grid, dim3(256), 0, (const CT *)q,
+                    (const CT *)kc, (const CT *)vc, st, sc.part_m, sc.part_l, sc.part_o, (int)H, (int)Hkv,
+                    (int)max_seq, scale, sc.nsplit));
+    return L.launch(KC_ATTN_COMBINE, 0, 0, attn_combine_kernel<CT>, dim3((unsigned)H), dim3((unsigned)D), 0,
+                    sc.part_m, sc.part_l, sc.part_o, (CT *)out, (int)D, sc.nsplit);
+}
+
+int launch_attn_decode(Launcher &L, int dtype, const void *q, const void *k_cache, const void *v_cache,
+                       const StepState *st, void *out, const AttnScratch &sc, int64_t H, int64_t Hkv, int64_t d,
+                       int64_t max_seq, float scale) {
+    const int G = (int)(H / Hkv);
+    const bool small = G <= 4;
+#define FL_DISPATCH(CT)                                                                                        \
+    if (d == 128) return small ? launch_decode_t<CT, 128, 4>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale) \
+                               : launch_decode_t<CT, 128, 8>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale); \
+    if (d == 64) return small ? launch_decode_t<CT, 64, 4>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale)   \
+                              : launch_decode_t<CT, 64, 8>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale);
+    if (dtype == FL_DTYPE_BF16) { FL_DISPATCH(bf16_t) }
+    else { FL_DISPATCH(float) }
+#undef FL_DISPATCH
+    FL_FAIL(FL_ERR_UNSUPPORTED, "attention: head_dim %lld not supported (64 or 128)", (long long)d);
+}
+
+// ------------------------------------------------------------------------------- prefill (T > 1)
+// grid (Hkv, T, ceil(G/GMAX)): one workgroup per (kv head, query row).  Mask (App. A.5): the
+// cached prefix [0,len) is fully visible; in-call key j is visible to query t iff j <= t and
+// (no window or j + window >= t).
+template <typename CT, int D, int GMAX>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(const CT *__restrict__ q, const CT *__restrict__ kc,
+                                                           const CT *__restrict__ vc, const StepState *__restrict__ st,
+                                                           CT *__restrict__ out, int T, int H, int Hkv, int max_seq,
+                                                           float scale, int window) {
+    __shared__ float lds[4 * GMAX * (D + 2)];
+    constexpr int LPK = D / 8;
+    const int hk = blockIdx.x, t = blockIdx.y;
+    const int Gall = H / Hkv, g0 = blockIdx.z * GMAX;
+    const int G = min(GMAX, Gall - g0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int len = (int)st->len;
+    const int hq0 = hk * Gall + g0;
+    const CT *kb = kc + (size_t)hk * max_seq * D, *vb = vc + (size_t)hk * max_seq * D;
+
+    float qv[GMAX][8];
+    load_q<CT, D, GMAX>(qv, q + (size_t)t * H * D, hq0, G, lane, scale);
+    AttnState<GMAX> s; s.init();
+    int jlo = 0;
+    if (window >= 0 && t - window > 0) jlo = t - window;
+    if (jlo == 0) {
+        attend_range<CT, D, GMAX>(s, qv, G, kb, vb, 0, len + t + 1, wave, lane);
+    } else {
+        if (len > 0) attend_range<CT, D, GMAX>(s, qv, G, kb, vb, 0, len, wave, lane);
+        attend_range<CT, D, GMAX>(s, qv, G, kb, vb, len + jlo, len + t + 1, wave, lane);
+    }
+    merge_block<D, GMAX>(s, G, lds, wave, lane);
+    if (wave == 0 && lane < LPK) {
+#pragma unroll
+        for (int g = 0; g < GMAX; g++) {
+            if (g < G) {
+                float o[8];
+                const float inv = 1.0f / s.l[g];
+#pragma unroll
+                for (int j = 0; j < 8; j++) o[j] = s.o[g][j] * inv;
+                store8(out + ((size_t)t * H + hq0 + g) * D + lane * 8, o);
+            }
+        }
+    }
+}
+
+template <typename CT, int D, int GMAX>
+static int launch_prefill_t(Launcher &L, const void *q, const void *kc, const void *vc, const StepState *st, void *out,
+                            int64_t T, int64_t H, int64_t Hkv, int64_t max_seq, float scale, int64_t window) {
+    const int G = (int)(H / Hkv);
+    dim3 grid((unsigned)Hkv, (unsigned)T, (unsigned)((G + GMAX - 1) / GMAX));
+    double flops = 2.0 * (double)T * T * H * D;       // QK^T + PV over the causal half
+    return L.launch(KC_ATTN_PREFILL, 0, flops, attn_prefill_kernel<CT, D, GMAX>, grid, dim3(256), 0, (const CT *)q,
+                    (const CT *)kc, (const CT *)vc, st, (CT *)out, (int)T, (int)H, (int)Hkv, (int)max_seq, scale,
+                    (int)window);
+}
+
+int launch_attn_prefill(Launcher &L, int dtype, const void *q, const void *k_cache, const void *v_cache,
+                        const StepState *st, void *out, int64_t T, int64_t H, int64_t Hkv, int64_t d,
+                        int64_t max_seq, float scale, int64_t window) {
+    const int G = (int)(H / Hkv);
+    const bool small = G <= 4;
+#define FL_DISPATCH(CT)                                                                                             \
+    if (d == 128) return small ? launch_prefill_t<CT, 128, 4>(L, q, k_cache, v_cache, st, out, T, H, Hkv, max_seq, scale, window) \
+                               : launch_prefill_t<CT, 128, 8>(L, q, k_cache, v_cache, st, out, T, H, Hkv, max_seq, scale, window); \
+    if (d == 64) return small ? launch_prefill_t<CT, 64, 4>(L, q, k_cache, v_cache, st, out, T, H, Hkv, max_seq, scale, window)   \
+                              : launch_prefill_t<CT, 64, 8>(L, q, k_cache, v_cache, st, out, T, H, Hkv, max_seq, scale, window);
+    if (dtype == FL_DTYPE_BF16) { FL_DISPATCH(bf16_t) }
+    else { FL_DISPATCH(float) }
+#undef FL_DISPATCH
+    FL_FAIL(FL_ERR_UNSUPPORTED, "attention: head_dim %lld not supported (64 or 128)", (long long)d);
+}
+
+}  // namespace fl

@@ -1,0 +1,147 @@
+// k_gemm_mfma.hip -- prefill projection GEMM on the gfx950 matrix cores.
+//
+//   Y[T,N] = X[T,K] . W[N,K]^T      bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16)
+//
+// 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA
+// tiles), BK = 64.  Both operands are K-contiguous, so X and W tiles have the same LDS image:
+// [128 rows][64 bf16] = 128-B rows, filled by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 rows
+// per wave-instruction) into two buffers; the 16-B chunk index is XOR-swizzled with (row>>1)&7
+// on the SOURCE address and on the ds_read_b128 address (linear LDS destination), which makes
+// the 16-lane groups of ds_read_b128 conflict-free for the 16x16x32 fragment pattern.
+// Workgroup ids are remapped so that the tiles sharing a W panel run on one XCD (shared L2).
+//
+// Epilogues: fp32 store (+bias) or SiLU-gate on the 16-interleaved gate/up layout (tile column
+// blocks alternate gate/up, so one lane holds gate[j] and up[j]).
+#include "kernels.h"
+
+namespace fl {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
+
+__device__ inline void glds16(const void *g, unsigned char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// stage one 128x64 tile: rows [row0, row0+128) of a [nrows][K] matrix at columns [k0, k0+64)
+__device__ inline void stage_tile(const bf16_t *__restrict__ M, int nrows, int K, int row0, int k0,
+                                  unsigned char *lds_tile, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int r = wave * 32 + i * 8 + (lane >> 3);         // tile row written by this lane
+        int pc = lane & 7;                               // physical 16-B chunk
+        int c = pc ^ ((r >> 1) & 7);                     // logical chunk it must hold
+        int gr = row0 + r; if (gr > nrows - 1) gr = nrows - 1;
+        const bf16_t *src = M + (size_t)gr * K + k0 + c * 8;
+        glds16(src, lds_tile + (wave * 32 + i * 8) * 128);
+    }
+}
+
+__device__ inline bf16x8 read_frag(const unsigned char *lds_tile, int row, int chunk) {
+    int pc = chunk ^ ((row >> 1) & 7);
+    return *reinterpret_cast<const bf16x8 *>(lds_tile + row * 128 + pc * 16);
+}
+
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
+                                                        const float *__restrict__ bias, void *__restrict__ out,
+                                                        int T, int N, int K, int epi, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2 buffers][X tile | W tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware remap (bijective for any grid size): ids that share an XCD get consecutive tiles
+    const int nwg = tiles_m * tiles_n, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int li = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tn = li / tiles_m, tm = li % tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    float4v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    stage_tile(X, T, K, m0, 0, lds, wave, lane);
+    stage_tile(W, N, K, n0, 0, lds + TILE_BYTES, wave, lane);
+    for (int kt = 0; kt < nk; kt++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned char *cur = lds + (kt & 1) * 2 * TILE_BYTES;
+        if (kt + 1 < nk) {
+            unsigned char *nxt = lds + ((kt + 1) & 1) * 2 * TILE_BYTES;
+            stage_tile(X, T, K, m0, (kt + 1) * BK, nxt, wave, lane);
+            stage_tile(W, N, K, n0, (kt + 1) * BK, nxt + TILE_BYTES, wave, lane);
+        }
+        const unsigned char *xt = cur, *wt = cur + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int chunk = ks * 4 + (lane >> 4);
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = read_frag(xt, wm * 64 + i * 16 + (lane & 15), chunk);
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[j] = read_frag(wt, wn * 64 + j * 16 + (lane & 15), chunk);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // C/D map of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+    const int cn = lane & 15, rm = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int m = m0 + wm * 64 + i * 16 + rm + rg;
+            if (m >= T) continue;
+            if (epi == EPI_GATEUP) {
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const int n = n0 + wn * 64 + j * 16 + cn;        // gate column; up = n + 16
+                    if (n + 16 < N) {
+                        const int qq = (n >> 5) * 16 + (n & 15);
+                        float gt = acc[i][j][rg], up = acc[i][j + 1][rg];
+                        float a = gt / (1.0f + expf(-gt)) * up;
+                        reinterpret_cast<bf16_t *>(out)[(size_t)m * (N / 2) + qq] = float_to_bf16_bits(a);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int n = n0 + wn * 64 + j * 16 + cn;
+                    if (n < N) reinterpret_cast<float *>(out)[(size_t)m * N + n] = acc[i][j][rg] + (bias ? bias[n] : 0.f);
+                }
+            }
+        }
+    }
+}
+
+bool gemm_mfma_supported(int dtype, int64_t T, int64_t N, int64_t K) {
+    return dtype == FL_DTYPE_BF16 && T > 1 && K % BK == 0 && K >= BK && N >= 1;
+}
+
+int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bias, void *y,
+                     int64_t T, int64_t N, int64_t K, int epi) {
+    const int tiles_m = (int)((T + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
+    const size_t lds = 4 * TILE_BYTES;     // 64 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        FL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_mfma_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    double bytes = ((double)N * K + (double)T * K) * 2.0;
+    return L.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, gemm_mfma_kernel, dim3((unsigned)(tiles_m * tiles_n)),
+                    dim3(256), lds, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi,
+                    tiles_m, tiles_n);
+}
+
+}  // namespace fl

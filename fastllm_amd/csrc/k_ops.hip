@@ -1,0 +1,236 @@
+// k_ops.hip -- the small memory-bound ops of the decoder: embedding gather (K1), fused
+// residual-add + RMSNorm (K2/K9), RoPE + KV-cache append (K4/K5), device argmax (K13),
+// local shard reduction, and the one-off weight conversion at model build.
+#include "kernels.h"
+
+namespace fl {
+
+static const char *kNames[KC_COUNT] = {
+    "embed", "rmsnorm_add", "gemv", "gemm_mfma", "gemm_generic", "rope_kv_append", "attn_decode",
+    "attn_combine", "attn_prefill", "argmax_advance", "reduce_shards", "convert"};
+const char *kernel_class_name(int kc) { return (kc >= 0 && kc < KC_COUNT) ? kNames[kc] : "?"; }
+
+// ------------------------------------------------------------------------------- embedding
+// Embedding::forward (index_select): x[t,:] = E[ids[t],:]; residual stream is fp32.
+template <typename WT>
+__global__ __launch_bounds__(256) void embed_kernel(const WT *__restrict__ E, const uint32_t *__restrict__ ids,
+                                                    const StepState *__restrict__ st, float *__restrict__ x, int h) {
+    const int t = blockIdx.x;
+    const uint32_t id = ids ? ids[t] : st->token;
+    const WT *row = E + (size_t)id * h;
+    float *dst = x + (size_t)t * h;
+    for (int c = threadIdx.x; c * 8 < h; c += 256) {
+        float v[8];
+        load8(row + c * 8, v);
+        store8(dst + c * 8, v);
+    }
+}
+
+int launch_embed(Launcher &L, int dtype, const void *E, const uint32_t *ids, const StepState *st,
+                 float *x_res, int64_t T, int64_t h) {
+    double bytes = (double)T * h * ((dtype == FL_DTYPE_BF16 ? 2 : 4) + 4);
+    if (dtype == FL_DTYPE_BF16)
+        return L.launch(KC_EMBED, bytes, 0, embed_kernel<bf16_t>, dim3((unsigned)T), dim3(256), 0,
+                        (const bf16_t *)E, ids, st, x_res, (int)h);
+    return L.launch(KC_EMBED, bytes, 0, embed_kernel<float>, dim3((unsigned)T), dim3(256), 0,
+                    (const float *)E, ids, st, x_res, (int)h);
+}
+
+// ------------------------------------------------------------------------------- rmsnorm (+add)
+// candle_nn::ops::rms_norm (App. A.2): m = sqrt(sum(x^2)/h + eps), y = x / m * w, sum in fp32.
+// Fused with the preceding residual add (x_res += delta) so the residual stream is read once.
+template <typename OT>
+__global__ __launch_bounds__(256) void rmsnorm_add_kernel(float *__restrict__ x_res, const float *__restrict__ delta,
+                                                          const float *__restrict__ w, float eps,
+                                                          OT *__restrict__ xn, int h) {
+    __shared__ float red[4];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    float *xr = x_res + (size_t)t * h;
+    const float *dr = delta ? delta + (size_t)t * h : nullptr;
+    float ss = 0.f;
+    for (int c = tid; c * 8 < h; c += 256) {
+        float v[8];
+        load8(xr + c * 8, v);
+        if (dr) {
+            float d[8];
+            load8(dr + c * 8, d);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] += d[j];
+            store8(xr + c * 8, v);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) ss = fmaf(v[j], v[j], ss);
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    ss = red[0] + red[1] + red[2] + red[3];
+    const float m = sqrtf(ss / (float)h + eps);
+    for (int c = tid; c * 8 < h; c += 256) {
+        float v[8], wv[8], o[8];
+        load8(xr + c * 8, v);          // own writes: same thread, same addresses
+        load8(w + c * 8, wv);
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = v[j] / m * wv[j];
+        store8(xn + (size_t)t * h + c * 8, o);
+    }
+}
+
+int launch_rmsnorm_add(Launcher &L, int dtype, float *x_res, const float *delta, const float *w, float eps,
+                       void *xn, int64_t T, int64_t h) {
+    double bytes = (double)T * h * (4.0 * (delta ? 3 : 1) + (dtype == FL_DTYPE_BF16 ? 2 : 4));
+    if (dtype == FL_DTYPE_BF16)
+        return L.launch(KC_RMSNORM, bytes, 0, rmsnorm_add_kernel<bf16_t>, dim3((unsigned)T), dim3(256), 0,
+                        x_res, delta, w, eps, (bf16_t *)xn, (int)h);
+    return L.launch(KC_RMSNORM, bytes, 0, rmsnorm_add_kernel<float>, dim3((unsigned)T), dim3(256), 0,
+                    x_res, delta, w, eps, (float *)xn, (int)h);
+}
+
+// ------------------------------------------------------------------------------- RoPE + KV append
+// candle_nn::rotary_emb::rope (rotate-half, App. A.4) on q and k, then the new K/V rows are
+// written in place at cache index len+t (the reference's Tensor::cat copies the whole cache every
+// step, K5).  One thread per (t, head, j < d/2) pair.  cos/sin come from host-built fp32 tables.
+template <typename CT>
+__global__ __launch_bounds__(256) void rope_kv_kernel(const float *__restrict__ qkv, const StepState *__restrict__ st,
+                                                      const float *__restrict__ cos_tab, const float *__restrict__ sin_tab,
+                                                      int max_pos, CT *__restrict__ q_out, CT *__restrict__ kc,
+                                                      CT *__restrict__ vc, int T, int H, int Hkv, int d, int max_seq) {
+    const int half = d >> 1;
+    const int nheads = H + 2 * Hkv;
+    const int per_t = nheads * half;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)T * per_t) return;
+    const int t = (int)(idx / per_t), rem = (int)(idx % per_t);
+    const int hd = rem / half, j = rem % half;
+    const float *src = qkv + (size_t)t * nheads * d + (size_t)hd * d;
+    const float a = src[j], b = src[j + half];
+    const uint32_t pos = st->pos + (uint32_t)t, slot = st->len + (uint32_t)t;
+    if (hd < H + Hkv) {
+        const uint32_t p = pos < (uint32_t)max_pos ? pos : (uint32_t)max_pos - 1;   // host validates range
+        const float c = cos_tab[(size_t)p * half + j], s = sin_tab[(size_t)p * half + j];
+        const float ra = a * c - b * s, rb = a * s + b * c;
+        if (hd < H) {
+            CT *o = q_out + ((size_t)t * H + hd) * d;
+            elem<CT>::st(o + j, ra); elem<CT>::st(o + j + half, rb);
+        } else {
+            CT *o = kc + ((size_t)(hd - H) * max_seq + slot) * d;
+            elem<CT>::st(o + j, ra); elem<CT>::st(o + j + half, rb);
+        }
+    } else {
+        CT *o = vc + ((size_t)(hd - H - Hkv) * max_seq + slot) * d;
+        elem<CT>::st(o + j, a); elem<CT>::st(o + j + half, b);
+    }
+}
+
+int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st, const float *cos_tab,
+                   const float *sin_tab, int64_t max_pos, void *q_out, void *k_cache, void *v_cache,
+                   int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t max_seq) {
+    const int64_t total = T * (H + 2 * Hkv) * (d / 2);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    const int es = dtype == FL_DTYPE_BF16 ? 2 : 4;
+    double bytes = (double)T * (H + 2 * Hkv) * d * (4 + es);
+    if (dtype == FL_DTYPE_BF16)
+        return L.launch(KC_ROPE_KV, bytes, 0, rope_kv_kernel<bf16_t>, dim3(blocks), dim3(256), 0, qkv, st, cos_tab,
+                        sin_tab, (int)max_pos, (bf16_t *)q_out, (bf16_t *)k_cache, (bf16_t *)v_cache, (int)T, (int)H,
+                        (int)Hkv, (int)d, (int)max_seq);
+    return L.launch(KC_ROPE_KV, bytes, 0, rope_kv_kernel<float>, dim3(blocks), dim3(256), 0, qkv, st, cos_tab,
+                    sin_tab, (int)max_pos, (float *)q_out, (float *)k_cache, (float *)v_cache, (int)T, (int)H,
+                    (int)Hkv, (int)d, (int)max_seq);
+}
+
+// ------------------------------------------------------------------------------- argmax + advance
+// LogitsProcessor ArgMax (App. A.7): iter().enumerate().max_by(total_cmp) -> on exact ties the
+// LAST maximal index wins.  Also advances the device-resident step state so that a captured
+// decode graph can be replayed back to back with no host round trip (mod.rs:411-453 loop body).
+__global__ __launch_bounds__(1024) void argmax_advance_kernel(const float *__restrict__ logits, int V,
+                                                              StepState *__restrict__ st,
+                                                              uint32_t *__restrict__ out_tokens, int advance) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const int tid = threadIdx.x;
+    float best = -INFINITY; int idx = -1;
+    for (int i = tid; i < V; i += 1024) {
+        float v = logits[i];
+        if (idx < 0 || v > best || (v == best && i > idx)) { best = v; idx = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(idx, o, 64);
+        if (oi >= 0 && (idx < 0 || ov > best || (ov == best && oi > idx))) { best = ov; idx = oi; }
+    }
+    if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; w++) {
+            float ov = bv[w]; int oi = bi[w];
+            if (oi >= 0 && (idx < 0 || ov > best || (ov == best && oi > idx))) { best = ov; idx = oi; }
+        }
+        const uint32_t tok = (uint32_t)(idx < 0 ? 0 : idx);
+        if (out_tokens) out_tokens[st->step] = tok;
+        st->token = tok;
+        if (st->eos >= 0 && tok == (uint32_t)st->eos) st->done = 1;
+        if (advance) { st->pos += 1; st->len += 1; st->step += 1; }
+    }
+}
+
+int launch_argmax_advance(Launcher &L, const float *logits, int64_t V, StepState *st, uint32_t *out_tokens,
+                          int advance) {
+    return L.launch(KC_ARGMAX, (double)V * 4, 0, argmax_advance_kernel, dim3(1), dim3(1024), 0, logits, (int)V, st,
+                    out_tokens, advance);
+}
+
+// ------------------------------------------------------------------------------- local shard reduce
+// FL_TP_EMULATED: all shards live on one GPU, so all-reduce(sum) is a local sum written back to
+// every shard's buffer.  Fixed summation order s = 0..n-1 (reproducible).
+__global__ __launch_bounds__(256) void reduce_shards_kernel(float *const *__restrict__ bufs, int nshards, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nshards; k++) s += bufs[k][i];
+    for (int k = 0; k < nshards; k++) bufs[k][i] = s;
+}
+
+int launch_reduce_shards(Launcher &L, float *const *bufs_dev, int nshards, int64_t n) {
+    return L.launch(KC_REDUCE, (double)n * 8 * nshards, 0, reduce_shards_kernel, dim3((unsigned)((n + 255) / 256)),
+                    dim3(256), 0, bufs_dev, nshards, (long long)n);
+}
+
+// ------------------------------------------------------------------------------- weight conversion
+__device__ inline float load_as_f32(const void *p, size_t i, int dt) {
+    if (dt == FL_DTYPE_F32) return reinterpret_cast<const float *>(p)[i];
+    if (dt == FL_DTYPE_BF16) return bf16_bits_to_float(reinterpret_cast<const bf16_t *>(p)[i]);
+    return (float)reinterpret_cast<const _Float16 *>(p)[i];
+}
+
+template <typename DT>
+__global__ __launch_bounds__(256) void convert_slice_kernel(const void *__restrict__ src, int src_dt, long long src_ld,
+                                                            long long r0, long long c0, long long rows, long long cols,
+                                                            DT *__restrict__ dst, long long dst_ld, long long dst_row0,
+                                                            int row_mode) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cols) return;
+    const long long r = i / cols, c = i % cols;
+    const float v = load_as_f32(src, (size_t)((r0 + r) * src_ld + c0 + c), src_dt);
+    long long dr = row_mode == 0 ? dst_row0 + r : gateup_row(r, row_mode == 2);
+    elem<DT>::st(dst + (size_t)(dr * dst_ld + c), v);
+}
+
+int launch_convert_slice(Launcher &L, int src_dtype, const void *src, int64_t src_ld, int64_t r0, int64_t c0,
+                         int64_t rows, int64_t cols, int dst_dtype, void *dst, int64_t dst_ld, int64_t dst_row0,
+                         int row_mode) {
+    const int64_t total = rows * cols;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (dst_dtype == FL_DTYPE_BF16)
+        return L.launch(KC_CONVERT, 0, 0, convert_slice_kernel<bf16_t>, dim3(blocks), dim3(256), 0, src, src_dtype,
+                        (long long)src_ld, (long long)r0, (long long)c0, (long long)rows, (long long)cols,
+                        (bf16_t *)dst, (long long)dst_ld, (long long)dst_row0, row_mode);
+    return L.launch(KC_CONVERT, 0, 0, convert_slice_kernel<float>, dim3(blocks), dim3(256), 0, src, src_dtype,
+                    (long long)src_ld, (long long)r0, (long long)c0, (long long)rows, (long long)cols, (float *)dst,
+                    (long long)dst_ld, (long long)dst_row0, row_mode);
+}
+
+int launch_convert_vec_f32(Launcher &L, int src_dtype, const void *src, int64_t off, int64_t n, float *dst) {
+    return launch_convert_slice(L, src_dtype, src, n + off, 0, off, 1, n, FL_DTYPE_F32, dst, n, 0, 0);
+}
+
+}  // namespace fl

@@ -1,0 +1,91 @@
+// kernels.h -- host-callable launch wrappers of the gfx950 kernels.
+#pragma once
+#include <vector>
+
+#include "common.h"
+
+namespace fl {
+
+// Kernel classes for the measurement hooks (fl_profile_*): one class per kernel symbol family.
+enum KernelClass {
+    KC_EMBED = 0, KC_RMSNORM, KC_GEMV, KC_GEMM_MFMA, KC_GEMM_GENERIC, KC_ROPE_KV, KC_ATTN_DECODE,
+    KC_ATTN_COMBINE, KC_ATTN_PREFILL, KC_ARGMAX, KC_REDUCE, KC_CONVERT, KC_COUNT
+};
+const char *kernel_class_name(int kc);
+
+struct ProfRecord { int kc; double bytes, flops; hipEvent_t e0, e1; };
+
+// Launch context: the stream a kernel goes to and, while profiling, where its event pair is kept.
+struct Launcher {
+    hipStream_t stream = nullptr;
+    std::vector<ProfRecord> *prof = nullptr;   // non-null: bracket every launch with HIP events
+
+    template <typename... KArgs, typename... Args>
+    int launch(int kc, double bytes, double flops, void (*kernel)(KArgs...), dim3 grid, dim3 block,
+               size_t lds, Args... args) {
+        if (grid.x == 0 || grid.y == 0 || grid.z == 0) return FL_OK;
+        if (prof) {
+            ProfRecord r{kc, bytes, flops, nullptr, nullptr};
+            FL_HIP(hipEventCreate(&r.e0));
+            FL_HIP(hipEventCreate(&r.e1));
+            hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, stream, r.e0, r.e1, 0, static_cast<KArgs>(args)...);
+            prof->push_back(r);
+        } else {
+            hipLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, stream, static_cast<KArgs>(args)...);
+        }
+        FL_HIP(hipGetLastError());
+        return FL_OK;
+    }
+};
+
+enum { EPI_F32 = 0, EPI_GATEUP = 1 };
+
+// dst row of gate/up pair q in the 16-interleaved fused layout: 16 gate rows then 16 up rows
+__host__ __device__ inline int64_t gateup_row(int64_t q, int is_up) { return (q / 16) * 32 + (q % 16) + (is_up ? 16 : 0); }
+
+// ---- projections ---------------------------------------------------------------------------
+// y = x[T,K] . W[N,K]^T (+bias).  EPI_F32: y fp32 [T,N].  EPI_GATEUP: W is the 16-interleaved
+// gate/up matrix (N = 2*I rows), y is XT [T, I] = silu(gate)*up.
+// dtype FL_DTYPE_BF16: W and x (and gate-up y) bf16; FL_DTYPE_F32: all fp32.
+int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const float *bias, void *y,
+                  int64_t T, int64_t N, int64_t K, int epi);
+// cheap capability probes used by tests / DESIGN numbers
+bool gemv_supported(int dtype, int64_t N, int64_t K);
+bool gemm_mfma_supported(int dtype, int64_t T, int64_t N, int64_t K);
+
+// ---- small ops -----------------------------------------------------------------------------
+// x_res[t,:] = E[ids[t],:]; ids == nullptr: single token read from st->token
+int launch_embed(Launcher &L, int dtype, const void *E, const uint32_t *ids, const StepState *st,
+                 float *x_res, int64_t T, int64_t h);
+// x_res += delta (if delta); xn = x_res / sqrt(mean(x_res^2)+eps) * w.  rows T, width h.
+int launch_rmsnorm_add(Launcher &L, int dtype, float *x_res, const float *delta, const float *w,
+                       float eps, void *xn, int64_t T, int64_t h);
+// RoPE(q,k) + KV append.  qkv fp32 [T, (H+2Hkv)*d]; q_out XT [T,H*d]; caches XT [Hkv][max_seq][d]
+int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st, const float *cos_tab,
+                   const float *sin_tab, int64_t max_pos, void *q_out, void *k_cache, void *v_cache,
+                   int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t max_seq);
+// logits[V] -> st->token (ties: last max index), out_tokens[st->step]; advances pos/len/step
+int launch_argmax_advance(Launcher &L, const float *logits, int64_t V, StepState *st, uint32_t *out_tokens,
+                          int advance);
+// dst[i] = sum_s src[s][i] for n floats, written to every src (emulated all-reduce)
+int launch_reduce_shards(Launcher &L, float *const *bufs_dev, int nshards, int64_t n);
+
+// ---- attention -----------------------------------------------------------------------------
+struct AttnScratch { float *part_m, *part_l, *part_o; int nsplit; int64_t kv_len_hint; };
+// decode: one query token over len+1 cached keys, no mask (App. A.5)
+int launch_attn_decode(Launcher &L, int dtype, const void *q, const void *k_cache, const void *v_cache,
+                       const StepState *st, void *out, const AttnScratch &sc, int64_t H, int64_t Hkv,
+                       int64_t d, int64_t max_seq, float scale);
+// prefill: T queries; key kj visible to query t iff kj < len, or (j=kj-len) j<=t and j+window>=t
+int launch_attn_prefill(Launcher &L, int dtype, const void *q, const void *k_cache, const void *v_cache,
+                        const StepState *st, void *out, int64_t T, int64_t H, int64_t Hkv, int64_t d,
+                        int64_t max_seq, float scale, int64_t window);
+
+// ---- weight conversion at model build ---------------------------------------------------------
+// dst[row_map(r)][c] = cvt(src[r0+r][c0+c]); row_mode 0: dst_row0+r, 1: gate rows, 2: up rows
+int launch_convert_slice(Launcher &L, int src_dtype, const void *src, int64_t src_ld, int64_t r0, int64_t c0,
+                         int64_t rows, int64_t cols, int dst_dtype, void *dst, int64_t dst_ld,
+                         int64_t dst_row0, int row_mode);
+int launch_convert_vec_f32(Launcher &L, int src_dtype, const void *src, int64_t off, int64_t n, float *dst);
+
+}  // namespace fl

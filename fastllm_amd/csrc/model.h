@@ -1,0 +1,112 @@
+// model.h -- model / cache objects behind the C ABI and the forward-pass orchestration.
+#pragma once
+#include <atomic>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "kernels.h"
+
+namespace fl {
+
+struct Dims {                    // resolved config (defaults applied)
+    int family = 0, qkv_bias = 0;
+    int64_t h = 0, inter = 0, V = 0, L = 0, H = 0, Hkv = 0, d = 0, max_pos = 0, window = -1;
+    float eps = 0.f, scale = 0.f;
+    double theta = 10000.0;
+};
+
+int resolve_config(const fl_config *cfg, Dims *out);
+int tp_slice(const Dims &D, const char *name, int rank, int tp, int64_t out[4]);
+
+struct LayerW {
+    void *wqkv = nullptr;        // [(Hs+2Hkvs)*d, h]  q | k | v rows of this shard
+    float *bqkv = nullptr;       // [(Hs+2Hkvs)*d] or null
+    void *wo = nullptr;          // [h, Hs*d]
+    void *wgu = nullptr;         // [2*Ip, h] 16-interleaved gate/up rows
+    void *wd = nullptr;          // [h, Ip]
+    float *ln1 = nullptr, *ln2 = nullptr;
+};
+
+struct Scratch {                 // activations of one forward chunk on one shard
+    int64_t cap_T = 0;
+    float *x_res = nullptr;      // [T,h] fp32 residual stream
+    float *delta = nullptr;      // [T,h] fp32 output of o_proj / down_proj (all-reduced under TP)
+    void *xn = nullptr;          // [T,h] normed activations (compute dtype)
+    float *qkv = nullptr;        // [T,(Hs+2Hkvs)*d] fp32
+    void *q = nullptr;           // [T,Hs*d]
+    void *ao = nullptr;          // [T,Hs*d] attention output
+    void *act = nullptr;         // [T,Ip] silu(gate)*up
+    uint32_t *ids = nullptr;     // [T]
+};
+
+struct Shard {
+    int device = 0;
+    int rank = 0;                // TP rank this shard plays
+    hipStream_t stream = nullptr;
+    int64_t Hs = 0, Hkvs = 0, Is = 0, Ip = 0, Vs = 0, v0 = 0;
+    void *embed = nullptr;       // [V,h]
+    std::vector<LayerW> layers;
+    float *norm = nullptr;
+    void *lm_head = nullptr;     // [Vs,h]
+    float *cos_tab = nullptr, *sin_tab = nullptr;   // [max_pos][d/2]
+    Scratch dec, pre;
+    float *logits_local = nullptr;   // [Vs]
+    float *logits_full = nullptr;    // [V]
+    std::vector<void *> allocs;
+    ncclComm_t comm = nullptr;
+};
+
+struct Model {
+    std::atomic<int> refs{1};
+    std::mutex mu;
+    Dims D;
+    fl_config cfg_resolved{};
+    int dtype = FL_DTYPE_BF16;   // compute dtype
+    int tp = 1, tp_mode = FL_TP_NONE;
+    bool vocab_parallel = false;
+    std::vector<Shard> shards;   // local shards (1 except SINGLE_PROCESS / EMULATED)
+    float **emu_ptrs = nullptr;  // EMULATED: device table of per-shard buffers for the local reduce
+    float *host_logits = nullptr;   // pinned staging [V]
+    uint32_t *host_tokens = nullptr;
+    bool use_graph = true;
+    std::vector<ProfRecord> prof;
+    bool profiling = false;
+    int64_t hbm_bytes = 0;
+    size_t esize() const { return dtype == FL_DTYPE_BF16 ? 2 : 4; }
+    ~Model();
+};
+
+struct CacheShard {
+    void *k = nullptr, *v = nullptr;     // [L][Hkvs][max_seq][d]
+    StepState *st = nullptr;
+    uint32_t *out_tokens = nullptr;
+    float *part_m = nullptr, *part_l = nullptr, *part_o = nullptr;
+    hipGraphExec_t graph = nullptr;
+    std::vector<void *> allocs;
+};
+
+constexpr size_t kOutTokensCap = 4096;
+
+struct Cache {
+    Model *m = nullptr;
+    size_t max_seq = 0, len = 0;
+    int nsplit = 1;
+    int warm_steps = 0;          // eager decode steps done (graph is captured after the first)
+    bool graph_failed = false;
+    std::vector<CacheShard> shards;
+    ~Cache();
+};
+
+int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int compute_dtype,
+                 const fl_parallel *par, Model **out);
+int cache_create(Model *m, size_t max_seq, Cache **out);
+// mode: 0 = logits to host, 1 = argmax token to host
+int forward(Model *m, Cache *c, const uint32_t *ids, size_t T, size_t pos, float *logits_out, uint32_t *token_out);
+int decode_greedy(Model *m, Cache *c, uint32_t first, size_t pos, size_t n_steps, int64_t eos,
+                  uint32_t *tokens_out, size_t *n_out);
+
+}  // namespace fl

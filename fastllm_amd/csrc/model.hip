@@ -1,0 +1,707 @@
+// model.hip -- model build (weight sharding + re-layout into HBM), KV cache, and the
+// per-layer orchestration of the decoder forward pass on MI355X.
+//
+// Reference semantics reproduced here (all citations into /root/reference/src/models):
+//   config defaults + validation   llama.rs:31-50, mistral.rs:93-154, qwen.rs:30-56, config.rs:31-54
+//   weights bound by HF name       llama.rs:112-120, mistral.rs:190-192, qwen.rs:108-109
+//   forward(input, pos, cache)     llama.rs:147-149, mistral.rs:206-236, qwen.rs:123-151
+// The arithmetic follows candle 0.8.x, restated in oracle/ for tests.
+//
+// HBM layout (per shard; compute dtype = bf16 or fp32):
+//   wqkv [(Hs+2Hkvs)d, h]  fused q|k|v rows       wo [h, Hs*d]
+//   wgu  [2*Ip, h] gate/up rows interleaved 16x16  wd [h, Ip]      (Ip = Is rounded up to 16)
+//   lm_head [Vs, h], embed [V, h], norms fp32, RoPE cos/sin fp32 [max_pos][d/2]
+//   KV cache [L][Hkvs][max_seq][d] x2, written in place (no Tensor::cat copy)
+#include "model.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <memory>
+
+namespace fl {
+
+// ------------------------------------------------------------------------------- errors
+static thread_local char g_err[1024];
+void set_error(const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+}
+const char *last_error() { return g_err; }
+
+#define FL_NCCL(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { \
+    ::fl::set_error("RCCL error %s at %s:%d (%s)", ncclGetErrorString(r_), __FILE__, __LINE__, #expr); \
+    return FL_ERR_RCCL; } } while (0)
+
+static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
+
+// ------------------------------------------------------------------------------- config
+int resolve_config(const fl_config *cfg, Dims *o) {
+    if (!cfg) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null config");
+    Dims D;
+    D.family = cfg->family;
+    if (D.family < FL_FAMILY_LLAMA || D.family > FL_FAMILY_QWEN2) FL_FAIL(FL_ERR_BAD_CONFIG, "unknown model family %d", D.family);
+    D.qkv_bias = cfg->qkv_bias != 0;
+    D.h = cfg->hidden_size; D.inter = cfg->intermediate_size; D.V = cfg->vocab_size;
+    D.L = cfg->num_hidden_layers; D.H = cfg->num_attention_heads;
+    if (D.h <= 0 || D.inter <= 0 || D.V <= 0 || D.L <= 0 || D.H <= 0) FL_FAIL(FL_ERR_BAD_CONFIG, "non-positive model dimension");
+    D.Hkv = cfg->num_key_value_heads > 0 ? cfg->num_key_value_heads : D.H;          // llama.rs:39
+    D.d = D.h / D.H;
+    if (D.d * D.H != D.h) FL_FAIL(FL_ERR_BAD_CONFIG, "hidden_size must be divisible by num_attention_heads");   // config.rs:34
+    if (D.d % 2) FL_FAIL(FL_ERR_BAD_CONFIG, "head_dim must be even for RoPE embeddings");                       // config.rs:39
+    if (D.H % D.Hkv) FL_FAIL(FL_ERR_BAD_CONFIG, "num_attention_heads must be divisible by num_key_value_heads"); // config.rs:48
+    if (cfg->rms_norm_eps < 0) FL_FAIL(FL_ERR_BAD_CONFIG, "negative rms_norm_eps");
+    D.eps = (float)cfg->rms_norm_eps;
+    D.theta = cfg->rope_theta > 0 ? cfg->rope_theta : 10000.0;                                                   // llama.rs:41
+    const int64_t dflt_pos = D.family == FL_FAMILY_LLAMA ? 4096 : 32768;                                        // llama.rs:47, mistral.rs:138
+    D.max_pos = cfg->max_position_embeddings > 0 ? cfg->max_position_embeddings : dflt_pos;
+    if (D.family == FL_FAMILY_LLAMA) D.window = -1;
+    else D.window = cfg->sliding_window > 0 ? cfg->sliding_window : (cfg->sliding_window < 0 ? -1 : 4096);      // mistral.rs:139
+    D.scale = (float)(1.0 / sqrt((double)D.d));
+    *o = D;
+    return FL_OK;
+}
+
+static bool ends_with(const std::string &s, const char *suf) {
+    size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+// Megatron-style partition: q/k/v/gate/up/lm_head column-parallel (rows of the
+// [out,in] matrix), o_proj/down_proj row-parallel (columns); norms and the embedding whole.
+int tp_slice(const Dims &D, const char *name_c, int rank, int tp, int64_t out[4]) {
+    if (tp < 1 || rank < 0 || rank >= tp) FL_FAIL(FL_ERR_BAD_ARGUMENT, "bad tp rank %d of %d", rank, tp);
+    if (D.H % tp || D.Hkv % tp) FL_FAIL(FL_ERR_UNSUPPORTED, "tp=%d must divide heads (%lld) and kv heads (%lld)", tp, (long long)D.H, (long long)D.Hkv);
+    if (D.inter % tp) FL_FAIL(FL_ERR_UNSUPPORTED, "tp=%d must divide intermediate_size %lld", tp, (long long)D.inter);
+    const std::string name(name_c);
+    const int64_t qd = D.H * D.d, kvd = D.Hkv * D.d;
+    int64_t R = 0, C = 0, r0 = 0, r1 = 0, c0 = 0, c1 = 0;
+    auto rows = [&](int64_t n, int64_t k) { R = n; C = k; r0 = n / tp * rank; r1 = n / tp * (rank + 1); c0 = 0; c1 = k; };
+    auto cols = [&](int64_t n, int64_t k) { R = n; C = k; r0 = 0; r1 = n; c0 = k / tp * rank; c1 = k / tp * (rank + 1); };
+    auto whole = [&](int64_t n, int64_t k) { R = n; C = k; r0 = 0; r1 = n; c0 = 0; c1 = k; };
+    if (ends_with(name, "q_proj.weight")) rows(qd, D.h);
+    else if (ends_with(name, "k_proj.weight") || ends_with(name, "v_proj.weight")) rows(kvd, D.h);
+    else if (ends_with(name, "q_proj.bias")) rows(qd, 1);
+    else if (ends_with(name, "k_proj.bias") || ends_with(name, "v_proj.bias")) rows(kvd, 1);
+    else if (ends_with(name, "o_proj.weight")) cols(D.h, qd);
+    else if (ends_with(name, "gate_proj.weight") || ends_with(name, "up_proj.weight")) rows(D.inter, D.h);
+    else if (ends_with(name, "down_proj.weight")) cols(D.h, D.inter);
+    else if (name == "lm_head.weight") { if (D.V % tp == 0) rows(D.V, D.h); else whole(D.V, D.h); }
+    else if (name == "model.embed_tokens.weight") whole(D.V, D.h);
+    else if (ends_with(name, "layernorm.weight") || name == "model.norm.weight") whole(D.h, 1);
+    else FL_FAIL(FL_ERR_MISSING_TENSOR, "unknown tensor name %s", name_c);
+    (void)R; (void)C;
+    out[0] = r0; out[1] = r1; out[2] = c0; out[3] = c1;
+    return FL_OK;
+}
+
+// ------------------------------------------------------------------------------- allocation
+static int dev_alloc(std::vector<void *> &owner, void **p, size_t bytes, int64_t *acct) {
+    if (bytes == 0) bytes = 16;
+    FL_HIP(hipMalloc(p, bytes));
+    owner.push_back(*p);
+    if (acct) *acct += (int64_t)bytes;
+    return FL_OK;
+}
+
+Model::~Model() {
+    std::vector<hipStream_t> closed;            // EMULATED shards share one stream
+    for (auto &s : shards) {
+        (void)hipSetDevice(s.device);
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        if (s.comm) ncclCommDestroy(s.comm);
+        for (void *p : s.allocs) (void)hipFree(p);
+        if (s.stream && std::find(closed.begin(), closed.end(), s.stream) == closed.end()) {
+            closed.push_back(s.stream);
+            (void)hipStreamDestroy(s.stream);
+        }
+    }
+    if (emu_ptrs) (void)hipFree(emu_ptrs);
+    if (host_logits) (void)hipHostFree(host_logits);
+    if (host_tokens) (void)hipHostFree(host_tokens);
+    for (auto &r : prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+}
+
+Cache::~Cache() {
+    if (!m) return;
+    for (size_t i = 0; i < shards.size(); i++) {
+        (void)hipSetDevice(m->shards[i].device);
+        (void)hipStreamSynchronize(m->shards[i].stream);
+        if (shards[i].graph) (void)hipGraphExecDestroy(shards[i].graph);
+        for (void *p : shards[i].allocs) (void)hipFree(p);
+    }
+}
+
+// ------------------------------------------------------------------------------- weight build
+struct Stager {                      // brings a source tensor to a device (whole), reusing one buffer
+    int device; void *buf = nullptr; size_t cap = 0;
+    explicit Stager(int dev) : device(dev) {}
+    ~Stager() { if (buf) { (void)hipSetDevice(device); (void)hipFree(buf); } }
+    int get(const fl_tensor &t, size_t bytes, const void **out) {
+        if (t.device == device) { *out = t.data; return FL_OK; }
+        if (bytes > cap) {
+            if (buf) { FL_HIP(hipFree(buf)); buf = nullptr; cap = 0; }
+            FL_HIP(hipMalloc(&buf, bytes)); cap = bytes;
+        }
+        FL_HIP(hipMemcpy(buf, t.data, bytes, hipMemcpyDefault));
+        *out = buf;
+        return FL_OK;
+    }
+};
+
+static size_t dtype_size(int dt) { return dt == FL_DTYPE_F32 ? 4 : 2; }
+
+struct Builder {
+    Model *m;
+    std::unordered_map<std::string, const fl_tensor *> map;
+    const fl_tensor *find(const std::string &name) const {
+        auto it = map.find(name); return it == map.end() ? nullptr : it->second;
+    }
+    int want(const std::string &name, int64_t R, int64_t C, const fl_tensor **out) const {
+        const fl_tensor *t = find(name);
+        if (!t) FL_FAIL(FL_ERR_MISSING_TENSOR, "cannot find tensor %s", name.c_str());
+        if (t->dtype < FL_DTYPE_F32 || t->dtype > FL_DTYPE_F16) FL_FAIL(FL_ERR_UNSUPPORTED, "tensor %s: unsupported dtype %d", name.c_str(), t->dtype);
+        bool ok = (C == 1 && t->ndim == 1) ? t->shape[0] == R : (t->ndim == 2 && t->shape[0] == R && t->shape[1] == C);
+        if (!ok) FL_FAIL(FL_ERR_SHAPE_MISMATCH, "shape mismatch for %s: expected [%lld,%lld]", name.c_str(), (long long)R, (long long)C);
+        if (!t->data) FL_FAIL(FL_ERR_BAD_ARGUMENT, "tensor %s has null data", name.c_str());
+        *out = t; return FL_OK;
+    }
+};
+
+// Copy slice [r0,r1) x [c0,c1) of tensor `name` (full shape R x C) into dst (ld = dst_ld) on every
+// shard that lives on st.device; dst_of(shard) gives the destination base, row_mode the row map.
+template <typename DstFn>
+static int put_matrix(Builder &B, Stager &st, const std::string &name, int64_t R, int64_t C, int dst_dtype,
+                      int64_t dst_ld, int64_t dst_row0, int row_mode, DstFn dst_of) {
+    Model *m = B.m;
+    const fl_tensor *t = nullptr;
+    FL_TRY(B.want(name, R, C, &t));
+    const void *src = nullptr;
+    FL_TRY(st.get(*t, (size_t)R * C * dtype_size(t->dtype), &src));
+    for (auto &sh : m->shards) {
+        if (sh.device != st.device) continue;
+        int64_t sl[4];
+        FL_TRY(tp_slice(m->D, name.c_str(), sh.rank, m->tp, sl));
+        Launcher L; L.stream = sh.stream;
+        FL_TRY(launch_convert_slice(L, t->dtype, src, C, sl[0], sl[2], sl[1] - sl[0], sl[3] - sl[2], dst_dtype,
+                                    dst_of(sh), dst_ld, dst_row0, row_mode));
+    }
+    FL_HIP(hipDeviceSynchronize());       // the staging buffer is reused by the next tensor
+    return FL_OK;
+}
+
+static int build_weights(Builder &B) {
+    Model *m = B.m;
+    const Dims &D = m->D;
+    const int wdt = m->dtype;
+    const size_t es = m->esize();
+    std::vector<int> devices;
+    for (auto &sh : m->shards) if (std::find(devices.begin(), devices.end(), sh.device) == devices.end()) devices.push_back(sh.device);
+
+    // allocate
+    for (auto &sh : m->shards) {
+        FL_HIP(hipSetDevice(sh.device));
+        const int64_t nq = (sh.Hs + 2 * sh.Hkvs) * D.d;
+        FL_TRY(dev_alloc(sh.allocs, &sh.embed, (size_t)D.V * D.h * es, &m->hbm_bytes));
+        FL_TRY(dev_alloc(sh.allocs, (void **)&sh.norm, (size_t)D.h * 4, &m->hbm_bytes));
+        FL_TRY(dev_alloc(sh.allocs, &sh.lm_head, (size_t)sh.Vs * D.h * es, &m->hbm_bytes));
+        sh.layers.resize(D.L);
+        for (auto &ly : sh.layers) {
+            FL_TRY(dev_alloc(sh.allocs, &ly.wqkv, (size_t)nq * D.h * es, &m->hbm_bytes));
+            if (D.qkv_bias) FL_TRY(dev_alloc(sh.allocs, (void **)&ly.bqkv, (size_t)nq * 4, &m->hbm_bytes));
+            FL_TRY(dev_alloc(sh.allocs, &ly.wo, (size_t)D.h * sh.Hs * D.d * es, &m->hbm_bytes));
+            FL_TRY(dev_alloc(sh.allocs, &ly.wgu, (size_t)2 * sh.Ip * D.h * es, &m->hbm_bytes));
+            FL_TRY(dev_alloc(sh.allocs, &ly.wd, (size_t)D.h * sh.Ip * es, &m->hbm_bytes));
+            FL_TRY(dev_alloc(sh.allocs, (void **)&ly.ln1, (size_t)D.h * 4, &m->hbm_bytes));
+            FL_TRY(dev_alloc(sh.allocs, (void **)&ly.ln2, (size_t)D.h * 4, &m->hbm_bytes));
+            if (sh.Ip != sh.Is) {            // zero padding rows/cols so they contribute nothing
+                FL_HIP(hipMemsetAsync(ly.wgu, 0, (size_t)2 * sh.Ip * D.h * es, sh.stream));
+                FL_HIP(hipMemsetAsync(ly.wd, 0, (size_t)D.h * sh.Ip * es, sh.stream));
+            }
+        }
+        FL_HIP(hipStreamSynchronize(sh.stream));
+    }
+
+    const bool has_lm_head = B.find("lm_head.weight") != nullptr;
+    if (!has_lm_head && D.family != FL_FAMILY_QWEN2) FL_FAIL(FL_ERR_MISSING_TENSOR, "cannot find tensor lm_head.weight");
+
+    for (int dev : devices) {
+        FL_HIP(hipSetDevice(dev));
+        Stager st(dev);
+        FL_TRY(put_matrix(B, st, "model.embed_tokens.weight", D.V, D.h, wdt, D.h, 0, 0, [](Shard &s) { return s.embed; }));
+        FL_TRY(put_matrix(B, st, "model.norm.weight", D.h, 1, FL_DTYPE_F32, 1, 0, 0, [](Shard &s) { return (void *)s.norm; }));
+        if (has_lm_head) {
+            FL_TRY(put_matrix(B, st, "lm_head.weight", D.V, D.h, wdt, D.h, 0, 0, [](Shard &s) { return s.lm_head; }));
+        } else {
+            // candle qwen2 falls back to the embedding matrix when lm_head.weight is absent (App. A.1)
+            const fl_tensor *t = nullptr; const void *src = nullptr;
+            FL_TRY(B.want("model.embed_tokens.weight", D.V, D.h, &t));
+            FL_TRY(st.get(*t, (size_t)D.V * D.h * dtype_size(t->dtype), &src));
+            for (auto &sh : m->shards) {
+                if (sh.device != dev) continue;
+                Launcher L; L.stream = sh.stream;
+                FL_TRY(launch_convert_slice(L, t->dtype, src, D.h, sh.v0, 0, sh.Vs, D.h, wdt, sh.lm_head, D.h, 0, 0));
+            }
+            FL_HIP(hipDeviceSynchronize());
+        }
+        for (int64_t l = 0; l < D.L; l++) {
+            const std::string p = "model.layers." + std::to_string(l) + ".";
+            auto LY = [l](Shard &s) -> LayerW & { return s.layers[l]; };
+            const int64_t qd = D.H * D.d, kvd = D.Hkv * D.d;
+            // fused q|k|v: destination row offsets inside the shard's fused matrix
+            struct { const char *nm; int64_t R; int which; } qkv[3] = {{"self_attn.q_proj", qd, 0}, {"self_attn.k_proj", kvd, 1}, {"self_attn.v_proj", kvd, 2}};
+            for (auto &e : qkv) {
+                // all local shards have equal Hs / Hkvs, so the row offset is shard-independent
+                const Shard &s0 = m->shards[0];
+                const int64_t off = e.which == 0 ? 0 : (e.which == 1 ? s0.Hs * D.d : (s0.Hs + s0.Hkvs) * D.d);
+                FL_TRY(put_matrix(B, st, p + e.nm + ".weight", e.R, D.h, wdt, D.h, off, 0, [&](Shard &s) { return LY(s).wqkv; }));
+                if (D.qkv_bias)
+                    FL_TRY(put_matrix(B, st, p + e.nm + ".bias", e.R, 1, FL_DTYPE_F32, 1, off, 0, [&](Shard &s) { return (void *)LY(s).bqkv; }));
+            }
+            FL_TRY(put_matrix(B, st, p + "self_attn.o_proj.weight", D.h, qd, wdt, m->shards[0].Hs * D.d, 0, 0, [&](Shard &s) { return LY(s).wo; }));
+            FL_TRY(put_matrix(B, st, p + "mlp.gate_proj.weight", D.inter, D.h, wdt, D.h, 0, 1, [&](Shard &s) { return LY(s).wgu; }));
+            FL_TRY(put_matrix(B, st, p + "mlp.up_proj.weight", D.inter, D.h, wdt, D.h, 0, 2, [&](Shard &s) { return LY(s).wgu; }));
+            FL_TRY(put_matrix(B, st, p + "mlp.down_proj.weight", D.h, D.inter, wdt, m->shards[0].Ip, 0, 0, [&](Shard &s) { return LY(s).wd; }));
+            FL_TRY(put_matrix(B, st, p + "input_layernorm.weight", D.h, 1, FL_DTYPE_F32, 1, 0, 0, [&](Shard &s) { return (void *)LY(s).ln1; }));
+            FL_TRY(put_matrix(B, st, p + "post_attention_layernorm.weight", D.h, 1, FL_DTYPE_F32, 1, 0, 0, [&](Shard &s) { return (void *)LY(s).ln2; }));
+        }
+    }
+    return FL_OK;
+}
+
+// RoPE tables (App. A.4): inv_freq[j] = 1 / theta^(2j/d) in fp32; angle = p * inv_freq[j] (fp32
+// product); cos/sin in fp32.  Built once on the host, one copy per shard.
+static int build_rope(Model *m) {
+    const Dims &D = m->D;
+    const int64_t half = D.d / 2;
+    std::vector<float> inv(half), c((size_t)D.max_pos * half), s((size_t)D.max_pos * half);
+    const float theta = (float)D.theta;
+    for (int64_t j = 0; j < half; j++) inv[j] = 1.0f / powf(theta, (float)(2 * j) / (float)D.d);
+    for (int64_t p = 0; p < D.max_pos; p++)
+        for (int64_t j = 0; j < half; j++) {
+            const float ang = (float)p * inv[j];
+            c[(size_t)p * half + j] = cosf(ang);
+            s[(size_t)p * half + j] = sinf(ang);
+        }
+    for (auto &sh : m->shards) {
+        FL_HIP(hipSetDevice(sh.device));
+        FL_TRY(dev_alloc(sh.allocs, (void **)&sh.cos_tab, c.size() * 4, &m->hbm_bytes));
+        FL_TRY(dev_alloc(sh.allocs, (void **)&sh.sin_tab, s.size() * 4, &m->hbm_bytes));
+        FL_HIP(hipMemcpy(sh.cos_tab, c.data(), c.size() * 4, hipMemcpyHostToDevice));
+        FL_HIP(hipMemcpy(sh.sin_tab, s.data(), s.size() * 4, hipMemcpyHostToDevice));
+    }
+    return FL_OK;
+}
+
+static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T) {
+    const Dims &D = m->D;
+    const size_t es = m->esize();
+    const int64_t nq = (sh.Hs + 2 * sh.Hkvs) * D.d;
+    // grow-only; the previous buffers stay owned by the shard until the model dies (rare path)
+    sc.cap_T = T;
+    FL_TRY(dev_alloc(sh.allocs, (void **)&sc.x_res, (size_t)T * D.h * 4, &m->hbm_bytes));
+    FL_TRY(dev_alloc(sh.allocs, (void **)&sc.delta, (size_t)T * D.h * 4, &m->hbm_bytes));
+    FL_TRY(dev_alloc(sh.allocs, &sc.xn, (size_t)T * D.h * es, &m->hbm_bytes));
+    FL_TRY(dev_alloc(sh.allocs, (void **)&sc.qkv, (size_t)T * nq * 4, &m->hbm_bytes));
+    FL_TRY(dev_alloc(sh.allocs, &sc.q, (size_t)T * sh.Hs * D.d * es, &m->hbm_bytes));
+    FL_TRY(dev_alloc(sh.allocs, &sc.ao, (size_t)T * sh.Hs * D.d * es, &m->hbm_bytes));
+    FL_TRY(dev_alloc(sh.allocs, &sc.act, (size_t)T * sh.Ip * es, &m->hbm_bytes));
+    FL_TRY(dev_alloc(sh.allocs, (void **)&sc.ids, (size_t)T * 4, &m->hbm_bytes));
+    return FL_OK;
+}
+
+int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int compute_dtype,
+                 const fl_parallel *par, Model **out) {
+    if (!out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null out pointer");
+    if (!tensors && n) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null tensors");
+    if (compute_dtype != FL_DTYPE_BF16 && compute_dtype != FL_DTYPE_F32)
+        FL_FAIL(FL_ERR_UNSUPPORTED, "compute dtype must be BF16 (reference default, main.rs:120) or F32");
+    Dims D;
+    FL_TRY(resolve_config(cfg, &D));
+    if (D.h % 8) FL_FAIL(FL_ERR_UNSUPPORTED, "hidden_size must be a multiple of 8 (16-byte rows)");
+    if (D.d != 64 && D.d != 128) FL_FAIL(FL_ERR_UNSUPPORTED, "head_dim %lld not supported (64 or 128)", (long long)D.d);
+    if (D.max_pos > (1 << 20)) D.max_pos = 1 << 20;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        FL_FAIL(FL_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU path");
+
+    fl_parallel P{};
+    if (par) P = *par;
+    if (P.mode == FL_TP_NONE) { P.tp_size = 1; P.tp_rank = 0; }
+    if (P.tp_size < 1) FL_FAIL(FL_ERR_BAD_ARGUMENT, "tp_size must be >= 1");
+    const int tp = P.tp_size;
+    if (D.H % tp || D.Hkv % tp || D.inter % tp)
+        FL_FAIL(FL_ERR_UNSUPPORTED, "tp=%d must divide heads %lld, kv heads %lld and intermediate %lld", tp,
+                (long long)D.H, (long long)D.Hkv, (long long)D.inter);
+
+    std::unique_ptr<Model> m(new Model());
+    m->D = D; m->dtype = compute_dtype; m->tp = tp; m->tp_mode = P.mode;
+    m->vocab_parallel = tp > 1 && D.V % tp == 0;
+    m->cfg_resolved = *cfg;
+    m->cfg_resolved.num_key_value_heads = D.Hkv; m->cfg_resolved.rope_theta = D.theta;
+    m->cfg_resolved.max_position_embeddings = D.max_pos; m->cfg_resolved.sliding_window = D.window;
+    m->use_graph = env_int("FL_GRAPH", 1) != 0;
+
+    auto dev_of = [&](int i) -> int { return (P.device_ids && i < P.n_device_ids) ? P.device_ids[i] : i; };
+    int nlocal = 1;
+    if (P.mode == FL_TP_SINGLE_PROCESS || P.mode == FL_TP_EMULATED) nlocal = tp;
+    m->shards.resize(nlocal);
+    for (int i = 0; i < nlocal; i++) {
+        Shard &sh = m->shards[i];
+        switch (P.mode) {
+            case FL_TP_NONE: sh.rank = 0; sh.device = P.device_ids && P.n_device_ids > 0 ? P.device_ids[0] : 0; break;
+            case FL_TP_SINGLE_PROCESS: sh.rank = i; sh.device = dev_of(i); break;
+            case FL_TP_MULTI_PROCESS: sh.rank = P.tp_rank; sh.device = P.device_ids && P.n_device_ids > 0 ? P.device_ids[0] : 0; break;
+            case FL_TP_EMULATED: sh.rank = i; sh.device = P.device_ids && P.n_device_ids > 0 ? P.device_ids[0] : 0; break;
+            default: FL_FAIL(FL_ERR_BAD_ARGUMENT, "unknown tp mode %d", P.mode);
+        }
+        if (sh.rank < 0 || sh.rank >= tp) FL_FAIL(FL_ERR_BAD_ARGUMENT, "tp_rank %d out of range", sh.rank);
+        if (sh.device < 0 || sh.device >= ndev) FL_FAIL(FL_ERR_NO_DEVICE, "device %d not present (%d visible)", sh.device, ndev);
+        sh.Hs = D.H / tp; sh.Hkvs = D.Hkv / tp; sh.Is = D.inter / tp; sh.Ip = (sh.Is + 15) / 16 * 16;
+        sh.Vs = m->vocab_parallel ? D.V / tp : D.V; sh.v0 = m->vocab_parallel ? sh.Vs * sh.rank : 0;
+        FL_HIP(hipSetDevice(sh.device));
+        if (P.mode == FL_TP_EMULATED && i > 0) sh.stream = m->shards[0].stream;     // one stream: sequential
+        else FL_HIP(hipStreamCreateWithFlags(&sh.stream, hipStreamNonBlocking));
+    }
+    {   // is it a gfx950?
+        hipDeviceProp_t prop;
+        FL_HIP(hipGetDeviceProperties(&prop, m->shards[0].device));
+        if (!strstr(prop.gcnArchName, "gfx950") && !env_int("FL_ALLOW_ANY_ARCH", 0))
+            FL_FAIL(FL_ERR_NO_DEVICE, "device is %s; this library is built for gfx950 only", prop.gcnArchName);
+    }
+
+    Builder B; B.m = m.get();
+    for (size_t i = 0; i < n; i++) {
+        if (!tensors[i].name) FL_FAIL(FL_ERR_BAD_ARGUMENT, "tensor %zu has no name", i);
+        B.map[tensors[i].name] = &tensors[i];
+    }
+    FL_TRY(build_weights(B));
+    FL_TRY(build_rope(m.get()));
+    for (auto &sh : m->shards) {
+        FL_HIP(hipSetDevice(sh.device));
+        FL_TRY(alloc_scratch(m.get(), sh, sh.dec, 1));
+        FL_TRY(dev_alloc(sh.allocs, (void **)&sh.logits_local, (size_t)sh.Vs * 4, &m->hbm_bytes));
+        FL_TRY(dev_alloc(sh.allocs, (void **)&sh.logits_full, (size_t)D.V * 4, &m->hbm_bytes));
+    }
+    FL_HIP(hipSetDevice(m->shards[0].device));
+    FL_HIP(hipHostMalloc((void **)&m->host_logits, (size_t)D.V * 4, hipHostMallocDefault));
+    FL_HIP(hipHostMalloc((void **)&m->host_tokens, kOutTokensCap * 4, hipHostMallocDefault));
+
+    // communicators
+    if (tp > 1 && P.mode == FL_TP_SINGLE_PROCESS) {
+        std::vector<int> devs; for (auto &sh : m->shards) devs.push_back(sh.device);
+        std::vector<ncclComm_t> comms(tp);
+        FL_NCCL(ncclCommInitAll(comms.data(), tp, devs.data()));
+        for (int i = 0; i < tp; i++) m->shards[i].comm = comms[i];
+    } else if (tp > 1 && P.mode == FL_TP_MULTI_PROCESS) {
+        if (!P.unique_id) FL_FAIL(FL_ERR_BAD_ARGUMENT, "FL_TP_MULTI_PROCESS needs a unique_id");
+        ncclUniqueId id; memcpy(&id, P.unique_id, sizeof id);
+        FL_HIP(hipSetDevice(m->shards[0].device));
+        FL_NCCL(ncclCommInitRank(&m->shards[0].comm, tp, id, P.tp_rank));
+    } else if (tp > 1 && P.mode == FL_TP_EMULATED) {
+        FL_HIP(hipMalloc((void **)&m->emu_ptrs, sizeof(float *) * tp * 2));
+    } else if (tp > 1) {
+        FL_FAIL(FL_ERR_BAD_ARGUMENT, "tp_size %d needs a tensor-parallel mode", tp);
+    }
+    *out = m.release();
+    return FL_OK;
+}
+
+// ------------------------------------------------------------------------------- cache
+int cache_create(Model *m, size_t max_seq, Cache **out) {
+    if (!m || !out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+    if (max_seq == 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "max_seq must be > 0");
+    const Dims &D = m->D;
+    std::unique_ptr<Cache> c(new Cache());
+    c->m = m; c->max_seq = max_seq; c->len = 0;
+    // split-S: ~64 keys per workgroup at full length, at most ~512 workgroups per launch
+    int64_t ns = (int64_t)((max_seq + 63) / 64);
+    int64_t cap = std::max<int64_t>(1, 512 / std::max<int64_t>(1, m->shards[0].Hkvs));
+    c->nsplit = (int)std::max<int64_t>(1, std::min(ns, cap));
+    c->nsplit = env_int("FL_ATTN_NSPLIT", c->nsplit);
+    c->shards.resize(m->shards.size());
+    for (size_t i = 0; i < m->shards.size(); i++) {
+        Shard &sh = m->shards[i]; CacheShard &cs = c->shards[i];
+        FL_HIP(hipSetDevice(sh.device));
+        const size_t kvb = (size_t)D.L * sh.Hkvs * max_seq * D.d * m->esize();
+        FL_TRY(dev_alloc(cs.allocs, &cs.k, kvb, nullptr));
+        FL_TRY(dev_alloc(cs.allocs, &cs.v, kvb, nullptr));
+        FL_TRY(dev_alloc(cs.allocs, (void **)&cs.st, sizeof(StepState), nullptr));
+        FL_TRY(dev_alloc(cs.allocs, (void **)&cs.out_tokens, kOutTokensCap * 4, nullptr));
+        FL_TRY(dev_alloc(cs.allocs, (void **)&cs.part_m, (size_t)sh.Hs * c->nsplit * 4, nullptr));
+        FL_TRY(dev_alloc(cs.allocs, (void **)&cs.part_l, (size_t)sh.Hs * c->nsplit * 4, nullptr));
+        FL_TRY(dev_alloc(cs.allocs, (void **)&cs.part_o, (size_t)sh.Hs * c->nsplit * D.d * 4, nullptr));
+        FL_HIP(hipMemset(cs.st, 0, sizeof(StepState)));
+    }
+    m->refs.fetch_add(1);
+    *out = c.release();
+    return FL_OK;
+}
+
+// ------------------------------------------------------------------------------- forward
+__global__ void set_state_kernel(StepState *st, uint32_t token, uint32_t pos, uint32_t len, uint32_t step, int32_t eos) {
+    st->token = token; st->pos = pos; st->len = len; st->step = step; st->eos = eos; st->done = 0;
+}
+
+static Launcher make_launcher(Model *m, Shard &sh) {
+    Launcher L; L.stream = sh.stream; L.prof = m->profiling ? &m->prof : nullptr; return L;
+}
+
+// all-reduce(sum) of each local shard's `delta` [count] fp32 (after o_proj / down_proj rows)
+static int all_reduce_delta(Model *m, bool pre, int64_t count) {
+    if (m->tp == 1) return FL_OK;
+    if (m->tp_mode == FL_TP_EMULATED) {
+        std::vector<float *> ptrs;
+        for (auto &sh : m->shards) ptrs.push_back(pre ? sh.pre.delta : sh.dec.delta);
+        Shard &s0 = m->shards[0];
+        FL_HIP(hipSetDevice(s0.device));
+        float **tab = m->emu_ptrs + (pre ? m->tp : 0);
+        FL_HIP(hipMemcpyAsync(tab, ptrs.data(), sizeof(float *) * m->tp, hipMemcpyHostToDevice, s0.stream));
+        FL_HIP(hipStreamSynchronize(s0.stream));          // ptrs is a stack vector
+        Launcher L = make_launcher(m, s0);
+        return launch_reduce_shards(L, tab, m->tp, count);
+    }
+    FL_NCCL(ncclGroupStart());
+    for (auto &sh : m->shards) {
+        float *buf = pre ? sh.pre.delta : sh.dec.delta;
+        FL_NCCL(ncclAllReduce(buf, buf, (size_t)count, ncclFloat, ncclSum, sh.comm, sh.stream));
+    }
+    FL_NCCL(ncclGroupEnd());
+    return FL_OK;
+}
+
+static int gather_logits(Model *m) {
+    const Dims &D = m->D;
+    if (!m->vocab_parallel) {
+        for (auto &sh : m->shards) {
+            FL_HIP(hipSetDevice(sh.device));
+            FL_HIP(hipMemcpyAsync(sh.logits_full, sh.logits_local, (size_t)D.V * 4, hipMemcpyDeviceToDevice, sh.stream));
+        }
+        return FL_OK;
+    }
+    if (m->tp_mode == FL_TP_EMULATED) {
+        Shard &s0 = m->shards[0];
+        FL_HIP(hipSetDevice(s0.device));
+        for (auto &dst : m->shards)
+            for (auto &src : m->shards)
+                FL_HIP(hipMemcpyAsync(dst.logits_full + src.v0, src.logits_local, (size_t)src.Vs * 4, hipMemcpyDeviceToDevice, s0.stream));
+        return FL_OK;
+    }
+    FL_NCCL(ncclGroupStart());
+    for (auto &sh : m->shards)
+        FL_NCCL(ncclAllGather(sh.logits_local, sh.logits_full, (size_t)sh.Vs, ncclFloat, sh.comm, sh.stream));
+    FL_NCCL(ncclGroupEnd());
+    return FL_OK;
+}
+
+// Enqueue one forward over T tokens on every local shard.  The step state (pos, len, token) of the
+// cache must already be set on the device.  ids_dev == null: the single token comes from the state.
+static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_scratch, int64_t len_hint) {
+    const Dims &D = m->D;
+    const int dt = m->dtype;
+    const size_t ns = m->shards.size();
+    auto SC = [&](Shard &sh) -> Scratch & { return pre ? sh.pre : sh.dec; };
+    for (size_t i = 0; i < ns; i++) {
+        Shard &sh = m->shards[i]; Scratch &sc = SC(sh);
+        FL_HIP(hipSetDevice(sh.device));
+        Launcher L = make_launcher(m, sh);
+        FL_TRY(launch_embed(L, dt, sh.embed, ids_in_scratch ? sc.ids : nullptr, c->shards[i].st, sc.x_res, T, D.h));
+    }
+    for (int64_t l = 0; l < D.L; l++) {
+        for (size_t i = 0; i < ns; i++) {
+            Shard &sh = m->shards[i]; Scratch &sc = SC(sh); CacheShard &cs = c->shards[i]; LayerW &ly = sh.layers[l];
+            FL_HIP(hipSetDevice(sh.device));
+            Launcher L = make_launcher(m, sh);
+            const int64_t nq = (sh.Hs + 2 * sh.Hkvs) * D.d;
+            const size_t kv_layer = (size_t)l * sh.Hkvs * c->max_seq * D.d * m->esize();
+            void *kc = (char *)cs.k + kv_layer, *vc = (char *)cs.v + kv_layer;
+            FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, l == 0 ? nullptr : sc.delta, ly.ln1, D.eps, sc.xn, T, D.h));
+            FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, ly.bqkv, sc.qkv, T, nq, D.h, EPI_F32));
+            FL_TRY(launch_rope_kv(L, dt, sc.qkv, cs.st, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, kc, vc, T, sh.Hs, sh.Hkvs, D.d, (int64_t)c->max_seq));
+            if (T == 1) {
+                AttnScratch as{cs.part_m, cs.part_l, cs.part_o, c->nsplit, len_hint + 1};
+                FL_TRY(launch_attn_decode(L, dt, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->max_seq, D.scale));
+            } else {
+                FL_TRY(launch_attn_prefill(L, dt, sc.q, kc, vc, cs.st, sc.ao, T, sh.Hs, sh.Hkvs, D.d, (int64_t)c->max_seq, D.scale, D.window));
+            }
+            FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, T, D.h, sh.Hs * D.d, EPI_F32));
+        }
+        FL_TRY(all_reduce_delta(m, pre, T * D.h));
+        for (size_t i = 0; i < ns; i++) {
+            Shard &sh = m->shards[i]; Scratch &sc = SC(sh); LayerW &ly = sh.layers[l];
+            FL_HIP(hipSetDevice(sh.device));
+            Launcher L = make_launcher(m, sh);
+            FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, sc.delta, ly.ln2, D.eps, sc.xn, T, D.h));
+            FL_TRY(launch_linear(L, dt, ly.wgu, sc.xn, nullptr, sc.act, T, 2 * sh.Ip, D.h, EPI_GATEUP));
+            FL_TRY(launch_linear(L, dt, ly.wd, sc.act, nullptr, sc.delta, T, D.h, sh.Ip, EPI_F32));
+        }
+        FL_TRY(all_reduce_delta(m, pre, T * D.h));
+    }
+    // narrow(1, T-1, 1) -> final norm -> lm_head on the last position only (K12)
+    for (size_t i = 0; i < ns; i++) {
+        Shard &sh = m->shards[i]; Scratch &sc = SC(sh);
+        FL_HIP(hipSetDevice(sh.device));
+        Launcher L = make_launcher(m, sh);
+        float *xl = sc.x_res + (size_t)(T - 1) * D.h, *dl = sc.delta + (size_t)(T - 1) * D.h;
+        void *xnl = (char *)sc.xn + (size_t)(T - 1) * D.h * m->esize();
+        FL_TRY(launch_rmsnorm_add(L, dt, xl, dl, sh.norm, D.eps, xnl, 1, D.h));
+        FL_TRY(launch_linear(L, dt, sh.lm_head, xnl, nullptr, sh.logits_local, 1, sh.Vs, D.h, EPI_F32));
+    }
+    FL_TRY(gather_logits(m));
+    return FL_OK;
+}
+
+static int set_state(Model *m, Cache *c, uint32_t token, size_t pos, size_t len, uint32_t step, int64_t eos) {
+    for (size_t i = 0; i < m->shards.size(); i++) {
+        Shard &sh = m->shards[i];
+        FL_HIP(hipSetDevice(sh.device));
+        hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, sh.stream, c->shards[i].st, token, (uint32_t)pos,
+                           (uint32_t)len, step, (int32_t)eos);
+        FL_HIP(hipGetLastError());
+    }
+    return FL_OK;
+}
+
+static int enqueue_argmax(Model *m, Cache *c, int advance) {
+    for (size_t i = 0; i < m->shards.size(); i++) {
+        Shard &sh = m->shards[i];
+        FL_HIP(hipSetDevice(sh.device));
+        Launcher L = make_launcher(m, sh);
+        FL_TRY(launch_argmax_advance(L, sh.logits_full, m->D.V, c->shards[i].st, c->shards[i].out_tokens, advance));
+    }
+    return FL_OK;
+}
+
+static int sync_all(Model *m) {
+    for (auto &sh : m->shards) { FL_HIP(hipSetDevice(sh.device)); FL_HIP(hipStreamSynchronize(sh.stream)); }
+    return FL_OK;
+}
+
+// One decode step (embed .. lm_head .. argmax+advance) reading everything from the device state.
+// Single-shard models replay it as a hipGraph (the ~11 launches per layer are launch-bound at
+// TinyLlama scale); captured lazily on the second step of a cache so that all lazy module /
+// attribute initialisation has already happened eagerly.
+static int decode_step(Model *m, Cache *c, int64_t len_hint) {
+    const bool graphable = m->use_graph && !m->profiling && m->shards.size() == 1 && m->tp == 1 && !c->graph_failed;
+    if (graphable && c->shards[0].graph) {
+        FL_HIP(hipSetDevice(m->shards[0].device));
+        FL_HIP(hipGraphLaunch(c->shards[0].graph, m->shards[0].stream));
+        return FL_OK;
+    }
+    if (graphable && c->warm_steps >= 1) {
+        Shard &sh = m->shards[0];
+        FL_HIP(hipSetDevice(sh.device));
+        hipGraph_t g = nullptr;
+        bool ok = hipStreamBeginCapture(sh.stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        int rc = FL_OK;
+        if (ok) {
+            rc = enqueue_forward(m, c, false, 1, false, len_hint);
+            if (rc == FL_OK) rc = enqueue_argmax(m, c, 1);
+            hipError_t e = hipStreamEndCapture(sh.stream, &g);
+            ok = rc == FL_OK && e == hipSuccess && g != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&c->shards[0].graph, g, nullptr, nullptr, 0) == hipSuccess;
+        if (g) (void)hipGraphDestroy(g);
+        if (ok) {
+            FL_HIP(hipGraphLaunch(c->shards[0].graph, sh.stream));
+            return FL_OK;
+        }
+        (void)hipGetLastError();
+        c->graph_failed = true; c->shards[0].graph = nullptr;      // fall through to eager launches
+    }
+    FL_TRY(enqueue_forward(m, c, false, 1, false, len_hint));
+    FL_TRY(enqueue_argmax(m, c, 1));
+    c->warm_steps++;
+    return FL_OK;
+}
+
+static int check_call(Model *m, Cache *c, size_t T, size_t pos) {
+    if (!m || !c) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null model or cache");
+    if (c->m != m) FL_FAIL(FL_ERR_BAD_ARGUMENT, "cache belongs to another model");
+    if (T == 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "empty input");
+    if (c->len + T > c->max_seq) FL_FAIL(FL_ERR_SEQ_OVERFLOW, "sequence overflow: %zu cached + %zu new > capacity %zu", c->len, T, c->max_seq);
+    if (pos + T > (size_t)m->D.max_pos) FL_FAIL(FL_ERR_SEQ_OVERFLOW, "position %zu exceeds max_position_embeddings %lld", pos + T, (long long)m->D.max_pos);
+    return FL_OK;
+}
+
+int forward(Model *m, Cache *c, const uint32_t *ids, size_t T, size_t pos, float *logits_out, uint32_t *token_out) {
+    FL_TRY(check_call(m, c, T, pos));
+    if (!ids) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null ids");
+    for (size_t t = 0; t < T; t++)
+        if ((int64_t)ids[t] >= m->D.V) FL_FAIL(FL_ERR_BAD_ARGUMENT, "token id %u out of range (vocab %lld)", ids[t], (long long)m->D.V);
+    std::lock_guard<std::mutex> lock(m->mu);
+    const Dims &D = m->D;
+    if (T == 1) {
+        FL_TRY(set_state(m, c, ids[0], pos, c->len, 0, -1));
+        FL_TRY(decode_step(m, c, (int64_t)c->len));
+        c->len += 1;
+    } else {
+        const int64_t chunk_max = env_int("FL_PREFILL_CHUNK", 8192);
+        size_t done = 0;
+        while (done < T) {
+            const int64_t Tc = (int64_t)std::min<size_t>(T - done, (size_t)chunk_max);
+            for (auto &sh : m->shards) {
+                FL_HIP(hipSetDevice(sh.device));
+                if (sh.pre.cap_T < Tc) FL_TRY(alloc_scratch(m, sh, sh.pre, Tc));
+                FL_HIP(hipMemcpyAsync(sh.pre.ids, ids + done, (size_t)Tc * 4, hipMemcpyHostToDevice, sh.stream));
+            }
+            FL_TRY(set_state(m, c, ids[done], pos + done, c->len, 0, -1));
+            if (Tc == 1) {
+                // a 1-token tail chunk goes through the decode kernels but is still one `forward`
+                FL_TRY(enqueue_forward(m, c, false, 1, false, (int64_t)c->len));
+            } else {
+                FL_TRY(enqueue_forward(m, c, true, Tc, true, (int64_t)c->len));
+            }
+            c->len += (size_t)Tc;
+            done += (size_t)Tc;
+        }
+        FL_TRY(enqueue_argmax(m, c, 0));
+    }
+    Shard &s0 = m->shards[0];
+    FL_HIP(hipSetDevice(s0.device));
+    if (logits_out) FL_HIP(hipMemcpyAsync(m->host_logits, s0.logits_full, (size_t)D.V * 4, hipMemcpyDeviceToHost, s0.stream));
+    if (token_out) FL_HIP(hipMemcpyAsync(m->host_tokens, c->shards[0].out_tokens, 4, hipMemcpyDeviceToHost, s0.stream));
+    FL_TRY(sync_all(m));
+    if (logits_out) memcpy(logits_out, m->host_logits, (size_t)D.V * 4);
+    if (token_out) *token_out = m->host_tokens[0];
+    return FL_OK;
+}
+
+int decode_greedy(Model *m, Cache *c, uint32_t first, size_t pos, size_t n_steps, int64_t eos,
+                  uint32_t *tokens_out, size_t *n_out) {
+    if (n_out) *n_out = 0;
+    if (n_steps == 0) return FL_OK;
+    FL_TRY(check_call(m, c, n_steps, pos));
+    if (!tokens_out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null tokens_out");
+    if ((int64_t)first >= m->D.V) FL_FAIL(FL_ERR_BAD_ARGUMENT, "token id %u out of range", first);
+    std::lock_guard<std::mutex> lock(m->mu);
+    Shard &s0 = m->shards[0];
+    size_t done = 0;
+    uint32_t tok = first;
+    while (done < n_steps) {
+        const size_t nb = std::min(n_steps - done, kOutTokensCap);
+        FL_TRY(set_state(m, c, tok, pos + done, c->len, 0, eos));
+        for (size_t i = 0; i < nb; i++) FL_TRY(decode_step(m, c, (int64_t)(c->len + i)));
+        FL_HIP(hipSetDevice(s0.device));
+        FL_HIP(hipMemcpyAsync(m->host_tokens, c->shards[0].out_tokens, nb * 4, hipMemcpyDeviceToHost, s0.stream));
+        FL_TRY(sync_all(m));
+        for (size_t i = 0; i < nb; i++) {
+            const uint32_t t = m->host_tokens[i];
+            if (eos >= 0 && (int64_t)t == eos) {
+                // the forward that produced EOS was needed; what ran after it is discarded
+                c->len += i + 1;
+                if (n_out) *n_out = done + i;
+                return FL_OK;
+            }
+            tokens_out[done + i] = t;
+        }
+        c->len += nb;
+        tok = m->host_tokens[nb - 1];
+        done += nb;
+    }
+    if (n_out) *n_out = done;
+    return FL_OK;
+}
+
+}  // namespace fl

@@ -1,0 +1,210 @@
+/*
+ * fastllm_mi355x.h -- C ABI of the MI355X (gfx950 / CDNA4) decoder forward-pass backend
+ * for FastLLM (lukehinds/fastllm).
+ *
+ * This is the drop-in boundary for ONE hot path of the reference: the batch-1, KV-cached
+ * causal-LM forward pass behind
+ *     trait ModelInitializer { initialize_model; initialize_cache; forward }
+ *     (/root/reference/src/models/model_initializer.rs:6-22)
+ * for the three families the reference registers (LlamaWithConfig llama.rs:94-150,
+ * MistralWithConfig mistral.rs:156-237, QwenWithConfig qwen.rs:89-152).  The reference has no
+ * FFI today (no extern "C" anywhere); its arithmetic is delegated to candle.  A Rust
+ * `impl ModelInitializer for Mi355xWithConfig` binds exactly the entry points below
+ * (binding shown in INTEGRATION.md).
+ *
+ * Conventions
+ *   - every entry returns an fl_status (0 = OK, negative = error); fl_last_error() gives a
+ *     thread-local message (anyhow::Error analogue).  Nothing aborts or throws across the ABI.
+ *   - plain pointers and sizes only; opaque handles for model and cache.
+ *   - thread-safe: any number of threads may call fl_forward on ONE model with DISTINCT caches
+ *     (the reference's streaming path does that, mod.rs:137-238); submission is serialised
+ *     per model.  Every entry sets the HIP device itself.
+ *   - the library never falls back to a CPU path: without a usable gfx950 device
+ *     fl_model_create fails with FL_ERR_NO_DEVICE.
+ */
+#ifndef FASTLLM_MI355X_H
+#define FASTLLM_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FL_ABI_VERSION 1
+
+typedef enum fl_status {
+    FL_OK = 0,
+    FL_ERR_BAD_CONFIG = -1,      /* reference: assert!/expect panics, mistral.rs:109-127, qwen.rs:32-37 */
+    FL_ERR_MISSING_TENSOR = -2,  /* candle VarBuilder "cannot find tensor" */
+    FL_ERR_SHAPE_MISMATCH = -3,
+    FL_ERR_OOM = -4,
+    FL_ERR_HIP = -5,
+    FL_ERR_RCCL = -6,
+    FL_ERR_SEQ_OVERFLOW = -7,
+    FL_ERR_BAD_ARGUMENT = -8,
+    FL_ERR_NO_DEVICE = -9,
+    FL_ERR_UNSUPPORTED = -10
+} fl_status;
+
+/* ModelArchitecture::get_family (llama.rs:153, mistral.rs:240, qwen.rs:174) */
+typedef enum fl_family { FL_FAMILY_LLAMA = 0, FL_FAMILY_MISTRAL = 1, FL_FAMILY_QWEN2 = 2 } fl_family;
+
+/* candle_core::DType subset the reference can hand over (dtype_utils.rs:10-23) */
+typedef enum fl_dtype { FL_DTYPE_F32 = 0, FL_DTYPE_BF16 = 1, FL_DTYPE_F16 = 2 } fl_dtype;
+
+/* The fields of the reference's ConfigFile / BaseModelConfig (llama.rs:18-29,
+ * mistral.rs:80-92, config.rs:6-18).  A 0 in an optional field means "absent from
+ * config.json" and takes the reference's default:
+ *   num_key_value_heads  -> num_attention_heads        (llama.rs:39, mistral.rs:97, qwen.rs:45)
+ *   rope_theta           -> 10000                      (llama.rs:41, mistral.rs:137, qwen.rs:47)
+ *   max_position_embeddings -> 4096 llama / 32768 mistral, qwen (llama.rs:47, mistral.rs:138, qwen.rs:48)
+ *   sliding_window       -> 4096 mistral, qwen; unused for llama (mistral.rs:139, qwen.rs:49)
+ * head_dim is hidden_size / num_attention_heads (mistral.rs:67-76, config.rs:32-44); it is not
+ * a config field in the reference and is validated, not passed. */
+typedef struct fl_config {
+    int32_t family;                 /* fl_family */
+    int32_t qkv_bias;               /* 1 for Qwen2 (q/k/v_proj.bias tensors), else 0 */
+    int64_t hidden_size;
+    int64_t intermediate_size;
+    int64_t vocab_size;
+    int64_t num_hidden_layers;
+    int64_t num_attention_heads;
+    int64_t num_key_value_heads;
+    int64_t max_position_embeddings;
+    int64_t sliding_window;
+    double  rms_norm_eps;
+    double  rope_theta;
+} fl_config;
+
+/* One entry of initialize_model's HashMap<String, Tensor> (model_initializer.rs:12).
+ * Borrowed for the duration of fl_model_create only; the library copies, shards and
+ * re-lays-out into HBM.  `device` < 0: `data` is host memory; >= 0: `data` is a device
+ * pointer on that HIP device (the reference loads safetensors straight onto `device`,
+ * huggingface.rs:88,125). */
+typedef struct fl_tensor {
+    const char *name;               /* HF name, e.g. "model.layers.0.self_attn.q_proj.weight" */
+    int32_t dtype;                  /* fl_dtype */
+    int32_t ndim;
+    int64_t shape[4];
+    const void *data;
+    int32_t device;
+    int32_t _pad;
+} fl_tensor;
+
+/* Tensor-parallel placement.  New capability (the reference is single-device, README.md:149). */
+typedef enum fl_tp_mode {
+    FL_TP_NONE = 0,                 /* one GPU: device_ids[0] (or device 0 if NULL) */
+    FL_TP_SINGLE_PROCESS = 1,       /* this process drives tp_size GPUs (device_ids[tp_size]); the
+                                       shape of the reference's one-process server (main.rs:128) */
+    FL_TP_MULTI_PROCESS = 2,        /* one process per GPU: this process is tp_rank of tp_size and
+                                       joins the RCCL communicator named by unique_id */
+    FL_TP_EMULATED = 3              /* tp_size shards on ONE GPU, collectives done locally: lets a
+                                       single-GPU box verify the sharded kernels (tests only) */
+} fl_tp_mode;
+
+#define FL_UNIQUE_ID_BYTES 128
+typedef struct fl_parallel {
+    int32_t mode;                   /* fl_tp_mode */
+    int32_t tp_size;
+    int32_t tp_rank;                /* FL_TP_MULTI_PROCESS only */
+    int32_t n_device_ids;
+    const int32_t *device_ids;
+    const void *unique_id;          /* FL_TP_MULTI_PROCESS: FL_UNIQUE_ID_BYTES from fl_comm_unique_id */
+} fl_parallel;
+
+typedef struct fl_model fl_model;
+typedef struct fl_cache fl_cache;
+
+int         fl_abi_version(void);
+const char *fl_last_error(void);
+int         fl_device_count(int *count);
+/* ncclGetUniqueId; rank 0 calls it and ships the bytes to the other ranks out of band */
+int         fl_comm_unique_id(void *out /* FL_UNIQUE_ID_BYTES */);
+
+/* ModelInitializer::initialize_model(&Config, HashMap<String,Tensor>, DType, &Device)
+ * (model_initializer.rs:10-17; call site huggingface.rs:135).  compute_dtype: FL_DTYPE_BF16 is
+ * the reference's hard-wired dtype (main.rs:120); FL_DTYPE_F32 is the fp32 parity mode. */
+int fl_model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n_tensors,
+                    int32_t compute_dtype, const fl_parallel *par, fl_model **out);
+/* Clone for the streaming path (mod.rs:155,181,207) is a refcount bump. */
+void fl_model_retain(fl_model *m);
+void fl_model_release(fl_model *m);
+
+typedef struct fl_model_info {
+    fl_config cfg;                  /* defaults resolved */
+    int64_t head_dim;
+    int32_t compute_dtype;
+    int32_t tp_size;
+    int64_t weight_bytes_per_token; /* algorithmic HBM bytes a decode step reads from weights (whole model) */
+    int64_t kv_bytes_per_position;  /* K+V bytes one cached position adds to a decode step */
+    int64_t hbm_bytes_allocated;    /* this process, all shards */
+} fl_model_info;
+int fl_model_get_info(const fl_model *m, fl_model_info *out);
+
+/* ModelInitializer::initialize_cache(&Device, DType) (model_initializer.rs:19; per request,
+ * mod.rs:370).  The reference's version cannot see the model (hard-coded TinyLlama dims,
+ * llama.rs:125-145); here the cache is derived from the model and owned by the caller. */
+int    fl_cache_create(fl_model *m, size_t max_seq, fl_cache **out);
+void   fl_cache_reset(fl_cache *c);          /* clear_kv_cache (mistral.rs:220, qwen.rs:148) */
+size_t fl_cache_len(const fl_cache *c);
+size_t fl_cache_capacity(const fl_cache *c);
+void   fl_cache_destroy(fl_cache *c);
+
+/* ModelInitializer::forward(&self, input[1,T] u32, pos, &mut cache) -> logits
+ * (model_initializer.rs:21; call sites mod.rs:402-405,446-451).
+ *   ids[T]      token ids (batch is always 1, mod.rs:283-291)
+ *   pos         RoPE offset of ids[0].  Keys/values are APPENDED at fl_cache_len (candle's
+ *               Tensor::cat), so a caller that passes the reference's call counter for
+ *               Mistral/Qwen (mistral.rs:226,234) gets the reference's results.
+ *   logits_out  host, [vocab_size] fp32: the LAST position's logits, i.e. what the caller takes
+ *               with logits.get(0)?.flatten_all()? (mod.rs:305,421) after to_dtype(F32).
+ * Blocking: returns when logits are on the host. */
+int fl_forward(fl_model *m, fl_cache *c, const uint32_t *ids, size_t T, size_t pos, float *logits_out);
+
+/* Same forward, but LogitsProcessor ArgMax (temperature < 1e-7; ties -> LAST maximal index,
+ * Rust Iterator::max_by) is evaluated on the device and only the token id comes back. */
+int fl_forward_argmax(fl_model *m, fl_cache *c, const uint32_t *ids, size_t T, size_t pos, uint32_t *token_out);
+
+/* The body of the greedy loop of Model<M>::generate (mod.rs:411-453) kept on the device:
+ * starting from `first_token` (already sampled by the caller from the prefill logits), run
+ * n_steps x { forward([tok], pos) ; tok = argmax ; pos += pos_stride } with no host round trip.
+ * tokens_out[i] is the token sampled after step i.  Stops early (n_out < n_steps) when the
+ * sampled token == eos (eos < 0: never).  pos_stride is 1; pos is whatever offset the caller's
+ * position mode dictates. */
+int fl_decode_greedy(fl_model *m, fl_cache *c, uint32_t first_token, size_t pos, size_t n_steps,
+                     int64_t eos, uint32_t *tokens_out, size_t *n_out);
+
+int fl_synchronize(fl_model *m);
+
+/* Which slice of a full HF tensor does tp_rank own?  Pure host function (no GPU):
+ * out = {row_begin, row_end, col_begin, col_end}.  Column-parallel q/k/v/gate/up/lm_head
+ * (rows of the [out,in] matrix), row-parallel o_proj/down_proj (columns), everything else whole. */
+int fl_tp_slice(const fl_config *cfg, const char *tensor_name, int32_t tp_rank, int32_t tp_size,
+                int64_t out[4]);
+
+/* ---- measurement hooks (bench.py / profiles) --------------------------------------------- */
+typedef struct fl_kernel_stat {
+    char    name[48];               /* kernel class, e.g. "gemv_bf16" */
+    int64_t launches;
+    double  total_ms;               /* sum of HIP-event durations (hipExtLaunchKernelGGL start/stop) */
+    double  bytes;                  /* algorithmic HBM bytes over those launches */
+    double  flops;                  /* algorithmic flops over those launches */
+} fl_kernel_stat;
+/* While profiling is on, forwards run eagerly and every kernel launch is bracketed by a HIP
+ * event pair on the launch stream. */
+int fl_profile_begin(fl_model *m);
+int fl_profile_end(fl_model *m, fl_kernel_stat *stats, size_t cap, size_t *n_stats);
+
+/* y[T,N] = x[T,K] . W[N,K]^T (+bias): the projection kernel family on host buffers, for unit
+ * tests and micro-benchmarks.  dtype is the storage type of x and W (bf16 or f32); y is fp32.
+ * epilogue: 0 none, 1 silu-gate (W rows are gate/up pairs in HF order: gate = rows [0,N/2),
+ * up = rows [N/2,N); y is [T, N/2]).  iters > 0 with ms_out != NULL times `iters` launches. */
+int fl_op_linear(const void *x, const void *w, const float *bias, int64_t T, int64_t N, int64_t K,
+                 int32_t dtype, int32_t epilogue, float *y, int32_t iters, double *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
