@@ -65,7 +65,7 @@ def cpu_baseline(torch, cfg, dev_tensors, kv_prompt=16, n_decode=8):
     from oracle import oracle
     L = cfg["num_hidden_layers"]
     res = {}
-    threads = os.cpu_count() or 1
+    threads = oracle.default_threads()
     prompt = np.arange(1, kv_prompt + 1, dtype=np.uint32)
     for ls in (2, 8):
         ls = min(ls, L)

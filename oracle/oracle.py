@@ -73,6 +73,24 @@ def lib():
     return _LIB
 
 
+def default_threads(cap=16):
+    """CPU threads this process may really use: affinity mask, cgroup quota, and at most `cap`
+    (a one-GPU box shares its host: 16 CPUs per GPU)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
 class OracleError(RuntimeError):
     pass
 
@@ -129,8 +147,7 @@ class OracleModel:
             raise OracleError(L.orc_last_error().decode())
         self._h = h
         self._cb = None
-        if threads:
-            L.orc_model_set_threads(h, threads)
+        L.orc_model_set_threads(h, threads or default_threads())
 
     def threads(self):
         return lib().orc_model_threads(self._h)

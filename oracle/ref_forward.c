@@ -271,7 +271,8 @@ static inline float dot_bf16(const uint16_t *w, const float *x, int64_t K) {
 static void linear_fwd(const orc_model *m, const linear_t *lin, const float *x, int64_t T, float *y) {
     const int64_t N = lin->N, K = lin->K;
     int nt = orc_model_threads(m); (void)nt;
-#pragma omp parallel for schedule(static) num_threads(nt)
+    /* tiny matrices: thread start-up would dominate */
+#pragma omp parallel for schedule(static) num_threads(nt) if ((double)N * (double)K * (double)T > 2e6)
     for (int64_t n = 0; n < N; n++) {
         float b = lin->bias ? lin->bias[n] : 0.f;
         if (lin->wb) { const uint16_t *w = lin->wb + (size_t)n * K;
@@ -328,7 +329,7 @@ static void attention_fwd(const orc_model *m, const orc_cache *c, int64_t layer,
     const int64_t H = m->H, Hkv = m->Hkv, d = m->d, G = H / Hkv;
     const size_t S = len + (size_t)T;
     int nt = orc_model_threads(m); (void)nt;
-#pragma omp parallel for collapse(2) schedule(static) num_threads(nt)
+#pragma omp parallel for collapse(2) schedule(static) num_threads(nt) if ((double)H * (double)T * (double)S * (double)d > 2e6)
     for (int64_t hq = 0; hq < H; hq++) {
         for (int64_t t = 0; t < T; t++) {
             const int64_t hk = hq / G;                                 /* repeat_kv: consecutive */
