@@ -5,5 +5,5 @@ include/fastllm_mi355x.h).  This Python package is the thin ctypes harness the t
 bench.py drive it with; it contains no arithmetic and no CPU fallback.
 """
 from .binding import (Cache, FastLLMError, Model, abi_version, comm_unique_id, device_count, lib, op_linear,  # noqa: F401
-                      tp_slice)
+                      tp_slice, tune)
 from .configs import MODEL_CONFIGS  # noqa: F401

@@ -88,6 +88,7 @@ def lib():
         L.fl_tp_slice.argtypes = [C.POINTER(FlConfig), C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
         L.fl_profile_begin.argtypes = [vp]
         L.fl_profile_end.argtypes = [vp, C.POINTER(FlKernelStat), sz, C.POINTER(sz)]
+        L.fl_tune.argtypes = [C.c_char_p, C.c_int]
         L.fl_op_linear.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int32,
                                    C.POINTER(C.c_double)]
         _LIB = L
@@ -264,6 +265,10 @@ class Cache:
             self.close()
         except Exception:
             pass
+
+
+def tune(key, value):
+    _check(lib().fl_tune(key.encode(), int(value)))
 
 
 def op_linear(x, w, bias=None, epilogue=0, iters=0):

@@ -150,6 +150,16 @@ int fl_profile_end(fl_model *m, fl_kernel_stat *stats, size_t cap, size_t *n_sta
     return FL_OK;
 }
 
+int fl_tune(const char *key, int value) {
+    if (!key || value <= 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "bad tuning key/value");
+    if (!strcmp(key, "gemv_r")) gemv_set_tuning(value, 0, 0, 0);
+    else if (!strcmp(key, "gemv_u")) gemv_set_tuning(0, value, 0, 0);
+    else if (!strcmp(key, "gemv_maxblocks")) gemv_set_tuning(0, 0, value, 0);
+    else if (!strcmp(key, "gemv_maxblocks_norm")) gemv_set_tuning(0, 0, 0, value);
+    else FL_FAIL(FL_ERR_BAD_ARGUMENT, "unknown tuning key %s", key);
+    return FL_OK;
+}
+
 int fl_op_linear(const void *x, const void *w, const float *bias, int64_t T, int64_t N, int64_t K, int32_t dtype,
                  int32_t epilogue, float *y, int32_t iters, double *ms_out) {
     if (!x || !w || !y) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");

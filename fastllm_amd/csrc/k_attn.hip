@@ -38,36 +38,47 @@ __device__ inline void merge_state(float &m, float &l, float (&o)[8], float m2, 
 }
 
 // Accumulate keys [lo, hi) of one kv head into this lane's state.  Uniform trip count per wave.
+// Two key batches per iteration: all four 16-B loads are issued before the first dot product.
+template <typename CT, int D, int GMAX>
+__device__ inline void attend_one(AttnState<GMAX> &s, const float (&q)[GMAX][8], int G, const float (&kv)[8],
+                                  const float (&vv)[8], bool valid) {
+    constexpr int LPK = D / 8;
+#pragma unroll
+    for (int g = 0; g < GMAX; g++) {
+        if (g < G) {
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) dot = fmaf(q[g][j], kv[j], dot);
+#pragma unroll
+            for (int off = 1; off < LPK; off <<= 1) dot += __shfl_xor(dot, off, 64);
+            if (valid) {
+                const float mn = fmaxf(s.m[g], dot);
+                const float alpha = __expf(s.m[g] - mn), p = __expf(dot - mn);
+                s.l[g] = s.l[g] * alpha + p;
+#pragma unroll
+                for (int j = 0; j < 8; j++) s.o[g][j] = s.o[g][j] * alpha + p * vv[j];
+                s.m[g] = mn;
+            }
+        }
+    }
+}
+
 template <typename CT, int D, int GMAX>
 __device__ inline void attend_range(AttnState<GMAX> &s, const float (&q)[GMAX][8], int G, const CT *__restrict__ kc,
                                     const CT *__restrict__ vc, int lo, int hi, int wave, int lane) {
     constexpr int LPK = D / 8, KPI = 64 / LPK;
     const int li = lane % LPK, ks = lane / LPK;
-    for (int base = lo + wave * KPI; base < hi; base += 4 * KPI) {
-        const int key = base + ks;
-        const bool valid = key < hi;
-        const int kk = valid ? key : hi - 1;
-        float kv[8], vv[8];
-        load8(kc + (size_t)kk * D + li * 8, kv);
-        load8(vc + (size_t)kk * D + li * 8, vv);
-#pragma unroll
-        for (int g = 0; g < GMAX; g++) {
-            if (g < G) {
-                float dot = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; j++) dot = fmaf(q[g][j], kv[j], dot);
-#pragma unroll
-                for (int off = 1; off < LPK; off <<= 1) dot += __shfl_xor(dot, off, 64);
-                if (valid) {
-                    const float mn = fmaxf(s.m[g], dot);
-                    const float alpha = __expf(s.m[g] - mn), p = __expf(dot - mn);
-                    s.l[g] = s.l[g] * alpha + p;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) s.o[g][j] = s.o[g][j] * alpha + p * vv[j];
-                    s.m[g] = mn;
-                }
-            }
-        }
+    for (int base = lo + wave * KPI; base < hi; base += 8 * KPI) {
+        const int key0 = base + ks, key1 = base + 4 * KPI + ks;
+        const bool v0 = key0 < hi, v1 = key1 < hi;
+        const int k0 = v0 ? key0 : hi - 1, k1 = v1 ? key1 : hi - 1;
+        float ka[8], va[8], kb[8], vb[8];
+        load8(kc + (size_t)k0 * D + li * 8, ka);
+        load8(vc + (size_t)k0 * D + li * 8, va);
+        load8(kc + (size_t)k1 * D + li * 8, kb);
+        load8(vc + (size_t)k1 * D + li * 8, vb);
+        attend_one<CT, D, GMAX>(s, q, G, ka, va, v0);
+        attend_one<CT, D, GMAX>(s, q, G, kb, vb, v1);
     }
 }
 
@@ -137,13 +148,20 @@ __device__ inline void load_q(float (&q)[GMAX][8], const CT *__restrict__ qrow, 
 
 // ------------------------------------------------------------------------------- decode (T = 1)
 // grid (Hkv, nsplit, ceil(G/GMAX)); T == 1: no mask, no window -- the whole cache is visible.
+// Split-S partials are merged in the same launch: every workgroup publishes its (m, l, o) slab
+// (plain stores -> per-wave vmcnt(0) -> barrier -> agent-scope release -> vmcnt(0) -> ticket),
+// and the workgroup that draws the last ticket of its (kv head, q-group) acquires and combines
+// (cdna guide, Guideline 16 counter form; placement-independent).  The ticket word is reset by
+// the last arriver, so a captured graph can be replayed without a memset node.
 template <typename CT, int D, int GMAX>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const CT *__restrict__ q, const CT *__restrict__ kc,
                                                           const CT *__restrict__ vc, const StepState *__restrict__ st,
                                                           float *__restrict__ part_m, float *__restrict__ part_l,
-                                                          float *__restrict__ part_o, int H, int Hkv, int max_seq,
+                                                          float *__restrict__ part_o, unsigned *__restrict__ counters,
+                                                          CT *__restrict__ out, int H, int Hkv, int max_seq,
                                                           float scale, int nsplit) {
     __shared__ float lds[4 * GMAX * (D + 2)];
+    __shared__ int is_last;
     constexpr int LPK = D / 8, KPI = 64 / LPK;
     const int hk = blockIdx.x, split = blockIdx.y;
     const int Gall = H / Hkv, g0 = blockIdx.z * GMAX;
@@ -173,23 +191,42 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const CT *__restrict__
             }
         }
     }
-}
-
-// grid H, block D threads: merge the split-S partials and normalise
-template <typename CT>
-__global__ void attn_combine_kernel(const float *__restrict__ part_m, const float *__restrict__ part_l,
-                                    const float *__restrict__ part_o, CT *__restrict__ out, int D, int nsplit) {
-    const int h = blockIdx.x, j = threadIdx.x;
-    float M = -INFINITY;
-    for (int s = 0; s < nsplit; s++) M = fmaxf(M, part_m[(size_t)h * nsplit + s]);
-    float L = 0.f, O = 0.f;
-    for (int s = 0; s < nsplit; s++) {
-        const size_t idx = (size_t)h * nsplit + s;
-        const float w = __expf(part_m[idx] - M);
-        L += part_l[idx] * w;
-        O += part_o[idx * D + j] * w;
+    // ---- publish + ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned *cnt = counters + (size_t)hk * gridDim.z + blockIdx.z;
+        const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == (unsigned)nsplit - 1;
+        if (last) {
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everyone has arrived
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        is_last = last;
     }
-    elem<CT>::st(out + (size_t)h * D + j, O / L);
+    __syncthreads();
+    if (!is_last) return;
+    // ---- combine the nsplit slabs of this workgroup's G heads: one thread per (g, 4 d-elements)
+    for (int e = threadIdx.x; e < G * (D / 4); e += 256) {
+        const int g = e / (D / 4), j4 = (e % (D / 4)) * 4;
+        const size_t hb = (size_t)(hq0 + g) * nsplit;
+        float M = -INFINITY;
+        for (int sp = 0; sp < nsplit; sp++) M = fmaxf(M, part_m[hb + sp]);
+        float L = 0.f, O[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < nsplit; sp++) {
+            const float w = __expf(part_m[hb + sp] - M);
+            L += part_l[hb + sp] * w;
+            const float4v o4 = *reinterpret_cast<const float4v *>(part_o + (hb + sp) * D + j4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) O[j] += o4[j] * w;
+        }
+        const float inv = 1.0f / L;
+#pragma unroll
+        for (int j = 0; j < 4; j++) elem<CT>::st(out + (size_t)(hq0 + g) * D + j4 + j, O[j] * inv);
+    }
 }
 
 template <typename CT, int D, int GMAX>
@@ -199,11 +236,9 @@ static int launch_decode_t(Launcher &L, const void *q, const void *kc, const voi
     dim3 grid((unsigned)Hkv, (unsigned)sc.nsplit, (unsigned)((G + GMAX - 1) / GMAX));
     // the KV length lives on the device; the caller passes its host copy for the byte accounting
     double kvbytes = 2.0 * (double)sc.kv_len_hint * Hkv * D * sizeof(CT);
-    FL_TRY(L.launch(KC_ATTN_DECODE, kvbytes, 0, attn_decode_kernel<CT, D, GMAX>, grid, dim3(256), 0, (const CT *)q,
-                    (const CT *)kc, (const CT *)vc, st, sc.part_m, sc.part_l, sc.part_o, (int)H, (int)Hkv,
-                    (int)max_seq, scale, sc.nsplit));
-    return L.launch(KC_ATTN_COMBINE, 0, 0, attn_combine_kernel<CT>, dim3((unsigned)H), dim3((unsigned)D), 0,
-                    sc.part_m, sc.part_l, sc.part_o, (CT *)out, (int)D, sc.nsplit);
+    return L.launch(KC_ATTN_DECODE, kvbytes, 4.0 * (double)sc.kv_len_hint * H * D, attn_decode_kernel<CT, D, GMAX>, grid,
+                    dim3(256), 0, (const CT *)q, (const CT *)kc, (const CT *)vc, st, sc.part_m, sc.part_l, sc.part_o,
+                    sc.counters, (CT *)out, (int)H, (int)Hkv, (int)max_seq, scale, sc.nsplit);
 }
 
 int launch_attn_decode(Launcher &L, int dtype, const void *q, const void *k_cache, const void *v_cache,

@@ -38,7 +38,30 @@ struct Launcher {
     }
 };
 
-enum { EPI_F32 = 0, EPI_GATEUP = 1 };
+enum { EPI_F32 = 0, EPI_GATEUP = 1, EPI_QKV_ROPE = 2 };
+enum { PRO_X = 0, PRO_NORM = 1 };
+
+// Arguments of the decode weight-streaming kernel (k_gemv.hip), passed by value as kernarg.
+struct GemvArgs {
+    const void *W = nullptr;        // [N,K] compute dtype
+    const void *x = nullptr;        // PRO_X: [K] compute dtype
+    const float *bias = nullptr;    // [N] or null
+    void *out = nullptr;            // EPI_F32: float[N]; EPI_GATEUP: XT[N/2]
+    int N = 0, K = 0, epi = EPI_F32, pro = PRO_X;
+    // PRO_NORM: x = rmsnorm(x_in + delta) * norm_w, or of the embedding row of st->token
+    const float *x_in = nullptr, *delta = nullptr, *norm_w = nullptr;
+    float eps = 0.f;
+    float *x_out = nullptr;         // updated residual, written by workgroup 0 (must differ from x_in)
+    const void *embed = nullptr;    // [V,K] compute dtype, or null
+    const StepState *st = nullptr;
+    // EPI_QKV_ROPE: rows are q | k | v heads of width d; RoPE + KV append fused
+    const float *cos_tab = nullptr, *sin_tab = nullptr;
+    void *q_out = nullptr, *k_cache = nullptr, *v_cache = nullptr;
+    int H = 0, Hkv = 0, d = 0, max_seq = 0, max_pos = 0;
+};
+int launch_gemv(Launcher &L, int dtype, const GemvArgs &a);
+bool gemv_norm_supported(int dtype, int64_t N, int64_t K);
+void gemv_set_tuning(int R, int U, int maxblocks, int maxblocks_norm);
 
 // dst row of gate/up pair q in the 16-interleaved fused layout: 16 gate rows then 16 up rows
 __host__ __device__ inline int64_t gateup_row(int64_t q, int is_up) { return (q / 16) * 32 + (q % 16) + (is_up ? 16 : 0); }
@@ -71,7 +94,7 @@ int launch_argmax_advance(Launcher &L, const float *logits, int64_t V, StepState
 int launch_reduce_shards(Launcher &L, float *const *bufs_dev, int nshards, int64_t n);
 
 // ---- attention -----------------------------------------------------------------------------
-struct AttnScratch { float *part_m, *part_l, *part_o; int nsplit; int64_t kv_len_hint; };
+struct AttnScratch { float *part_m, *part_l, *part_o; unsigned *counters; int nsplit; int64_t kv_len_hint; };
 // decode: one query token over len+1 cached keys, no mask (App. A.5)
 int launch_attn_decode(Launcher &L, int dtype, const void *q, const void *k_cache, const void *v_cache,
                        const StepState *st, void *out, const AttnScratch &sc, int64_t H, int64_t Hkv,

@@ -34,6 +34,7 @@ struct LayerW {
 struct Scratch {                 // activations of one forward chunk on one shard
     int64_t cap_T = 0;
     float *x_res = nullptr;      // [T,h] fp32 residual stream
+    float *x_res2 = nullptr;     // decode only: ping-pong partner of x_res for the fused norm prologue
     float *delta = nullptr;      // [T,h] fp32 output of o_proj / down_proj (all-reduced under TP)
     void *xn = nullptr;          // [T,h] normed activations (compute dtype)
     float *qkv = nullptr;        // [T,(Hs+2Hkvs)*d] fp32
@@ -73,6 +74,7 @@ struct Model {
     float *host_logits = nullptr;   // pinned staging [V]
     uint32_t *host_tokens = nullptr;
     bool use_graph = true;
+    bool fused_decode = true;    // norm / RoPE / KV-append fused into the GEMV kernels
     std::vector<ProfRecord> prof;
     bool profiling = false;
     int64_t hbm_bytes = 0;
@@ -85,6 +87,7 @@ struct CacheShard {
     StepState *st = nullptr;
     uint32_t *out_tokens = nullptr;
     float *part_m = nullptr, *part_l = nullptr, *part_o = nullptr;
+    unsigned *counters = nullptr;        // split-S arrival tickets, [Hkvs * q-groups]
     hipGraphExec_t graph = nullptr;
     std::vector<void *> allocs;
 };

@@ -300,6 +300,7 @@ static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T) {
     // grow-only; the previous buffers stay owned by the shard until the model dies (rare path)
     sc.cap_T = T;
     FL_TRY(dev_alloc(sh.allocs, (void **)&sc.x_res, (size_t)T * D.h * 4, &m->hbm_bytes));
+    if (T == 1) FL_TRY(dev_alloc(sh.allocs, (void **)&sc.x_res2, (size_t)D.h * 4, &m->hbm_bytes));
     FL_TRY(dev_alloc(sh.allocs, (void **)&sc.delta, (size_t)T * D.h * 4, &m->hbm_bytes));
     FL_TRY(dev_alloc(sh.allocs, &sc.xn, (size_t)T * D.h * es, &m->hbm_bytes));
     FL_TRY(dev_alloc(sh.allocs, (void **)&sc.qkv, (size_t)T * nq * 4, &m->hbm_bytes));
@@ -342,6 +343,7 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
     m->cfg_resolved.num_key_value_heads = D.Hkv; m->cfg_resolved.rope_theta = D.theta;
     m->cfg_resolved.max_position_embeddings = D.max_pos; m->cfg_resolved.sliding_window = D.window;
     m->use_graph = env_int("FL_GRAPH", 1) != 0;
+    m->fused_decode = env_int("FL_FUSED", 1) != 0 && gemv_norm_supported(compute_dtype, 1, D.h);
 
     auto dev_of = [&](int i) -> int { return (P.device_ids && i < P.n_device_ids) ? P.device_ids[i] : i; };
     int nlocal = 1;
@@ -415,8 +417,8 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
     const Dims &D = m->D;
     std::unique_ptr<Cache> c(new Cache());
     c->m = m; c->max_seq = max_seq; c->len = 0;
-    // split-S: ~64 keys per workgroup at full length, at most ~512 workgroups per launch
-    int64_t ns = (int64_t)((max_seq + 63) / 64);
+    // split-S: ~32 keys per workgroup at full length, at most ~512 workgroups per launch
+    int64_t ns = (int64_t)((max_seq + 31) / 32);
     int64_t cap = std::max<int64_t>(1, 512 / std::max<int64_t>(1, m->shards[0].Hkvs));
     c->nsplit = (int)std::max<int64_t>(1, std::min(ns, cap));
     c->nsplit = env_int("FL_ATTN_NSPLIT", c->nsplit);
@@ -432,6 +434,8 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.part_m, (size_t)sh.Hs * c->nsplit * 4, nullptr));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.part_l, (size_t)sh.Hs * c->nsplit * 4, nullptr));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.part_o, (size_t)sh.Hs * c->nsplit * D.d * 4, nullptr));
+        FL_TRY(dev_alloc(cs.allocs, (void **)&cs.counters, (size_t)sh.Hs * 4, nullptr));
+        FL_HIP(hipMemset(cs.counters, 0, (size_t)sh.Hs * 4));
         FL_HIP(hipMemset(cs.st, 0, sizeof(StepState)));
     }
     m->refs.fetch_add(1);
@@ -495,9 +499,64 @@ static int gather_logits(Model *m) {
     return FL_OK;
 }
 
+// Decode step with the fused kernels: 5 launches per layer instead of 10.
+//   K1 gemv[norm1(+residual add, or embedding) -> qkv -> RoPE -> q buffer / KV cache slot]
+//   K2 attn_decode (+ in-launch split-S combine)      K3 gemv[o_proj] -> delta   (all-reduce)
+//   K4 gemv[norm2(+add) -> gate/up -> silu*up]        K5 gemv[down]   -> delta   (all-reduce)
+// and finally gemv[final norm -> lm_head].  The residual ping-pongs x_res <-> x_res2 because the
+// norm prologue of every workgroup reads x_in while workgroup 0 writes the updated residual.
+static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
+    const Dims &D = m->D;
+    const int dt = m->dtype;
+    const size_t ns = m->shards.size();
+    for (int64_t l = 0; l < D.L; l++) {
+        for (size_t i = 0; i < ns; i++) {
+            Shard &sh = m->shards[i]; Scratch &sc = sh.dec; CacheShard &cs = c->shards[i]; LayerW &ly = sh.layers[l];
+            FL_HIP(hipSetDevice(sh.device));
+            Launcher L = make_launcher(m, sh);
+            const size_t kv_layer = (size_t)l * sh.Hkvs * c->max_seq * D.d * m->esize();
+            void *kc = (char *)cs.k + kv_layer, *vc = (char *)cs.v + kv_layer;
+            GemvArgs a;
+            a.W = ly.wqkv; a.bias = ly.bqkv; a.N = (int)((sh.Hs + 2 * sh.Hkvs) * D.d); a.K = (int)D.h;
+            a.epi = EPI_QKV_ROPE; a.pro = PRO_NORM; a.norm_w = ly.ln1; a.eps = D.eps; a.st = cs.st;
+            if (l == 0) { a.embed = sh.embed; a.x_out = sc.x_res2; }
+            else { a.x_in = sc.x_res; a.delta = sc.delta; a.x_out = sc.x_res2; }
+            a.cos_tab = sh.cos_tab; a.sin_tab = sh.sin_tab; a.q_out = sc.q; a.k_cache = kc; a.v_cache = vc;
+            a.H = (int)sh.Hs; a.Hkv = (int)sh.Hkvs; a.d = (int)D.d; a.max_seq = (int)c->max_seq; a.max_pos = (int)D.max_pos;
+            FL_TRY(launch_gemv(L, dt, a));
+            AttnScratch as{cs.part_m, cs.part_l, cs.part_o, cs.counters, c->nsplit, len_hint + 1};
+            FL_TRY(launch_attn_decode(L, dt, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->max_seq, D.scale));
+            FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, 1, D.h, sh.Hs * D.d, EPI_F32));
+        }
+        FL_TRY(all_reduce_delta(m, false, D.h));
+        for (size_t i = 0; i < ns; i++) {
+            Shard &sh = m->shards[i]; Scratch &sc = sh.dec; LayerW &ly = sh.layers[l];
+            FL_HIP(hipSetDevice(sh.device));
+            Launcher L = make_launcher(m, sh);
+            GemvArgs a;
+            a.W = ly.wgu; a.out = sc.act; a.N = (int)(2 * sh.Ip); a.K = (int)D.h; a.epi = EPI_GATEUP; a.pro = PRO_NORM;
+            a.x_in = sc.x_res2; a.delta = sc.delta; a.norm_w = ly.ln2; a.eps = D.eps; a.x_out = sc.x_res; a.st = c->shards[i].st;
+            FL_TRY(launch_gemv(L, dt, a));
+            FL_TRY(launch_linear(L, dt, ly.wd, sc.act, nullptr, sc.delta, 1, D.h, sh.Ip, EPI_F32));
+        }
+        FL_TRY(all_reduce_delta(m, false, D.h));
+    }
+    for (size_t i = 0; i < ns; i++) {
+        Shard &sh = m->shards[i]; Scratch &sc = sh.dec;
+        FL_HIP(hipSetDevice(sh.device));
+        Launcher L = make_launcher(m, sh);
+        GemvArgs a;
+        a.W = sh.lm_head; a.out = sh.logits_local; a.N = (int)sh.Vs; a.K = (int)D.h; a.epi = EPI_F32; a.pro = PRO_NORM;
+        a.x_in = sc.x_res; a.delta = sc.delta; a.norm_w = sh.norm; a.eps = D.eps; a.st = c->shards[i].st;
+        FL_TRY(launch_gemv(L, dt, a));
+    }
+    return gather_logits(m);
+}
+
 // Enqueue one forward over T tokens on every local shard.  The step state (pos, len, token) of the
 // cache must already be set on the device.  ids_dev == null: the single token comes from the state.
 static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_scratch, int64_t len_hint) {
+    if (T == 1 && !pre && !ids_in_scratch && m->fused_decode) return enqueue_decode_fused(m, c, len_hint);
     const Dims &D = m->D;
     const int dt = m->dtype;
     const size_t ns = m->shards.size();
@@ -520,7 +579,7 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, ly.bqkv, sc.qkv, T, nq, D.h, EPI_F32));
             FL_TRY(launch_rope_kv(L, dt, sc.qkv, cs.st, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, kc, vc, T, sh.Hs, sh.Hkvs, D.d, (int64_t)c->max_seq));
             if (T == 1) {
-                AttnScratch as{cs.part_m, cs.part_l, cs.part_o, c->nsplit, len_hint + 1};
+                AttnScratch as{cs.part_m, cs.part_l, cs.part_o, cs.counters, c->nsplit, len_hint + 1};
                 FL_TRY(launch_attn_decode(L, dt, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->max_seq, D.scale));
             } else {
                 FL_TRY(launch_attn_prefill(L, dt, sc.q, kc, vc, cs.st, sc.ao, T, sh.Hs, sh.Hkvs, D.d, (int64_t)c->max_seq, D.scale, D.window));

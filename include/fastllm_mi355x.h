@@ -197,6 +197,11 @@ typedef struct fl_kernel_stat {
 int fl_profile_begin(fl_model *m);
 int fl_profile_end(fl_model *m, fl_kernel_stat *stats, size_t cap, size_t *n_stats);
 
+/* Tuning knobs of the decode weight-streaming kernel (sweeps in tools/; not needed in normal use):
+ * "gemv_r" rows per wave pass (2|4), "gemv_u" 512-element chunks in flight (2|4|8),
+ * "gemv_maxblocks", "gemv_maxblocks_norm" grid caps (plain / fused-norm kernels). */
+int fl_tune(const char *key, int value);
+
 /* y[T,N] = x[T,K] . W[N,K]^T (+bias): the projection kernel family on host buffers, for unit
  * tests and micro-benchmarks.  dtype is the storage type of x and W (bf16 or f32); y is fp32.
  * epilogue: 0 none, 1 silu-gate (W rows are gate/up pairs in HF order: gate = rows [0,N/2),
