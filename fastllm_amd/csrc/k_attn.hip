@@ -63,30 +63,35 @@ __device__ inline void attend_one(AttnState<GMAX> &s, const float (&q)[GMAX][8],
     }
 }
 
-template <typename CT, int D, int GMAX>
+// NW waves share the key range; UNR key batches are loaded (K and V, 16 B per lane each) before
+// the first dot product so 2*UNR wave-loads are in flight per wave.
+template <typename CT, int D, int GMAX, int NW, int UNR>
 __device__ inline void attend_range(AttnState<GMAX> &s, const float (&q)[GMAX][8], int G, const CT *__restrict__ kc,
                                     const CT *__restrict__ vc, int lo, int hi, int wave, int lane) {
     constexpr int LPK = D / 8, KPI = 64 / LPK;
     const int li = lane % LPK, ks = lane / LPK;
-    for (int base = lo + wave * KPI; base < hi; base += 8 * KPI) {
-        const int key0 = base + ks, key1 = base + 4 * KPI + ks;
-        const bool v0 = key0 < hi, v1 = key1 < hi;
-        const int k0 = v0 ? key0 : hi - 1, k1 = v1 ? key1 : hi - 1;
-        float ka[8], va[8], kb[8], vb[8];
-        load8(kc + (size_t)k0 * D + li * 8, ka);
-        load8(vc + (size_t)k0 * D + li * 8, va);
-        load8(kc + (size_t)k1 * D + li * 8, kb);
-        load8(vc + (size_t)k1 * D + li * 8, vb);
-        attend_one<CT, D, GMAX>(s, q, G, ka, va, v0);
-        attend_one<CT, D, GMAX>(s, q, G, kb, vb, v1);
+    for (int base = lo + wave * KPI; base < hi; base += UNR * NW * KPI) {
+        float kf[UNR][8], vf[UNR][8];
+        bool valid[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const int key = base + u * NW * KPI + ks;
+            valid[u] = key < hi;
+            const int kk = valid[u] ? key : hi - 1;
+            load8(kc + (size_t)kk * D + li * 8, kf[u]);
+            load8(vc + (size_t)kk * D + li * 8, vf[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) attend_one<CT, D, GMAX>(s, q, G, kf[u], vf[u], valid[u]);
     }
 }
 
-// merge the KPI key-slot states of a wave into lanes [0, LPK), then the 4 waves through LDS into
-// wave 0.  lds: [4 waves][GMAX][D + 2] floats.  Returns with the block result in wave 0, lanes < LPK.
-template <int D, int GMAX>
-__device__ inline void merge_block(AttnState<GMAX> &s, int G, float *lds, int wave, int lane) {
-    constexpr int LPK = D / 8;
+// Merge the per-lane states of a workgroup.  First the KPI key-slot states of each wave (xor
+// shuffles), then the NW waves through LDS: lds [NW][GMAX][D + 2] floats holds (o[D], m, l) per
+// (wave, head).  After the barrier every thread can combine any (head, d-slice) from LDS.
+template <int D, int GMAX, int NW>
+__device__ inline void merge_to_lds(AttnState<GMAX> &s, int G, float *lds, int wave, int lane) {
+    constexpr int LPK = D / 8, STR = D + 2;
     const int li = lane % LPK;
 #pragma unroll
     for (int g = 0; g < GMAX; g++) {
@@ -100,7 +105,6 @@ __device__ inline void merge_block(AttnState<GMAX> &s, int G, float *lds, int wa
             }
         }
     }
-    constexpr int STR = D + 2;
     if (lane < LPK) {
 #pragma unroll
         for (int g = 0; g < GMAX; g++) {
@@ -113,19 +117,23 @@ __device__ inline void merge_block(AttnState<GMAX> &s, int G, float *lds, int wa
         }
     }
     __syncthreads();
-    if (wave == 0 && lane < LPK) {
+}
+
+// combine the NW wave slabs in LDS for (head g, 4 d-elements at j4): returns M, L and O[4] (unnormalised)
+template <int D, int GMAX, int NW>
+__device__ inline void combine_lds(const float *lds, int g, int j4, float &M, float &L, float (&O)[4]) {
+    constexpr int STR = D + 2;
+    M = -INFINITY;
 #pragma unroll
-        for (int g = 0; g < GMAX; g++) {
-            if (g < G) {
-                for (int w = 1; w < 4; w++) {
-                    const float *p = lds + ((size_t)w * GMAX + g) * STR;
-                    float o2[8];
+    for (int w = 0; w < NW; w++) M = fmaxf(M, lds[((size_t)w * GMAX + g) * STR + D]);
+    L = 0.f; O[0] = O[1] = O[2] = O[3] = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) o2[j] = p[li * 8 + j];
-                    merge_state(s.m[g], s.l[g], s.o[g], p[D], p[D + 1], o2);
-                }
-            }
-        }
+    for (int w = 0; w < NW; w++) {
+        const float *p = lds + ((size_t)w * GMAX + g) * STR;
+        const float wt = p[D] == -INFINITY ? 0.f : __expf(p[D] - M);
+        L += p[D + 1] * wt;
+#pragma unroll
+        for (int j = 0; j < 4; j++) O[j] += p[j4 + j] * wt;
     }
 }
 
@@ -147,29 +155,33 @@ __device__ inline void load_q(float (&q)[GMAX][8], const CT *__restrict__ qrow, 
 }
 
 // ------------------------------------------------------------------------------- decode (T = 1)
-// grid (Hkv, nsplit, ceil(G/GMAX)); T == 1: no mask, no window -- the whole cache is visible.
-// Split-S partials are merged in the same launch: every workgroup publishes its (m, l, o) slab
-// (plain stores -> per-wave vmcnt(0) -> barrier -> agent-scope release -> vmcnt(0) -> ticket),
-// and the workgroup that draws the last ticket of its (kv head, q-group) acquires and combines
-// (cdna guide, Guideline 16 counter form; placement-independent).  The ticket word is reset by
-// the last arriver, so a captured graph can be replayed without a memset node.
-template <typename CT, int D, int GMAX>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const CT *__restrict__ q, const CT *__restrict__ kc,
-                                                          const CT *__restrict__ vc, const StepState *__restrict__ st,
-                                                          float *__restrict__ part_m, float *__restrict__ part_l,
-                                                          float *__restrict__ part_o, unsigned *__restrict__ counters,
-                                                          CT *__restrict__ out, int H, int Hkv, int max_seq,
-                                                          float scale, int nsplit) {
-    __shared__ float lds[4 * GMAX * (D + 2)];
+// grid (Hkv, nsplit, ceil(G/GMAX)), NW waves per workgroup.  T == 1: no mask, no window -- the
+// whole cache is visible.  A decode step is a chain of short dependent kernels, so the kernel is
+// built to minimise serial memory round trips rather than to spread over many CUs: with
+// nsplit == 1 (cache capacity up to 2048 positions per split) ONE 16-wave workgroup per kv head
+// streams that head's K/V (<= ~1 MB) and writes the normalised output directly -- no partial
+// buffers, no fences, no second launch.  Longer caches split S across workgroups; their (m, l, o)
+// slabs are merged in the same launch by the workgroup that draws the last ticket (plain stores ->
+// per-wave vmcnt(0) -> barrier -> agent-scope release -> vmcnt(0) -> ticket; last arriver: acquire
+// -> barrier -> plain loads; cdna guide Guideline 16 counter form, placement-independent).  The
+// ticket word is reset by the last arriver, so a captured graph replays without a memset node.
+template <typename CT, int D, int GMAX, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const CT *__restrict__ q, const CT *__restrict__ kc,
+                                                              const CT *__restrict__ vc, const StepState *__restrict__ st,
+                                                              float *__restrict__ part_m, float *__restrict__ part_l,
+                                                              float *__restrict__ part_o, unsigned *__restrict__ counters,
+                                                              CT *__restrict__ out, int H, int Hkv, int max_seq,
+                                                              float scale, int nsplit) {
+    __shared__ float lds[NW * GMAX * (D + 2)];
     __shared__ int is_last;
-    constexpr int LPK = D / 8, KPI = 64 / LPK;
+    constexpr int LPK = D / 8, KPI = 64 / LPK, UNR = 2;
     const int hk = blockIdx.x, split = blockIdx.y;
     const int Gall = H / Hkv, g0 = blockIdx.z * GMAX;
     const int G = min(GMAX, Gall - g0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = (int)st->len + 1;
     int per = (S + nsplit - 1) / nsplit;
-    per = (per + 4 * KPI - 1) / (4 * KPI) * (4 * KPI);
+    per = (per + NW * KPI - 1) / (NW * KPI) * (NW * KPI);
     const int lo = split * per, hi = min(S, lo + per);
     const int hq0 = hk * Gall + g0;
 
@@ -177,21 +189,29 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const CT *__restrict__
     load_q<CT, D, GMAX>(qv, q, hq0, G, lane, scale);
     AttnState<GMAX> s; s.init();
     if (lo < hi)
-        attend_range<CT, D, GMAX>(s, qv, G, kc + (size_t)hk * max_seq * D, vc + (size_t)hk * max_seq * D, lo, hi, wave, lane);
-    merge_block<D, GMAX>(s, G, lds, wave, lane);
-    if (wave == 0 && lane < LPK) {
+        attend_range<CT, D, GMAX, NW, UNR>(s, qv, G, kc + (size_t)hk * max_seq * D, vc + (size_t)hk * max_seq * D, lo, hi, wave, lane);
+    merge_to_lds<D, GMAX, NW>(s, G, lds, wave, lane);
+
+    if (nsplit == 1) {
+        for (int e = threadIdx.x; e < G * (D / 4); e += NW * 64) {
+            const int g = e / (D / 4), j4 = (e % (D / 4)) * 4;
+            float M, L, O[4];
+            combine_lds<D, GMAX, NW>(lds, g, j4, M, L, O);
+            const float inv = 1.0f / L;
 #pragma unroll
-        for (int g = 0; g < GMAX; g++) {
-            if (g < G) {
-                const size_t idx = (size_t)(hq0 + g) * nsplit + split;
-                float *po = part_o + idx * D + lane * 8;
-#pragma unroll
-                for (int j = 0; j < 8; j++) po[j] = s.o[g][j];
-                if (lane == 0) { part_m[idx] = s.m[g]; part_l[idx] = s.l[g]; }
-            }
+            for (int j = 0; j < 4; j++) elem<CT>::st(out + (size_t)(hq0 + g) * D + j4 + j, O[j] * inv);
         }
+        return;
     }
-    // ---- publish + ticket
+    // ---- publish this split's slab
+    for (int e = threadIdx.x; e < G * (D / 4); e += NW * 64) {
+        const int g = e / (D / 4), j4 = (e % (D / 4)) * 4;
+        float M, L, O[4];
+        combine_lds<D, GMAX, NW>(lds, g, j4, M, L, O);
+        const size_t idx = (size_t)(hq0 + g) * nsplit + split;
+        *reinterpret_cast<float4v *>(part_o + idx * D + j4) = float4v{O[0], O[1], O[2], O[3]};
+        if (j4 == 0) { part_m[idx] = M; part_l[idx] = L; }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -209,16 +229,25 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const CT *__restrict__
     }
     __syncthreads();
     if (!is_last) return;
-    // ---- combine the nsplit slabs of this workgroup's G heads: one thread per (g, 4 d-elements)
-    for (int e = threadIdx.x; e < G * (D / 4); e += 256) {
+    // ---- last arriver: stage the (m, l) of all splits in LDS, then combine the o slabs in parallel
+    float *lm = lds, *ll = lds + GMAX * nsplit;                       // nsplit <= NW * (D + 2) / 2 (host-checked)
+    for (int e = threadIdx.x; e < G * nsplit; e += NW * 64) {
+        const int g = e / nsplit, sp = e % nsplit;
+        const size_t idx = (size_t)(hq0 + g) * nsplit + sp;
+        lm[g * nsplit + sp] = part_m[idx]; ll[g * nsplit + sp] = part_l[idx];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < G * (D / 4); e += NW * 64) {
         const int g = e / (D / 4), j4 = (e % (D / 4)) * 4;
         const size_t hb = (size_t)(hq0 + g) * nsplit;
         float M = -INFINITY;
-        for (int sp = 0; sp < nsplit; sp++) M = fmaxf(M, part_m[hb + sp]);
+        for (int sp = 0; sp < nsplit; sp++) M = fmaxf(M, lm[g * nsplit + sp]);
         float L = 0.f, O[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
         for (int sp = 0; sp < nsplit; sp++) {
-            const float w = __expf(part_m[hb + sp] - M);
-            L += part_l[hb + sp] * w;
+            const float mm = lm[g * nsplit + sp];
+            const float w = mm == -INFINITY ? 0.f : __expf(mm - M);
+            L += ll[g * nsplit + sp] * w;
             const float4v o4 = *reinterpret_cast<const float4v *>(part_o + (hb + sp) * D + j4);
 #pragma unroll
             for (int j = 0; j < 4; j++) O[j] += o4[j] * w;
@@ -229,15 +258,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const CT *__restrict__
     }
 }
 
-template <typename CT, int D, int GMAX>
+template <typename CT, int D, int GMAX, int NW>
 static int launch_decode_t(Launcher &L, const void *q, const void *kc, const void *vc, const StepState *st,
                            void *out, const AttnScratch &sc, int64_t H, int64_t Hkv, int64_t max_seq, float scale) {
     const int G = (int)(H / Hkv);
+    if (sc.nsplit > 64) FL_FAIL(FL_ERR_BAD_ARGUMENT, "attention: at most 64 splits");
     dim3 grid((unsigned)Hkv, (unsigned)sc.nsplit, (unsigned)((G + GMAX - 1) / GMAX));
     // the KV length lives on the device; the caller passes its host copy for the byte accounting
     double kvbytes = 2.0 * (double)sc.kv_len_hint * Hkv * D * sizeof(CT);
-    return L.launch(KC_ATTN_DECODE, kvbytes, 4.0 * (double)sc.kv_len_hint * H * D, attn_decode_kernel<CT, D, GMAX>, grid,
-                    dim3(256), 0, (const CT *)q, (const CT *)kc, (const CT *)vc, st, sc.part_m, sc.part_l, sc.part_o,
+    return L.launch(KC_ATTN_DECODE, kvbytes, 4.0 * (double)sc.kv_len_hint * H * D, attn_decode_kernel<CT, D, GMAX, NW>, grid,
+                    dim3(NW * 64), 0, (const CT *)q, (const CT *)kc, (const CT *)vc, st, sc.part_m, sc.part_l, sc.part_o,
                     sc.counters, (CT *)out, (int)H, (int)Hkv, (int)max_seq, scale, sc.nsplit);
 }
 
@@ -247,10 +277,10 @@ int launch_attn_decode(Launcher &L, int dtype, const void *q, const void *k_cach
     const int G = (int)(H / Hkv);
     const bool small = G <= 4;
 #define FL_DISPATCH(CT)                                                                                        \
-    if (d == 128) return small ? launch_decode_t<CT, 128, 4>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale) \
-                               : launch_decode_t<CT, 128, 8>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale); \
-    if (d == 64) return small ? launch_decode_t<CT, 64, 4>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale)   \
-                              : launch_decode_t<CT, 64, 8>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale);
+    if (d == 128) return small ? launch_decode_t<CT, 128, 4, 16>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale) \
+                               : launch_decode_t<CT, 128, 8, 8>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale); \
+    if (d == 64) return small ? launch_decode_t<CT, 64, 4, 16>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale)   \
+                              : launch_decode_t<CT, 64, 8, 8>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale);
     if (dtype == FL_DTYPE_BF16) { FL_DISPATCH(bf16_t) }
     else { FL_DISPATCH(float) }
 #undef FL_DISPATCH
@@ -267,7 +297,6 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const CT *__restrict_
                                                            CT *__restrict__ out, int T, int H, int Hkv, int max_seq,
                                                            float scale, int window) {
     __shared__ float lds[4 * GMAX * (D + 2)];
-    constexpr int LPK = D / 8;
     const int hk = blockIdx.x, t = blockIdx.y;
     const int Gall = H / Hkv, g0 = blockIdx.z * GMAX;
     const int G = min(GMAX, Gall - g0);
@@ -282,23 +311,19 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const CT *__restrict_
     int jlo = 0;
     if (window >= 0 && t - window > 0) jlo = t - window;
     if (jlo == 0) {
-        attend_range<CT, D, GMAX>(s, qv, G, kb, vb, 0, len + t + 1, wave, lane);
+        attend_range<CT, D, GMAX, 4, 2>(s, qv, G, kb, vb, 0, len + t + 1, wave, lane);
     } else {
-        if (len > 0) attend_range<CT, D, GMAX>(s, qv, G, kb, vb, 0, len, wave, lane);
-        attend_range<CT, D, GMAX>(s, qv, G, kb, vb, len + jlo, len + t + 1, wave, lane);
+        if (len > 0) attend_range<CT, D, GMAX, 4, 2>(s, qv, G, kb, vb, 0, len, wave, lane);
+        attend_range<CT, D, GMAX, 4, 2>(s, qv, G, kb, vb, len + jlo, len + t + 1, wave, lane);
     }
-    merge_block<D, GMAX>(s, G, lds, wave, lane);
-    if (wave == 0 && lane < LPK) {
+    merge_to_lds<D, GMAX, 4>(s, G, lds, wave, lane);
+    for (int e = threadIdx.x; e < G * (D / 4); e += 256) {
+        const int g = e / (D / 4), j4 = (e % (D / 4)) * 4;
+        float M, L, O[4];
+        combine_lds<D, GMAX, 4>(lds, g, j4, M, L, O);
+        const float inv = 1.0f / L;
 #pragma unroll
-        for (int g = 0; g < GMAX; g++) {
-            if (g < G) {
-                float o[8];
-                const float inv = 1.0f / s.l[g];
-#pragma unroll
-                for (int j = 0; j < 8; j++) o[j] = s.o[g][j] * inv;
-                store8(out + ((size_t)t * H + hq0 + g) * D + lane * 8, o);
-            }
-        }
+        for (int j = 0; j < 4; j++) elem<CT>::st(out + ((size_t)t * H + hq0 + g) * D + j4 + j, O[j] * inv);
     }
 }
 

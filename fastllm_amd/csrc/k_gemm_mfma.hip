@@ -47,7 +47,8 @@ __device__ inline bf16x8 read_frag(const unsigned char *lds_tile, int row, int c
 
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
                                                         const float *__restrict__ bias, void *__restrict__ out,
-                                                        int T, int N, int K, int epi, int tiles_m, int tiles_n) {
+                                                        int T, int N, int K, int epi, int tiles_m, int tiles_n,
+                                                        const float *__restrict__ row_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2 buffers][X tile | W tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -102,13 +103,14 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const bf16_t *__restrict
         for (int rg = 0; rg < 4; rg++) {
             const int m = m0 + wm * 64 + i * 16 + rm + rg;
             if (m >= T) continue;
+            const float rs = row_scale ? row_scale[m] : 1.0f;
             if (epi == EPI_GATEUP) {
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
                     const int n = n0 + wn * 64 + j * 16 + cn;        // gate column; up = n + 16
                     if (n + 16 < N) {
                         const int qq = (n >> 5) * 16 + (n & 15);
-                        float gt = acc[i][j][rg], up = acc[i][j + 1][rg];
+                        float gt = acc[i][j][rg] * rs, up = acc[i][j + 1][rg] * rs;
                         float a = gt / (1.0f + expf(-gt)) * up;
                         reinterpret_cast<bf16_t *>(out)[(size_t)m * (N / 2) + qq] = float_to_bf16_bits(a);
                     }
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const bf16_t *__restrict
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int n = n0 + wn * 64 + j * 16 + cn;
-                    if (n < N) reinterpret_cast<float *>(out)[(size_t)m * N + n] = acc[i][j][rg] + (bias ? bias[n] : 0.f);
+                    if (n < N) reinterpret_cast<float *>(out)[(size_t)m * N + n] = acc[i][j][rg] * rs + (bias ? bias[n] : 0.f);
                 }
             }
         }
@@ -129,7 +131,7 @@ bool gemm_mfma_supported(int dtype, int64_t T, int64_t N, int64_t K) {
 }
 
 int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bias, void *y,
-                     int64_t T, int64_t N, int64_t K, int epi) {
+                     int64_t T, int64_t N, int64_t K, int epi, const float *row_scale) {
     const int tiles_m = (int)((T + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
     const size_t lds = 4 * TILE_BYTES;     // 64 KiB
     static bool attr_set = false;
@@ -141,7 +143,7 @@ int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bia
     double bytes = ((double)N * K + (double)T * K) * 2.0;
     return L.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, gemm_mfma_kernel, dim3((unsigned)(tiles_m * tiles_n)),
                     dim3(256), lds, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi,
-                    tiles_m, tiles_n);
+                    tiles_m, tiles_n, row_scale);
 }
 
 }  // namespace fl

@@ -7,11 +7,14 @@
 // chunks of all R rows in flight before the first FMA; fp32 accumulate; 64-lane shuffle reduce.
 // x (the activation vector) is staged once per workgroup in LDS and re-read with ds_read_b128.
 //
-// Prologue PRO_NORM (fused K2/K9, and K1 for layer 0): the workgroup builds its own normalised
-// input  xn = rmsnorm(x_in + delta) * w  (or from the embedding row of the current token) in
-// LDS, so no separate norm kernel and no xn round trip; workgroup 0 also writes the updated
-// residual to x_out (a different buffer than x_in: other workgroups still read x_in).  The
-// first weight loads are issued before the reduction so HBM is busy during the prologue.
+// Prologue PRO_NORM (fused K2/K9, and K1 for layer 0): RMSNorm is folded around the dot product,
+//     W . (v / m * w)  =  (1/m) * W . (v * w),     v = x_in + delta (or the token's embedding row),
+// so the workgroup stages x' = v * w in LDS with no dependence on m = sqrt(mean(v^2) + eps): the
+// sum of squares rides along in the same pass and is combined behind the SAME barrier as the
+// staging; 1/m is applied to the accumulator in the epilogue.  No separate norm kernel, no xn
+// round trip, no extra barrier.  Workgroup 0 also writes the updated residual v to x_out (a
+// different buffer than x_in: other workgroups still read x_in).  The first weight loads are
+// issued before the staging so HBM is busy from the first cycle.
 //
 // Epilogues: EPI_F32 (+bias) -> fp32;  EPI_GATEUP: silu(gate)*up on the 16-interleaved layout;
 // EPI_QKV_ROPE (fused K4/K5): rows are paired (j, j+d/2) per head, RoPE is applied with the
@@ -24,6 +27,22 @@
 #include "kernels.h"
 
 namespace fl {
+
+__device__ inline void load_raw_nt(const bf16_t *p, uint4v (&r)[1]) {
+    r[0] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(p));
+}
+__device__ inline void load_raw_nt(const float *p, uint4v (&r)[2]) {
+    r[0] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(p));
+    r[1] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(p + 4));
+}
+template <typename WT> __device__ inline void unpack_raw(const uint4v (&r)[sizeof(WT) == 2 ? 1 : 2], float (&o)[8]) {
+    if constexpr (sizeof(WT) == 2) {
+        unpack8(r[0], o);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { o[i] = __uint_as_float(r[0][i]); o[4 + i] = __uint_as_float(r[1][i]); }
+    }
+}
 
 template <typename WT, typename XT, int R, int U, int PRO>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
@@ -44,8 +63,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
         return g * R + r;
     };
 
-    float pre[R][U][8];
+    uint4v pre[R][U][sizeof(WT) == 2 ? 1 : 2];      // raw 16-B loads; unpacked at the FMA
     bool have_pre = false;
+    float inv_m = 1.0f;
     if constexpr (PRO == PRO_NORM) {
         constexpr int NCH = 3;                       // K <= 6144 (host-checked)
         float v[NCH][8], wn[NCH][8];
@@ -65,7 +85,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
                 }
             }
         }
-        // first weight block of this wave: in flight while the norm is reduced
+        // first weight block of this wave: in flight while x' is staged
         if (gw < ngroups && lane + 64 * (U - 1) < nchunk) {
             have_pre = true;
 #pragma unroll
@@ -73,33 +93,29 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     int row = row_of(gw, r);
-                    load8_nt(W + (size_t)(row < N ? row : N - 1) * K + (size_t)(lane + 64 * u) * 8, pre[r][u]);
+                    load_raw_nt(W + (size_t)(row < N ? row : N - 1) * K + (size_t)(lane + 64 * u) * 8, pre[r][u]);
                 }
         }
         float ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < NCH; i++)
-            if (tid + 256 * i < nchunk)
-#pragma unroll
-                for (int j = 0; j < 8; j++) ss = fmaf(v[i][j], v[i][j], ss);
-        ss = wave_sum(ss);
-        if (lane == 0) red[wave] = ss;
-        __syncthreads();
-        ss = red[0] + red[1] + red[2] + red[3];
-        const float m = sqrtf(ss / (float)K + a.eps);          // candle rms_norm (App. A.2)
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
             const int c = tid + 256 * i;
             if (c < nchunk) {
                 float o[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) o[j] = v[i][j] / m * wn[i][j];
+                for (int j = 0; j < 8; j++) { ss = fmaf(v[i][j], v[i][j], ss); o[j] = v[i][j] * wn[i][j]; }
                 store8(xs + c * 8, o);
                 if (blockIdx.x == 0 && a.x_out) store8(a.x_out + c * 8, v[i]);
             }
         }
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        ss = red[0] + red[1] + red[2] + red[3];
+        inv_m = 1.0f / sqrtf(ss / (float)K + a.eps);           // candle rms_norm (App. A.2)
     } else {
         const XT *__restrict__ x = reinterpret_cast<const XT *>(a.x);
+        if (a.x_scale) inv_m = *a.x_scale;
         for (int c = tid; c < nchunk; c += 256) {
             if constexpr (sizeof(XT) == 2) {
                 *reinterpret_cast<uint4v *>(xs + c * 8) = *reinterpret_cast<const uint4v *>(x + c * 8);
@@ -108,8 +124,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
                 *reinterpret_cast<float4v *>(xs + c * 8 + 4) = *reinterpret_cast<const float4v *>(x + c * 8 + 4);
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
 
     for (int g = gw; g < ngroups; g += nw) {
         int rows[R];
@@ -130,26 +146,32 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
                 float xv[8];
                 load8(xs + (c0 + 64 * u) * 8, xv);
 #pragma unroll
-                for (int r = 0; r < R; r++)
+                for (int r = 0; r < R; r++) {
+                    float wv[8];
+                    unpack_raw<WT>(pre[r][u], wv);
 #pragma unroll
-                    for (int j = 0; j < 8; j++) acc[r] = fmaf(pre[r][u][j], xv[j], acc[r]);
+                    for (int j = 0; j < 8; j++) acc[r] = fmaf(wv[j], xv[j], acc[r]);
+                }
             }
             c0 += 64 * U;
         }
         for (; c0 + 64 * (U - 1) < nchunk; c0 += 64 * U) {      // full blocks of U chunks: no predicates
-            float w[R][U][8];
+            uint4v w[R][U][sizeof(WT) == 2 ? 1 : 2];
 #pragma unroll
             for (int u = 0; u < U; u++)
 #pragma unroll
-                for (int r = 0; r < R; r++) load8_nt(wp[r] + (size_t)(c0 + 64 * u) * 8, w[r][u]);
+                for (int r = 0; r < R; r++) load_raw_nt(wp[r] + (size_t)(c0 + 64 * u) * 8, w[r][u]);
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 float xv[8];
                 load8(xs + (c0 + 64 * u) * 8, xv);
 #pragma unroll
-                for (int r = 0; r < R; r++)
+                for (int r = 0; r < R; r++) {
+                    float wv[8];
+                    unpack_raw<WT>(w[r][u], wv);
 #pragma unroll
-                    for (int j = 0; j < 8; j++) acc[r] = fmaf(w[r][u][j], xv[j], acc[r]);
+                    for (int j = 0; j < 8; j++) acc[r] = fmaf(wv[j], xv[j], acc[r]);
+                }
             }
         }
         for (; c0 < nchunk; c0 += 64) {                          // tail
@@ -164,7 +186,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
             }
         }
 #pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);
+        for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]) * inv_m;
         if (lane == 0) {
             if (epi == EPI_GATEUP) {
 #pragma unroll
@@ -238,14 +260,23 @@ static int launch_gemv_t(Launcher &L, const GemvArgs &a) {
             raised.store(lds);
         }
     }
-    int64_t ngroups = (N + R - 1) / R;
-    int64_t blocks = (ngroups + 3) / 4;
-    // grid-stride beyond the cap so that x is staged (or the norm recomputed) a bounded number of times
+    // Grid: every wave should get the same number of row groups (a ragged last round costs up to
+    // 1/rounds of the kernel), and all workgroups should be resident at once (<= cap).
+    const int64_t ngroups = (N + R - 1) / R;
     int mb = g_gemv_maxblocks.load(), mbn = g_gemv_maxblocks_norm.load();
-    if (!mb) { mb = env_int("FL_GEMV_MAXBLOCKS", 2048); g_gemv_maxblocks = mb; }
-    if (!mbn) { mbn = env_int("FL_GEMV_MAXBLOCKS_NORM", 1024); g_gemv_maxblocks_norm = mbn; }
+    if (!mb) { mb = env_int("FL_GEMV_MAXBLOCKS", 768); g_gemv_maxblocks = mb; }
+    if (!mbn) { mbn = env_int("FL_GEMV_MAXBLOCKS_NORM", 768); g_gemv_maxblocks_norm = mbn; }
     const int64_t cap = PRO == PRO_NORM ? mbn : mb;
-    if (blocks > cap) blocks = cap;
+    int64_t blocks = (ngroups + 3) / 4;
+    if (blocks > cap) {
+        double best_eff = 0.0; int64_t best_b = cap;
+        for (int64_t b = cap; b >= cap / 2 && b >= 1; b--) {
+            const int64_t per_wave = (ngroups + 4 * b - 1) / (4 * b);
+            const double eff = (double)ngroups / (double)(per_wave * 4 * b);
+            if (eff > best_eff + 1e-9) { best_eff = eff; best_b = b; }
+        }
+        blocks = best_b;
+    }
     double bytes = (double)N * K * sizeof(WT);
     return L.launch(KC_GEMV, bytes, 2.0 * N * K, kern, dim3((unsigned)blocks), dim3(256), lds, a);
 }

@@ -25,7 +25,8 @@ static int env_int(const char *name, int dflt) {
 template <typename WT, typename XT>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(const WT *__restrict__ W, const XT *__restrict__ X,
                                                            const float *__restrict__ bias, void *__restrict__ out,
-                                                           int T, int N, int K, int epi) {
+                                                           int T, int N, int K, int epi,
+                                                           const float *__restrict__ row_scale) {
     __shared__ float xs[16][64 + 1];
     __shared__ float ws[16][64 + 1];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -55,6 +56,11 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const WT *__restrict_
     for (int i = 0; i < 4; i++) {
         int m = m0 + ty * 4 + i;
         if (m >= T) continue;
+        if (row_scale) {
+            const float rs = row_scale[m];
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] *= rs;
+        }
         if (epi == EPI_GATEUP) {
 #pragma unroll
             for (int j = 0; j < 4; j += 2) {
@@ -78,34 +84,36 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const WT *__restrict_
 
 template <typename WT, typename XT>
 static int launch_gemm_generic(Launcher &L, const void *W, const void *x, const float *bias, void *y,
-                               int64_t T, int64_t N, int64_t K, int epi) {
+                               int64_t T, int64_t N, int64_t K, int epi, const float *row_scale) {
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((T + 63) / 64));
     double bytes = (double)N * K * sizeof(WT) + (double)T * K * sizeof(XT);
     return L.launch(KC_GEMM_GENERIC, bytes, 2.0 * T * N * K, gemm_generic_kernel<WT, XT>, grid, dim3(256), 0,
-                    (const WT *)W, (const XT *)x, bias, y, (int)T, (int)N, (int)K, epi);
+                    (const WT *)W, (const XT *)x, bias, y, (int)T, (int)N, (int)K, epi, row_scale);
 }
 
 int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bias, void *y,
-                     int64_t T, int64_t N, int64_t K, int epi);   // k_gemm_mfma.hip
+                     int64_t T, int64_t N, int64_t K, int epi, const float *row_scale);   // k_gemm_mfma.hip
 
-static GemvArgs plain_args(const void *W, const void *x, const float *bias, void *y, int64_t N, int64_t K, int epi) {
+static GemvArgs plain_args(const void *W, const void *x, const float *bias, void *y, int64_t N, int64_t K, int epi,
+                           const float *scale) {
     GemvArgs a; a.W = W; a.x = x; a.bias = bias; a.out = y; a.N = (int)N; a.K = (int)K; a.epi = epi; a.pro = PRO_X;
+    a.x_scale = scale;
     return a;
 }
 
 int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const float *bias, void *y,
-                  int64_t T, int64_t N, int64_t K, int epi) {
+                  int64_t T, int64_t N, int64_t K, int epi, const float *row_scale) {
     if (T <= 0 || N <= 0 || K <= 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "launch_linear: bad shape");
     if (epi == EPI_GATEUP && N % 32) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gate/up matrix rows must be a multiple of 32");
     static const int force_generic = env_int("FL_FORCE_GENERIC_GEMM", 0);
     if (dtype == FL_DTYPE_BF16) {
-        if (T == 1 && gemv_supported(dtype, N, K)) return launch_gemv(L, dtype, plain_args(W, x, bias, y, N, K, epi));
-        if (!force_generic && gemm_mfma_supported(dtype, T, N, K)) return launch_gemm_mfma(L, W, x, bias, y, T, N, K, epi);
-        return launch_gemm_generic<bf16_t, bf16_t>(L, W, x, bias, y, T, N, K, epi);
+        if (T == 1 && gemv_supported(dtype, N, K)) return launch_gemv(L, dtype, plain_args(W, x, bias, y, N, K, epi, row_scale));
+        if (!force_generic && gemm_mfma_supported(dtype, T, N, K)) return launch_gemm_mfma(L, W, x, bias, y, T, N, K, epi, row_scale);
+        return launch_gemm_generic<bf16_t, bf16_t>(L, W, x, bias, y, T, N, K, epi, row_scale);
     }
     if (dtype == FL_DTYPE_F32) {
-        if (T == 1 && gemv_supported(dtype, N, K)) return launch_gemv(L, dtype, plain_args(W, x, bias, y, N, K, epi));
-        return launch_gemm_generic<float, float>(L, W, x, bias, y, T, N, K, epi);
+        if (T == 1 && gemv_supported(dtype, N, K)) return launch_gemv(L, dtype, plain_args(W, x, bias, y, N, K, epi, row_scale));
+        return launch_gemm_generic<float, float>(L, W, x, bias, y, T, N, K, epi, row_scale);
     }
     FL_FAIL(FL_ERR_UNSUPPORTED, "launch_linear: unsupported dtype %d", dtype);
 }

@@ -39,18 +39,21 @@ int launch_embed(Launcher &L, int dtype, const void *E, const uint32_t *ids, con
 // ------------------------------------------------------------------------------- rmsnorm (+add)
 // candle_nn::ops::rms_norm (App. A.2): m = sqrt(sum(x^2)/h + eps), y = x / m * w, sum in fp32.
 // Fused with the preceding residual add (x_res += delta) so the residual stream is read once.
+// Emits xs = x * w and inv_rms = 1/m separately: y = inv_rms * xs is finished by the consumer's
+// epilogue (single pass over x here, and the same rounding point as the fused decode prologue).
 template <typename OT>
 __global__ __launch_bounds__(256) void rmsnorm_add_kernel(float *__restrict__ x_res, const float *__restrict__ delta,
                                                           const float *__restrict__ w, float eps,
-                                                          OT *__restrict__ xn, int h) {
+                                                          OT *__restrict__ xs, float *__restrict__ inv_rms, int h) {
     __shared__ float red[4];
     const int t = blockIdx.x, tid = threadIdx.x;
     float *xr = x_res + (size_t)t * h;
     const float *dr = delta ? delta + (size_t)t * h : nullptr;
     float ss = 0.f;
     for (int c = tid; c * 8 < h; c += 256) {
-        float v[8];
+        float v[8], wv[8], o[8];
         load8(xr + c * 8, v);
+        load8(w + c * 8, wv);
         if (dr) {
             float d[8];
             load8(dr + c * 8, d);
@@ -59,31 +62,23 @@ __global__ __launch_bounds__(256) void rmsnorm_add_kernel(float *__restrict__ x_
             store8(xr + c * 8, v);
         }
 #pragma unroll
-        for (int j = 0; j < 8; j++) ss = fmaf(v[j], v[j], ss);
+        for (int j = 0; j < 8; j++) { ss = fmaf(v[j], v[j], ss); o[j] = v[j] * wv[j]; }
+        store8(xs + (size_t)t * h + c * 8, o);
     }
     ss = wave_sum(ss);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
-    ss = red[0] + red[1] + red[2] + red[3];
-    const float m = sqrtf(ss / (float)h + eps);
-    for (int c = tid; c * 8 < h; c += 256) {
-        float v[8], wv[8], o[8];
-        load8(xr + c * 8, v);          // own writes: same thread, same addresses
-        load8(w + c * 8, wv);
-#pragma unroll
-        for (int j = 0; j < 8; j++) o[j] = v[j] / m * wv[j];
-        store8(xn + (size_t)t * h + c * 8, o);
-    }
+    if (tid == 0) inv_rms[t] = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)h + eps);
 }
 
 int launch_rmsnorm_add(Launcher &L, int dtype, float *x_res, const float *delta, const float *w, float eps,
-                       void *xn, int64_t T, int64_t h) {
+                       void *xs, float *inv_rms, int64_t T, int64_t h) {
     double bytes = (double)T * h * (4.0 * (delta ? 3 : 1) + (dtype == FL_DTYPE_BF16 ? 2 : 4));
     if (dtype == FL_DTYPE_BF16)
         return L.launch(KC_RMSNORM, bytes, 0, rmsnorm_add_kernel<bf16_t>, dim3((unsigned)T), dim3(256), 0,
-                        x_res, delta, w, eps, (bf16_t *)xn, (int)h);
+                        x_res, delta, w, eps, (bf16_t *)xs, inv_rms, (int)h);
     return L.launch(KC_RMSNORM, bytes, 0, rmsnorm_add_kernel<float>, dim3((unsigned)T), dim3(256), 0,
-                    x_res, delta, w, eps, (float *)xn, (int)h);
+                    x_res, delta, w, eps, (float *)xs, inv_rms, (int)h);
 }
 
 // ------------------------------------------------------------------------------- RoPE + KV append
@@ -149,7 +144,18 @@ __global__ __launch_bounds__(1024) void argmax_advance_kernel(const float *__res
     __shared__ int bi[16];
     const int tid = threadIdx.x;
     float best = -INFINITY; int idx = -1;
-    for (int i = tid; i < V; i += 1024) {
+    int i = tid;
+    for (; i + 7 * 1024 < V; i += 8 * 1024) {          // 8 independent loads in flight
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = logits[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int ii = i + u * 1024;
+            if (idx < 0 || v[u] > best || (v[u] == best && ii > idx)) { best = v[u]; idx = ii; }
+        }
+    }
+    for (; i < V; i += 1024) {
         float v = logits[i];
         if (idx < 0 || v > best || (v == best && i > idx)) { best = v; idx = i; }
     }

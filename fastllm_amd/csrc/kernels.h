@@ -45,6 +45,7 @@ enum { PRO_X = 0, PRO_NORM = 1 };
 struct GemvArgs {
     const void *W = nullptr;        // [N,K] compute dtype
     const void *x = nullptr;        // PRO_X: [K] compute dtype
+    const float *x_scale = nullptr; // PRO_X: optional scalar applied to the accumulator (1/rms)
     const float *bias = nullptr;    // [N] or null
     void *out = nullptr;            // EPI_F32: float[N]; EPI_GATEUP: XT[N/2]
     int N = 0, K = 0, epi = EPI_F32, pro = PRO_X;
@@ -70,8 +71,10 @@ __host__ __device__ inline int64_t gateup_row(int64_t q, int is_up) { return (q 
 // y = x[T,K] . W[N,K]^T (+bias).  EPI_F32: y fp32 [T,N].  EPI_GATEUP: W is the 16-interleaved
 // gate/up matrix (N = 2*I rows), y is XT [T, I] = silu(gate)*up.
 // dtype FL_DTYPE_BF16: W and x (and gate-up y) bf16; FL_DTYPE_F32: all fp32.
+// row_scale (optional, fp32 [T]): y[t,:] = row_scale[t] * (x[t,:] . W^T) (+bias) -- the 1/rms factor of
+// a preceding RMSNorm, applied after the dot product (see launch_rmsnorm_add).
 int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const float *bias, void *y,
-                  int64_t T, int64_t N, int64_t K, int epi);
+                  int64_t T, int64_t N, int64_t K, int epi, const float *row_scale = nullptr);
 // cheap capability probes used by tests / DESIGN numbers
 bool gemv_supported(int dtype, int64_t N, int64_t K);
 bool gemm_mfma_supported(int dtype, int64_t T, int64_t N, int64_t K);
@@ -80,9 +83,11 @@ bool gemm_mfma_supported(int dtype, int64_t T, int64_t N, int64_t K);
 // x_res[t,:] = E[ids[t],:]; ids == nullptr: single token read from st->token
 int launch_embed(Launcher &L, int dtype, const void *E, const uint32_t *ids, const StepState *st,
                  float *x_res, int64_t T, int64_t h);
-// x_res += delta (if delta); xn = x_res / sqrt(mean(x_res^2)+eps) * w.  rows T, width h.
+// x_res += delta (if delta); xs = x_res * w (compute dtype); inv_rms[t] = 1/sqrt(mean(x_res^2)+eps).
+// RMSNorm(x) * w == inv_rms * xs: the scalar is applied by the consuming projection's epilogue, so
+// the bf16 rounding point (xs) is the same in the prefill and the fused decode path.
 int launch_rmsnorm_add(Launcher &L, int dtype, float *x_res, const float *delta, const float *w,
-                       float eps, void *xn, int64_t T, int64_t h);
+                       float eps, void *xs, float *inv_rms, int64_t T, int64_t h);
 // RoPE(q,k) + KV append.  qkv fp32 [T, (H+2Hkv)*d]; q_out XT [T,H*d]; caches XT [Hkv][max_seq][d]
 int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st, const float *cos_tab,
                    const float *sin_tab, int64_t max_pos, void *q_out, void *k_cache, void *v_cache,

@@ -36,7 +36,8 @@ struct Scratch {                 // activations of one forward chunk on one shar
     float *x_res = nullptr;      // [T,h] fp32 residual stream
     float *x_res2 = nullptr;     // decode only: ping-pong partner of x_res for the fused norm prologue
     float *delta = nullptr;      // [T,h] fp32 output of o_proj / down_proj (all-reduced under TP)
-    void *xn = nullptr;          // [T,h] normed activations (compute dtype)
+    void *xn = nullptr;          // [T,h] x * norm_weight (compute dtype); RMSNorm = inv_rms * xn
+    float *inv_rms = nullptr;    // [T]
     float *qkv = nullptr;        // [T,(Hs+2Hkvs)*d] fp32
     void *q = nullptr;           // [T,Hs*d]
     void *ao = nullptr;          // [T,Hs*d] attention output

@@ -303,6 +303,7 @@ static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T) {
     if (T == 1) FL_TRY(dev_alloc(sh.allocs, (void **)&sc.x_res2, (size_t)D.h * 4, &m->hbm_bytes));
     FL_TRY(dev_alloc(sh.allocs, (void **)&sc.delta, (size_t)T * D.h * 4, &m->hbm_bytes));
     FL_TRY(dev_alloc(sh.allocs, &sc.xn, (size_t)T * D.h * es, &m->hbm_bytes));
+    FL_TRY(dev_alloc(sh.allocs, (void **)&sc.inv_rms, (size_t)T * 4, &m->hbm_bytes));
     FL_TRY(dev_alloc(sh.allocs, (void **)&sc.qkv, (size_t)T * nq * 4, &m->hbm_bytes));
     FL_TRY(dev_alloc(sh.allocs, &sc.q, (size_t)T * sh.Hs * D.d * es, &m->hbm_bytes));
     FL_TRY(dev_alloc(sh.allocs, &sc.ao, (size_t)T * sh.Hs * D.d * es, &m->hbm_bytes));
@@ -417,10 +418,10 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
     const Dims &D = m->D;
     std::unique_ptr<Cache> c(new Cache());
     c->m = m; c->max_seq = max_seq; c->len = 0;
-    // split-S: ~32 keys per workgroup at full length, at most ~512 workgroups per launch
-    int64_t ns = (int64_t)((max_seq + 31) / 32);
-    int64_t cap = std::max<int64_t>(1, 512 / std::max<int64_t>(1, m->shards[0].Hkvs));
-    c->nsplit = (int)std::max<int64_t>(1, std::min(ns, cap));
+    // decode attention: one 16-wave workgroup per kv head streams up to 2048 cached positions with
+    // no cross-workgroup combine; longer caches split S (k_attn.hip)
+    int64_t ns = (int64_t)((max_seq + 2047) / 2048);
+    c->nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(ns, 64));
     c->nsplit = env_int("FL_ATTN_NSPLIT", c->nsplit);
     c->shards.resize(m->shards.size());
     for (size_t i = 0; i < m->shards.size(); i++) {
@@ -575,8 +576,8 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             const int64_t nq = (sh.Hs + 2 * sh.Hkvs) * D.d;
             const size_t kv_layer = (size_t)l * sh.Hkvs * c->max_seq * D.d * m->esize();
             void *kc = (char *)cs.k + kv_layer, *vc = (char *)cs.v + kv_layer;
-            FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, l == 0 ? nullptr : sc.delta, ly.ln1, D.eps, sc.xn, T, D.h));
-            FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, ly.bqkv, sc.qkv, T, nq, D.h, EPI_F32));
+            FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, l == 0 ? nullptr : sc.delta, ly.ln1, D.eps, sc.xn, sc.inv_rms, T, D.h));
+            FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, ly.bqkv, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms));
             FL_TRY(launch_rope_kv(L, dt, sc.qkv, cs.st, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, kc, vc, T, sh.Hs, sh.Hkvs, D.d, (int64_t)c->max_seq));
             if (T == 1) {
                 AttnScratch as{cs.part_m, cs.part_l, cs.part_o, cs.counters, c->nsplit, len_hint + 1};
@@ -591,8 +592,8 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             Shard &sh = m->shards[i]; Scratch &sc = SC(sh); LayerW &ly = sh.layers[l];
             FL_HIP(hipSetDevice(sh.device));
             Launcher L = make_launcher(m, sh);
-            FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, sc.delta, ly.ln2, D.eps, sc.xn, T, D.h));
-            FL_TRY(launch_linear(L, dt, ly.wgu, sc.xn, nullptr, sc.act, T, 2 * sh.Ip, D.h, EPI_GATEUP));
+            FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, sc.delta, ly.ln2, D.eps, sc.xn, sc.inv_rms, T, D.h));
+            FL_TRY(launch_linear(L, dt, ly.wgu, sc.xn, nullptr, sc.act, T, 2 * sh.Ip, D.h, EPI_GATEUP, sc.inv_rms));
             FL_TRY(launch_linear(L, dt, ly.wd, sc.act, nullptr, sc.delta, T, D.h, sh.Ip, EPI_F32));
         }
         FL_TRY(all_reduce_delta(m, pre, T * D.h));
@@ -604,8 +605,8 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
         Launcher L = make_launcher(m, sh);
         float *xl = sc.x_res + (size_t)(T - 1) * D.h, *dl = sc.delta + (size_t)(T - 1) * D.h;
         void *xnl = (char *)sc.xn + (size_t)(T - 1) * D.h * m->esize();
-        FL_TRY(launch_rmsnorm_add(L, dt, xl, dl, sh.norm, D.eps, xnl, 1, D.h));
-        FL_TRY(launch_linear(L, dt, sh.lm_head, xnl, nullptr, sh.logits_local, 1, sh.Vs, D.h, EPI_F32));
+        FL_TRY(launch_rmsnorm_add(L, dt, xl, dl, sh.norm, D.eps, xnl, sc.inv_rms + (T - 1), 1, D.h));
+        FL_TRY(launch_linear(L, dt, sh.lm_head, xnl, nullptr, sh.logits_local, 1, sh.Vs, D.h, EPI_F32, sc.inv_rms + (T - 1)));
     }
     FL_TRY(gather_logits(m));
     return FL_OK;

@@ -292,8 +292,9 @@ static void rmsnorm_fwd(const orc_model *m, const float *x, const float *w, int6
         for (int64_t i = 0; i < h; i++) ss += xr[i] * xr[i];
         float r = sqrtf(ss / (float)h + m->eps);
         for (int64_t i = 0; i < h; i++) {
-            float v = xr[i] / r * w[i];
-            yr[i] = m->round_bf16 ? round_bf16f(v) : v;
+            /* bf16 emulation: the MI355X path stores x*w in bf16 and applies 1/rms after the
+             * projection's dot product, so the rounding point is x*w */
+            yr[i] = m->round_bf16 ? round_bf16f(xr[i] * w[i]) / r : xr[i] / r * w[i];
         }
     }
 }

@@ -71,7 +71,7 @@ typedef void (*orc_allreduce_fn)(float *buf, size_t n, void *ctx);
 
 /* round_bf16 = 0: pure fp32 arithmetic (the "reference CPU provider" mode).
  * round_bf16 = 1: fp32 arithmetic, but activations are rounded to bf16 at the
- *   tensor boundaries where the MI355X bf16 path stores bf16 (normed x, q/k/v
+ *   tensor boundaries where the MI355X bf16 path stores bf16 (x*norm_weight, q/k/v
  *   after RoPE, attention output, SiLU-gate product).  Residual stream, norms,
  *   softmax and logits stay fp32. */
 int  orc_model_create(const orc_config *cfg, const orc_tensor *tensors, size_t n,

@@ -233,3 +233,22 @@ def test_unfused_decode_path_matches_fused(fa, monkeypatch):
         gm.forward(c, ids[:8], 0)
         outs.append(gm.forward(c, ids[8:9], 8))
     np.testing.assert_allclose(outs[0], outs[1], atol=1e-5, rtol=0)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("name", ["llama_a", "mistral_a", "qwen2_a"])
+def test_decode_split_s_path(fa, name, dtype):
+    """Cache capacity > 2048 positions makes the decode attention split S across workgroups and
+    combine in-launch (ticket + release/acquire); results must not depend on the split."""
+    cfg = synth.CONFIGS[name]
+    w = synth.synth_weights(cfg)
+    gm, om = _models(fa, cfg, w, dtype)
+    ids = synth.prompt_ids(cfg, 40, seed=5)
+    big, small, oc = gm.new_cache(7000), gm.new_cache(64), om.new_cache(64)
+    gm.forward(big, ids[:30], 0); gm.forward(small, ids[:30], 0); om.forward(oc, ids[:30], 0)
+    for i in range(30, 40):
+        a = gm.forward(big, ids[i:i + 1], i)
+        b = gm.forward(small, ids[i:i + 1], i)
+        o = om.forward(oc, ids[i:i + 1], i)
+        check_logits(a, o, dtype, "split-S decode step %d" % i)
+        np.testing.assert_allclose(a, b, atol=1e-4 if dtype == "f32" else 5e-2, rtol=0)
