@@ -10,6 +10,8 @@
 // dot-product reduce (wavefront shuffles) -- and the states are merged once at the end:
 // key-slots by shuffles, waves through LDS, split-S workgroups through a small fp32 partial
 // buffer + combine kernel.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace fl {
@@ -276,11 +278,16 @@ int launch_attn_decode(Launcher &L, int dtype, const void *q, const void *k_cach
                        int64_t max_seq, float scale) {
     const int G = (int)(H / Hkv);
     const bool small = G <= 4;
+    static const int nw = getenv("FL_ATTN_NW") ? atoi(getenv("FL_ATTN_NW")) : 4;
 #define FL_DISPATCH(CT)                                                                                        \
-    if (d == 128) return small ? launch_decode_t<CT, 128, 4, 16>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale) \
+    if (d == 128 && nw >= 16) return small ? launch_decode_t<CT, 128, 4, 16>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale) \
                                : launch_decode_t<CT, 128, 8, 8>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale); \
-    if (d == 64) return small ? launch_decode_t<CT, 64, 4, 16>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale)   \
-                              : launch_decode_t<CT, 64, 8, 8>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale);
+    if (d == 64 && nw >= 16) return small ? launch_decode_t<CT, 64, 4, 16>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale)   \
+                              : launch_decode_t<CT, 64, 8, 8>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale); \
+    if (d == 128) return small ? launch_decode_t<CT, 128, 4, 4>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale) \
+                               : launch_decode_t<CT, 128, 8, 4>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale); \
+    if (d == 64) return small ? launch_decode_t<CT, 64, 4, 4>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale)   \
+                              : launch_decode_t<CT, 64, 8, 4>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale);
     if (dtype == FL_DTYPE_BF16) { FL_DISPATCH(bf16_t) }
     else { FL_DISPATCH(float) }
 #undef FL_DISPATCH

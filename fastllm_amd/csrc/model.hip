@@ -5,7 +5,7 @@
 //   config defaults + validation   llama.rs:31-50, mistral.rs:93-154, qwen.rs:30-56, config.rs:31-54
 //   weights bound by HF name       llama.rs:112-120, mistral.rs:190-192, qwen.rs:108-109
 //   forward(input, pos, cache)     llama.rs:147-149, mistral.rs:206-236, qwen.rs:123-151
-// The arithmetic follows candle 0.8.x, restated in oracle/ for tests.
+// The arithmetic follows candle 0.8.x.
 //
 // HBM layout (per shard; compute dtype = bf16 or fp32):
 //   wqkv [(Hs+2Hkvs)d, h]  fused q|k|v rows       wo [h, Hs*d]
@@ -406,6 +406,14 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
         FL_HIP(hipMalloc((void **)&m->emu_ptrs, sizeof(float *) * tp * 2));
     } else if (tp > 1) {
         FL_FAIL(FL_ERR_BAD_ARGUMENT, "tp_size %d needs a tensor-parallel mode", tp);
+    } else if (env_int("FL_DEBUG_RCCL_SELF", 0)) {
+        // single-GPU rehearsal of the RCCL plumbing: a 1-rank communicator whose all-reduce is the
+        // identity, issued at the two real call sites (after o_proj and down_proj) on the compute stream
+        ncclUniqueId id;
+        FL_NCCL(ncclGetUniqueId(&id));
+        FL_HIP(hipSetDevice(m->shards[0].device));
+        FL_NCCL(ncclCommInitRank(&m->shards[0].comm, 1, id, 0));
+        m->use_graph = env_int("FL_GRAPH", 0) != 0;     // eager unless graph capture of RCCL is asked for
     }
     *out = m.release();
     return FL_OK;
@@ -418,9 +426,9 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
     const Dims &D = m->D;
     std::unique_ptr<Cache> c(new Cache());
     c->m = m; c->max_seq = max_seq; c->len = 0;
-    // decode attention: one 16-wave workgroup per kv head streams up to 2048 cached positions with
-    // no cross-workgroup combine; longer caches split S (k_attn.hip)
-    int64_t ns = (int64_t)((max_seq + 2047) / 2048);
+    // decode attention splits S so that the K/V stream of one kv head is spread over many CUs
+    // (~64 cached positions per 4-wave workgroup at full length); partials are combined in-launch
+    int64_t ns = (int64_t)((max_seq + 63) / 64);
     c->nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(ns, 64));
     c->nsplit = env_int("FL_ATTN_NSPLIT", c->nsplit);
     c->shards.resize(m->shards.size());
@@ -455,7 +463,7 @@ static Launcher make_launcher(Model *m, Shard &sh) {
 
 // all-reduce(sum) of each local shard's `delta` [count] fp32 (after o_proj / down_proj rows)
 static int all_reduce_delta(Model *m, bool pre, int64_t count) {
-    if (m->tp == 1) return FL_OK;
+    if (m->tp == 1 && !m->shards[0].comm) return FL_OK;
     if (m->tp_mode == FL_TP_EMULATED) {
         std::vector<float *> ptrs;
         for (auto &sh : m->shards) ptrs.push_back(pre ? sh.pre.delta : sh.dec.delta);

@@ -1,0 +1,448 @@
+// fastllm_host.hpp -- host-side mirror of FastLLM's model-trait surface for the causal-LM forward
+// path, written in C++ over the C ABI (include/fastllm_mi355x.h).
+//
+// The reference's host language is Rust and there is no Rust toolchain in the build image, so the
+// layer a Rust maintainer would write as `impl ModelInitializer for Mi355xWithConfig`
+// (INTEGRATION.md shows that binding) is mirrored here 1:1 in C++: same type names, same argument
+// meaning, same error behaviour, so the parity tests read like the reference's own unit tests.
+//
+//   reference item                                   mirror
+//   ------------------------------------------------ -----------------------------------------
+//   trait ModelInitializer  (model_initializer.rs:6-22)   static initialize_model / initialize_cache, forward
+//   trait ModelArchitecture (model_initializer.rs:24-27)  static get_family / supports_architecture
+//   trait ModelCache, CommonCache (cache.rs:5-42)          struct ModelCache, CommonCache
+//   BaseModelConfig + ModelConfigValidation (config.rs)    struct BaseModelConfig
+//   llama::ConfigFile, LlamaCache, LlamaWithConfig         same names (llama.rs:18-159)
+//   mistral::ConfigFile, MistralCache, MistralWithConfig   same names (mistral.rs:16-247)
+//   QwenCache, QwenWithConfig                              same names (qwen.rs:13-184)
+//   Model<M>::generate (mod.rs:363-463)                    Model<M>::generate_ids (token ids in/out;
+//                                                          the tokenizer is outside the hot path)
+//
+// Errors: anyhow::Result -> fastllm::Error (exception, carries the fl_status code); config
+// violations that `assert!`/`expect` in the reference (mistral.rs:109-127, qwen.rs:32-37) throw
+// fastllm::Panic.  There is no CPU fallback: Device::Cpu is rejected by initialize_model.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "../../include/fastllm_mi355x.h"
+
+namespace fastllm {
+
+// ------------------------------------------------------------------------------------ errors
+struct Error : std::runtime_error {          // anyhow::Error
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+struct Panic : std::logic_error {            // assert!/expect in the reference
+    explicit Panic(const std::string &m) : std::logic_error(m) {}
+};
+inline void check(int rc, const char *ctx) {
+    if (rc != FL_OK) throw Error(rc, std::string(ctx) + ": " + fl_last_error());
+}
+
+// ------------------------------------------------------------------------------------ candle stand-ins
+enum class DType { F32 = FL_DTYPE_F32, BF16 = FL_DTYPE_BF16, F16 = FL_DTYPE_F16 };   // candle_core::DType
+
+struct Device {                               // candle_core::Device
+    enum Kind { Cpu, Mi355x } kind = Cpu;
+    std::vector<int32_t> ordinals;            // one GPU, or the TP group driven by this process
+    static Device cpu() { return Device{}; }
+    static Device mi355x(int ordinal = 0) { Device d; d.kind = Mi355x; d.ordinals = {ordinal}; return d; }
+    static Device mi355x_tp(std::vector<int32_t> ords) { Device d; d.kind = Mi355x; d.ordinals = std::move(ords); return d; }
+    // main.rs:81-97 on linux: Device::cuda_if_available(0) -> the accelerator when present, else Cpu
+    static Device cuda_if_available(int ordinal) {
+        int n = 0; fl_device_count(&n);
+        return n > ordinal ? mi355x(ordinal) : cpu();
+    }
+    bool is_cpu() const { return kind == Cpu; }
+};
+
+struct Tensor {                               // a borrowed view, like the HashMap<String, Tensor> entries
+    DType dtype = DType::F32;
+    std::vector<int64_t> shape;
+    const void *data = nullptr;
+    int32_t device = -1;                      // -1 host
+    std::shared_ptr<void> owner;              // keeps host storage alive when the tensor owns it
+
+    static Tensor from_ids(const std::vector<uint32_t> &ids) {          // Tensor::new(ids, dev).reshape((1,T))
+        auto buf = std::make_shared<std::vector<uint32_t>>(ids);
+        Tensor t; t.dtype = DType::F32; t.shape = {1, (int64_t)ids.size()}; t.data = buf->data(); t.owner = buf;
+        return t;
+    }
+    std::pair<int64_t, int64_t> dims2() const {
+        if (shape.size() != 2) throw Error(FL_ERR_SHAPE_MISMATCH, "unexpected rank, expected 2");
+        return {shape[0], shape[1]};
+    }
+    // logits.get(0)?.flatten_all()?.to_vec1::<f32>()  (mod.rs:421; LogitsProcessor::sample)
+    const float *f32() const { return static_cast<const float *>(data); }
+    int64_t elem_count() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+using TensorMap = std::unordered_map<std::string, Tensor>;
+
+// ------------------------------------------------------------------------------------ cache.rs
+struct ModelCache {                           // cache.rs:5-10
+    virtual void increment_offset() = 0;
+    virtual void reset() = 0;
+    virtual size_t get_offset() const = 0;
+    virtual ~ModelCache() = default;
+};
+struct CommonCache : ModelCache {             // cache.rs:13-42
+    size_t seqlen_offset = 0;
+    void increment_offset() override { seqlen_offset += 1; }
+    void reset() override { seqlen_offset = 0; }
+    size_t get_offset() const override { return seqlen_offset; }
+};
+
+// ------------------------------------------------------------------------------------ minimal JSON (config.json)
+namespace detail {
+struct JsonFlat {                             // top-level object: numbers, strings, null/bool; nested values skipped
+    std::unordered_map<std::string, std::string> raw;
+    static void skip_ws(const std::string &s, size_t &i) { while (i < s.size() && std::isspace((unsigned char)s[i])) i++; }
+    static std::string parse_string(const std::string &s, size_t &i) {
+        std::string out; i++;
+        while (i < s.size() && s[i] != '"') { if (s[i] == '\\' && i + 1 < s.size()) i++; out += s[i++]; }
+        if (i >= s.size()) throw Error(FL_ERR_BAD_CONFIG, "unterminated string in config JSON");
+        i++; return out;
+    }
+    static void skip_value(const std::string &s, size_t &i) {
+        int depth = 0;
+        while (i < s.size()) {
+            char c = s[i];
+            if (c == '"') { parse_string(s, i); continue; }
+            if (c == '{' || c == '[') depth++;
+            else if (c == '}' || c == ']') { if (depth == 0) return; depth--; }
+            else if (c == ',' && depth == 0) return;
+            i++;
+        }
+    }
+    explicit JsonFlat(const std::string &s) {
+        size_t i = 0; skip_ws(s, i);
+        if (i >= s.size() || s[i] != '{') throw Error(FL_ERR_BAD_CONFIG, "config JSON must be an object");
+        i++;
+        while (true) {
+            skip_ws(s, i);
+            if (i < s.size() && s[i] == '}') break;
+            if (i >= s.size() || s[i] != '"') throw Error(FL_ERR_BAD_CONFIG, "malformed config JSON");
+            std::string key = parse_string(s, i);
+            skip_ws(s, i);
+            if (i >= s.size() || s[i] != ':') throw Error(FL_ERR_BAD_CONFIG, "malformed config JSON (missing ':')");
+            i++; skip_ws(s, i);
+            size_t b = i;
+            if (s[i] == '"') { std::string v = parse_string(s, i); raw[key] = "\"" + v; }
+            else { skip_value(s, i); std::string v = s.substr(b, i - b); while (!v.empty() && std::isspace((unsigned char)v.back())) v.pop_back(); raw[key] = v; }
+            skip_ws(s, i);
+            if (i < s.size() && s[i] == ',') { i++; continue; }
+            if (i < s.size() && s[i] == '}') break;
+            throw Error(FL_ERR_BAD_CONFIG, "malformed config JSON");
+        }
+    }
+    bool has(const std::string &k) const { auto it = raw.find(k); return it != raw.end() && it->second != "null"; }
+    double num(const std::string &k) const {                  // serde: missing non-Option field is an error
+        auto it = raw.find(k);
+        if (it == raw.end() || it->second == "null") throw Error(FL_ERR_BAD_CONFIG, "missing field `" + k + "`");
+        char *end = nullptr; double v = std::strtod(it->second.c_str(), &end);
+        if (end == it->second.c_str()) throw Error(FL_ERR_BAD_CONFIG, "invalid type for field `" + k + "`");
+        return v;
+    }
+    std::optional<double> opt(const std::string &k) const { return has(k) ? std::optional<double>(num(k)) : std::nullopt; }
+    std::optional<std::string> str(const std::string &k) const {
+        auto it = raw.find(k);
+        if (it == raw.end() || it->second.empty() || it->second[0] != '"') return std::nullopt;
+        return it->second.substr(1);
+    }
+};
+}  // namespace detail
+
+// ------------------------------------------------------------------------------------ config.rs
+struct BaseModelConfig {                      // config.rs:6-18 (also llama::ConfigFile llama.rs:18-29, mistral::ConfigFile mistral.rs:80-92)
+    size_t hidden_size = 0, intermediate_size = 0, vocab_size = 0, num_hidden_layers = 0, num_attention_heads = 0;
+    std::optional<size_t> num_key_value_heads;
+    double rms_norm_eps = 0;
+    std::optional<double> rope_theta;
+    std::optional<size_t> max_position_embeddings;
+    std::optional<size_t> sliding_window;
+    std::optional<std::string> torch_dtype;
+
+    static BaseModelConfig from_json(const std::string &text) {          // serde_json::from_str (huggingface.rs:78-79)
+        detail::JsonFlat j(text);
+        BaseModelConfig c;
+        c.hidden_size = (size_t)j.num("hidden_size");
+        c.intermediate_size = (size_t)j.num("intermediate_size");
+        c.vocab_size = (size_t)j.num("vocab_size");
+        c.num_hidden_layers = (size_t)j.num("num_hidden_layers");
+        c.num_attention_heads = (size_t)j.num("num_attention_heads");
+        if (auto v = j.opt("num_key_value_heads")) c.num_key_value_heads = (size_t)*v;
+        c.rms_norm_eps = j.num("rms_norm_eps");
+        c.rope_theta = j.opt("rope_theta");
+        if (auto v = j.opt("max_position_embeddings")) c.max_position_embeddings = (size_t)*v;
+        if (auto v = j.opt("sliding_window")) c.sliding_window = (size_t)*v;
+        c.torch_dtype = j.str("torch_dtype");
+        return c;
+    }
+    // ModelConfigValidation (config.rs:31-54)
+    size_t validate_head_dimensions() const {
+        if (num_attention_heads == 0) throw Error(FL_ERR_BAD_CONFIG, "hidden_size must be divisible by num_attention_heads");
+        size_t head_dim = hidden_size / num_attention_heads;
+        if (head_dim * num_attention_heads != hidden_size) throw Error(FL_ERR_BAD_CONFIG, "hidden_size must be divisible by num_attention_heads");
+        if (head_dim % 2 != 0) throw Error(FL_ERR_BAD_CONFIG, "head_dim must be even for RoPE embeddings");
+        return head_dim;
+    }
+    void validate_gqa_config() const {
+        if (num_key_value_heads && (*num_key_value_heads == 0 || num_attention_heads % *num_key_value_heads != 0))
+            throw Error(FL_ERR_BAD_CONFIG, "num_attention_heads must be divisible by num_key_value_heads");
+    }
+    fl_config to_fl(fl_family family, bool qkv_bias) const {
+        fl_config c{};
+        c.family = family; c.qkv_bias = qkv_bias;
+        c.hidden_size = (int64_t)hidden_size; c.intermediate_size = (int64_t)intermediate_size;
+        c.vocab_size = (int64_t)vocab_size; c.num_hidden_layers = (int64_t)num_hidden_layers;
+        c.num_attention_heads = (int64_t)num_attention_heads;
+        c.num_key_value_heads = (int64_t)num_key_value_heads.value_or(0);
+        c.max_position_embeddings = (int64_t)max_position_embeddings.value_or(0);
+        c.sliding_window = (int64_t)sliding_window.value_or(0);
+        c.rms_norm_eps = rms_norm_eps; c.rope_theta = rope_theta.value_or(0.0);
+        return c;
+    }
+};
+
+// ------------------------------------------------------------------------------------ shared plumbing
+namespace detail {
+struct ModelHandle {                          // owns one fl_model reference; Clone = refcount bump (mod.rs:155)
+    fl_model *m = nullptr;
+    explicit ModelHandle(fl_model *mm) : m(mm) {}
+    ~ModelHandle() { if (m) fl_model_release(m); }
+    ModelHandle(const ModelHandle &) = delete;
+};
+struct CacheHandle {
+    fl_cache *c = nullptr;
+    ~CacheHandle() { if (c) fl_cache_destroy(c); }
+};
+
+inline size_t default_max_seq(const fl_model *m) {
+    fl_model_info info; check(fl_model_get_info(m, &info), "fl_model_get_info");
+    size_t cap = 4096;                                         // KV capacity of one request
+    if (const char *e = std::getenv("FASTLLM_MAX_SEQ")) cap = (size_t)std::strtoull(e, nullptr, 10);
+    return std::min<size_t>(cap, (size_t)info.cfg.max_position_embeddings);
+}
+
+inline std::shared_ptr<ModelHandle> create(const fl_config &cfg, const TensorMap &tensors, DType dtype, const Device &device) {
+    if (device.is_cpu())
+        throw Error(FL_ERR_NO_DEVICE, "the MI355X backend has no CPU path: pass Device::mi355x(..) (main.rs:81-97 picks the accelerator)");
+    std::vector<fl_tensor> arr;
+    arr.reserve(tensors.size());
+    for (auto &kv : tensors) {
+        fl_tensor t{};
+        t.name = kv.first.c_str(); t.dtype = (int32_t)kv.second.dtype; t.ndim = (int32_t)kv.second.shape.size();
+        if (t.ndim > 4) throw Error(FL_ERR_SHAPE_MISMATCH, "tensor " + kv.first + " has rank > 4");
+        for (int i = 0; i < t.ndim; i++) t.shape[i] = kv.second.shape[i];
+        t.data = kv.second.data; t.device = kv.second.device;
+        arr.push_back(t);
+    }
+    fl_parallel par{};
+    par.mode = device.ordinals.size() > 1 ? FL_TP_SINGLE_PROCESS : FL_TP_NONE;
+    par.tp_size = (int32_t)std::max<size_t>(1, device.ordinals.size());
+    par.device_ids = device.ordinals.data(); par.n_device_ids = (int32_t)device.ordinals.size();
+    fl_model *m = nullptr;
+    check(fl_model_create(&cfg, arr.data(), arr.size(), (int32_t)dtype, &par, &m), "Failed to initialize model");
+    return std::make_shared<ModelHandle>(m);
+}
+
+inline Tensor run_forward(fl_model *m, fl_cache *c, const Tensor &input, size_t pos) {
+    auto [b, t] = input.dims2();
+    if (b != 1) throw Error(FL_ERR_BAD_ARGUMENT, "batch size must be 1 (mod.rs:283-291)");
+    fl_model_info info; check(fl_model_get_info(m, &info), "fl_model_get_info");
+    auto buf = std::make_shared<std::vector<float>>((size_t)info.cfg.vocab_size);
+    check(fl_forward(m, c, static_cast<const uint32_t *>(input.data), (size_t)t, pos, buf->data()), "Model forward pass failed");
+    Tensor out; out.dtype = DType::F32; out.data = buf->data(); out.owner = buf;
+    return out;
+}
+}  // namespace detail
+
+enum class PosMode { Reference, Tokens };
+// Reference (default): bug-compatible with the reference -- Mistral/Qwen pass a per-call counter as the
+// RoPE offset (mistral.rs:226,234; qwen.rs:142-143).  Tokens: the offset is the token position.
+inline PosMode pos_mode() {
+    const char *e = std::getenv("FASTLLM_POS_MODE");
+    return (e && std::string(e) == "tokens") ? PosMode::Tokens : PosMode::Reference;
+}
+
+// ------------------------------------------------------------------------------------ llama.rs
+struct LlamaCache : ModelCache {              // llama.rs:62-92: wraps candle's Cache{cos,sin,kvs} + an unused counter
+    std::shared_ptr<detail::CacheHandle> inner;
+    size_t seqlen_offset = 0;
+    void increment_offset() override { seqlen_offset += 1; }
+    void reset() override { seqlen_offset = 0; }
+    size_t get_offset() const override { return seqlen_offset; }
+};
+
+struct LlamaWithConfig {
+    using Config = BaseModelConfig;           // llama::ConfigFile (llama.rs:18-29): same fields minus sliding_window
+    using Cache = LlamaCache;
+    std::shared_ptr<detail::ModelHandle> model;
+
+    static std::shared_ptr<detail::ModelHandle> &last() { static std::shared_ptr<detail::ModelHandle> p; return p; }
+
+    // llama.rs:98-123.  From<ConfigFile> (llama.rs:31-50): kv heads default to heads, theta 1e4, max pos 4096.
+    static std::pair<LlamaWithConfig, LlamaCache> initialize_model(const Config &config, const TensorMap &tensors, DType dtype, const Device &device) {
+        LlamaWithConfig self;
+        self.model = detail::create(config.to_fl(FL_FAMILY_LLAMA, false), tensors, dtype, device);
+        last() = self.model;
+        return {self, new_cache(self.model)};
+    }
+    // llama.rs:125-145 builds the cache from hard-coded TinyLlama dims because the associated fn cannot see
+    // the model (quirk C.2).  Here it is derived from the most recently initialised model of this process
+    // (the reference serves one model per process, main.rs:128).
+    static LlamaCache initialize_cache(const Device &, DType) {
+        if (!last()) throw Error(FL_ERR_BAD_ARGUMENT, "Failed to initialize model cache: no model initialised");
+        return new_cache(last());
+    }
+    // llama.rs:147-149: self.model.forward(input, pos, &mut cache.inner) -- the caller's token position is used
+    Tensor forward(const Tensor &input, size_t pos, Cache &cache) const {
+        Tensor logits = detail::run_forward(model->m, cache.inner->c, input, pos);
+        logits.shape = {1, logits.owner ? (int64_t)static_cast<std::vector<float> *>(logits.owner.get())->size() : 0};   // [1, V] f32
+        return logits;
+    }
+    static const char *get_family() { return "Llama"; }                                             // llama.rs:153
+    static bool supports_architecture(const std::string &a) { return a == "LlamaForCausalLM"; }     // llama.rs:157-159
+
+   private:
+    static LlamaCache new_cache(const std::shared_ptr<detail::ModelHandle> &m) {
+        LlamaCache c; c.inner = std::make_shared<detail::CacheHandle>();
+        check(fl_cache_create(m->m, detail::default_max_seq(m->m), &c.inner->c), "Failed to initialize model cache");
+        return c;
+    }
+};
+
+// ------------------------------------------------------------------------------------ mistral.rs / qwen.rs
+// The reference keeps KV inside the candle model (RefCell) and the adapter cache is only a counter
+// (mistral.rs:16-47, qwen.rs:59-87).  Here KV is a caller-owned fl_cache attached to the counter object,
+// so concurrent streams on one model are sound (quirk C.7).
+struct CounterCache : ModelCache {
+    size_t seqlen_offset = 0;
+    std::shared_ptr<detail::CacheHandle> kv;  // created lazily by forward (initialize_cache cannot see the model)
+    void increment_offset() override { seqlen_offset += 1; }
+    void reset() override { seqlen_offset = 0; }
+    size_t get_offset() const override { return seqlen_offset; }
+};
+using MistralCache = CounterCache;
+using QwenCache = CounterCache;
+
+template <fl_family FAMILY, bool BIAS>
+struct CounterFamily {
+    using Config = BaseModelConfig;
+    using Cache = CounterCache;
+    std::shared_ptr<detail::ModelHandle> model;
+
+    static size_t get_head_dim(size_t hidden_size, size_t num_attention_heads) {                    // mistral.rs:67-76
+        if (num_attention_heads == 0 || (hidden_size / num_attention_heads) * num_attention_heads != hidden_size)
+            throw Panic("hidden_size must be divisible by num_attention_heads");
+        return hidden_size / num_attention_heads;
+    }
+    static void validate(const Config &cf) {                                                        // mistral.rs:93-127, qwen.rs:30-37
+        size_t head_dim = get_head_dim(cf.hidden_size, cf.num_attention_heads);
+        size_t kv = cf.num_key_value_heads.value_or(cf.num_attention_heads);
+        if (kv == 0 || cf.num_attention_heads % kv != 0) throw Panic("num_attention_heads must be divisible by num_key_value_heads");
+        if (head_dim % 2 != 0) throw Panic("head_dim must be even for RoPE embeddings");
+    }
+    static std::pair<CounterFamily, Cache> initialize_model(const Config &config, const TensorMap &tensors, DType dtype, const Device &device) {
+        validate(config);
+        CounterFamily self;
+        self.model = detail::create(config.to_fl(FAMILY, BIAS), tensors, dtype, device);
+        return {self, Cache{}};
+    }
+    static Cache initialize_cache(const Device &, DType) { return Cache{}; }                        // mistral.rs:202-204, qwen.rs:119-121
+    // mistral.rs:206-236 / qwen.rs:123-151: `_pos` is ignored; offset 0 clears the KV cache; the model is run
+    // at the per-call counter; the counter then advances by ONE per call (quirk C.1).
+    Tensor forward(const Tensor &input, size_t pos, Cache &cache) const {
+        if (!cache.kv) {
+            cache.kv = std::make_shared<detail::CacheHandle>();
+            check(fl_cache_create(model->m, detail::default_max_seq(model->m), &cache.kv->c), "Failed to initialize model cache");
+        }
+        if (cache.seqlen_offset == 0) fl_cache_reset(cache.kv->c);                                  // clear_kv_cache()
+        const size_t rope_offset = pos_mode() == PosMode::Reference ? cache.seqlen_offset : pos;
+        Tensor logits = detail::run_forward(model->m, cache.kv->c, input, rope_offset);
+        logits.shape = {1, 1, (int64_t)static_cast<std::vector<float> *>(logits.owner.get())->size()};   // [1,1,V]
+        cache.increment_offset();
+        return logits;
+    }
+};
+
+struct MistralWithConfig : CounterFamily<FL_FAMILY_MISTRAL, false> {
+    MistralWithConfig() = default;
+    MistralWithConfig(const CounterFamily &b) : CounterFamily(b) {}
+    static std::pair<MistralWithConfig, MistralCache> initialize_model(const Config &c, const TensorMap &t, DType d, const Device &dev) {
+        auto r = CounterFamily::initialize_model(c, t, d, dev); return {MistralWithConfig(r.first), r.second};
+    }
+    static const char *get_family() { return "Mistral"; }                                           // mistral.rs:240
+    static bool supports_architecture(const std::string &a) { return a == "MistralForCausalLM"; }   // mistral.rs:244-246
+};
+
+struct QwenWithConfig : CounterFamily<FL_FAMILY_QWEN2, true> {
+    QwenWithConfig() = default;
+    QwenWithConfig(const CounterFamily &b) : CounterFamily(b) {}
+    // qwen.rs:30-37: validate_head_dimensions().expect(..) / validate_gqa_config().expect(..) -> panic
+    static std::pair<QwenWithConfig, QwenCache> initialize_model(const Config &c, const TensorMap &t, DType d, const Device &dev) {
+        try { c.validate_head_dimensions(); } catch (const Error &e) { throw Panic(std::string("Invalid head dimensions: ") + e.what()); }
+        try { c.validate_gqa_config(); } catch (const Error &e) { throw Panic(std::string("Invalid GQA configuration: ") + e.what()); }
+        auto r = CounterFamily::initialize_model(c, t, d, dev); return {QwenWithConfig(r.first), r.second};
+    }
+    static const char *get_family() { return "Qwen"; }                                              // qwen.rs:174
+    static bool supports_architecture(const std::string &a) {                                       // qwen.rs:178-183
+        return a == "Qwen2ForCausalLM" || a == "Qwen2_5_VLForConditionalGeneration";
+    }
+};
+
+// ------------------------------------------------------------------------------------ mod.rs: Model<M>
+inline uint32_t argmax_last(const float *v, size_t n) {      // LogitsProcessor ArgMax: max_by(total_cmp) -> last max
+    size_t best = 0;
+    for (size_t i = 1; i < n; i++) if (!(v[i] < v[best])) best = i;
+    return (uint32_t)best;
+}
+
+template <class M>
+struct Model {                                // mod.rs:342-361
+    M model;
+    Device device;
+    typename M::Cache cache;
+    DType dtype = DType::BF16;                // mod.rs:359
+    size_t forwards = 0;                      // forwards executed by the last generate (incl. the wasted one, C.5)
+
+    Model(M m, Device d, typename M::Cache c) : model(std::move(m)), device(std::move(d)), cache(std::move(c)) {}
+
+    // Model::generate (mod.rs:363-463) on token ids.  eos = tokenizer.token_to_id("</s>") (mod.rs:431).
+    std::vector<uint32_t> generate_ids(const std::vector<uint32_t> &prompt, size_t max_tokens, float temperature,
+                                       std::optional<uint32_t> eos = std::nullopt) {
+        cache = M::initialize_cache(device, dtype);                       // mod.rs:370
+        if (!(temperature < 1e-7f))                                        // LogitsProcessor::new(seed, Some(t), None)
+            throw Error(FL_ERR_UNSUPPORTED, "sampling with temperature >= 1e-7 is outside the accelerated path (greedy only)");
+        if (prompt.empty()) throw Error(FL_ERR_BAD_ARGUMENT, "Tokenization error: empty prompt");
+        Tensor input = Tensor::from_ids(prompt);                           // mod.rs:386-394
+        std::vector<uint32_t> output_ids;
+        size_t pos = 0;
+        forwards = 0;
+        Tensor logits = model.forward(input, pos, cache); forwards++;      // mod.rs:402-405
+        pos += prompt.size();                                              // mod.rs:408
+        for (size_t i = 0; i < max_tokens; i++) {                          // mod.rs:411
+            const uint32_t next = argmax_last(logits.f32(), (size_t)logits.elem_count());   // mod.rs:421-428
+            if (eos && next == *eos) break;                                // mod.rs:431-436
+            output_ids.push_back(next);                                    // mod.rs:438
+            Tensor next_input = Tensor::from_ids({next});                  // mod.rs:441-444
+            logits = model.forward(next_input, pos, cache); forwards++;    // mod.rs:446-451 (also after the last token)
+            pos += 1;                                                      // mod.rs:452
+        }
+        return output_ids;
+    }
+};
+
+}  // namespace fastllm

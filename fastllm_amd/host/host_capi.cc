@@ -1,0 +1,136 @@
+// host_capi.cc -- a small C surface over fastllm_host.hpp so that pytest (ctypes) can drive the C++
+// mirror of the reference's trait layer.  Built into fastllm_amd/lib/libfastllm_host.so.
+#include <cstdio>
+#include <string>
+
+#include "fastllm_host.hpp"
+
+using namespace fastllm;
+
+namespace {
+thread_local std::string g_err;
+
+struct Handle {
+    int family;                               // 0 llama, 1 mistral, 2 qwen
+    std::unique_ptr<Model<LlamaWithConfig>> llama;
+    std::unique_ptr<Model<MistralWithConfig>> mistral;
+    std::unique_ptr<Model<QwenWithConfig>> qwen;
+};
+
+template <class F> int guard(F &&f) {
+    try { return f(); }
+    catch (const Error &e) { g_err = e.what(); return e.code ? e.code : -100; }
+    catch (const Panic &e) { g_err = std::string("panic: ") + e.what(); return -101; }
+    catch (const std::exception &e) { g_err = e.what(); return -102; }
+}
+
+TensorMap to_map(const fl_tensor *ts, size_t n) {
+    TensorMap m;
+    for (size_t i = 0; i < n; i++) {
+        Tensor t; t.dtype = (DType)ts[i].dtype; t.data = ts[i].data; t.device = ts[i].device;
+        for (int d = 0; d < ts[i].ndim; d++) t.shape.push_back(ts[i].shape[d]);
+        m[ts[i].name] = t;
+    }
+    return m;
+}
+}  // namespace
+
+extern "C" {
+
+const char *flh_last_error(void) { return g_err.c_str(); }
+
+const char *flh_get_family(int family) {
+    switch (family) { case 0: return LlamaWithConfig::get_family(); case 1: return MistralWithConfig::get_family(); case 2: return QwenWithConfig::get_family(); }
+    return "";
+}
+
+int flh_supports_architecture(int family, const char *arch) {
+    switch (family) {
+        case 0: return LlamaWithConfig::supports_architecture(arch);
+        case 1: return MistralWithConfig::supports_architecture(arch);
+        case 2: return QwenWithConfig::supports_architecture(arch);
+    }
+    return 0;
+}
+
+// parse config.json and run the family's validation; out (optional) receives the resolved fl_config
+int flh_config_check(int family, const char *json, fl_config *out) {
+    return guard([&] {
+        BaseModelConfig c = BaseModelConfig::from_json(json);
+        if (family == 1) MistralWithConfig::validate(c);
+        if (family == 2) {
+            try { c.validate_head_dimensions(); c.validate_gqa_config(); }
+            catch (const Error &e) { throw Panic(e.what()); }
+        }
+        if (out) *out = c.to_fl((fl_family)family, family == 2);
+        return 0;
+    });
+}
+
+int flh_model_create(int family, const char *config_json, const fl_tensor *tensors, size_t n, int dtype,
+                     int device_ordinal, void **out) {
+    return guard([&] {
+        BaseModelConfig cfg = BaseModelConfig::from_json(config_json);
+        TensorMap map = to_map(tensors, n);
+        Device dev = device_ordinal < 0 ? Device::cpu() : Device::mi355x(device_ordinal);
+        auto h = std::make_unique<Handle>();
+        h->family = family;
+        if (family == 0) { auto r = LlamaWithConfig::initialize_model(cfg, map, (DType)dtype, dev); h->llama = std::make_unique<Model<LlamaWithConfig>>(r.first, dev, r.second); }
+        else if (family == 1) { auto r = MistralWithConfig::initialize_model(cfg, map, (DType)dtype, dev); h->mistral = std::make_unique<Model<MistralWithConfig>>(r.first, dev, r.second); }
+        else if (family == 2) { auto r = QwenWithConfig::initialize_model(cfg, map, (DType)dtype, dev); h->qwen = std::make_unique<Model<QwenWithConfig>>(r.first, dev, r.second); }
+        else throw Error(FL_ERR_BAD_ARGUMENT, "unknown family");
+        *out = h.release();
+        return 0;
+    });
+}
+
+void flh_model_destroy(void *h) { delete static_cast<Handle *>(h); }
+
+// Model<M>::generate on token ids (mod.rs:363-463)
+int flh_generate(void *hv, const uint32_t *prompt, size_t T, size_t max_tokens, float temperature, int64_t eos,
+                 uint32_t *out_tokens, size_t *n_out, size_t *forwards) {
+    return guard([&] {
+        Handle *h = static_cast<Handle *>(hv);
+        std::vector<uint32_t> p(prompt, prompt + T), r;
+        std::optional<uint32_t> e = eos >= 0 ? std::optional<uint32_t>((uint32_t)eos) : std::nullopt;
+        size_t fw = 0;
+        if (h->llama) { r = h->llama->generate_ids(p, max_tokens, temperature, e); fw = h->llama->forwards; }
+        else if (h->mistral) { r = h->mistral->generate_ids(p, max_tokens, temperature, e); fw = h->mistral->forwards; }
+        else { r = h->qwen->generate_ids(p, max_tokens, temperature, e); fw = h->qwen->forwards; }
+        for (size_t i = 0; i < r.size(); i++) out_tokens[i] = r[i];
+        *n_out = r.size();
+        if (forwards) *forwards = fw;
+        return 0;
+    });
+}
+
+// ModelInitializer::forward through the model's own cache object (trait-level call)
+int flh_forward(void *hv, const uint32_t *ids, size_t T, size_t pos, float *logits_out, size_t *n_logits) {
+    return guard([&] {
+        Handle *h = static_cast<Handle *>(hv);
+        Tensor in = Tensor::from_ids(std::vector<uint32_t>(ids, ids + T)), lg;
+        if (h->llama) lg = h->llama->model.forward(in, pos, h->llama->cache);
+        else if (h->mistral) lg = h->mistral->model.forward(in, pos, h->mistral->cache);
+        else lg = h->qwen->model.forward(in, pos, h->qwen->cache);
+        const size_t n = (size_t)lg.elem_count();
+        std::memcpy(logits_out, lg.f32(), n * sizeof(float));
+        if (n_logits) *n_logits = n;
+        return 0;
+    });
+}
+
+size_t flh_cache_offset(void *hv) {
+    Handle *h = static_cast<Handle *>(hv);
+    if (h->llama) return h->llama->cache.get_offset();
+    if (h->mistral) return h->mistral->cache.get_offset();
+    return h->qwen->cache.get_offset();
+}
+
+void flh_cache_reset(void *hv) {           // ModelCache::reset (+ a fresh cache object for Llama)
+    Handle *h = static_cast<Handle *>(hv);
+    if (h->llama) h->llama->cache = LlamaWithConfig::initialize_cache(h->llama->device, h->llama->dtype);
+    else if (h->mistral) h->mistral->cache.reset();
+    else h->qwen->cache.reset();
+}
+
+}  // extern "C"

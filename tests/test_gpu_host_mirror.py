@@ -1,0 +1,113 @@
+"""GPU tests of the C++ host mirror: Model<M>::generate semantics through the trait-shaped layer."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import synth
+from oracle import oracle
+from test_host_mirror import config_json, host  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+FAM = {"llama": 0, "mistral": 1, "qwen2": 2}
+
+
+def make(host, name, dtype=0):
+    from fastllm_amd import binding
+    cfg = synth.CONFIGS[name]
+    w = synth.synth_weights(cfg)
+    arr = (binding.FlTensor * len(w))()
+    keep = []
+    for i, (k, a) in enumerate(w.items()):
+        a = np.ascontiguousarray(a)
+        keep.append(a)
+        arr[i].name, arr[i].dtype, arr[i].ndim, arr[i].data, arr[i].device = k.encode(), 1, a.ndim, a.ctypes.data, -1
+        for j, s in enumerate(a.shape):
+            arr[i].shape[j] = s
+    h = C.c_void_p()
+    rc = host.flh_model_create(FAM[cfg["family"]], config_json(cfg), arr, len(w), dtype, 0, C.byref(h))
+    assert rc == 0, host.flh_last_error()
+    return h, cfg, w
+
+
+def generate(host, h, prompt, n, eos=-1):
+    prompt = np.ascontiguousarray(prompt, dtype=np.uint32)
+    out = np.zeros(n, dtype=np.uint32)
+    n_out, fw = C.c_size_t(0), C.c_size_t(0)
+    rc = host.flh_generate(h, prompt.ctypes.data, prompt.size, n, 0.0, eos, out.ctypes.data, C.byref(n_out), C.byref(fw))
+    assert rc == 0, host.flh_last_error()
+    return out[: n_out.value], fw.value
+
+
+@pytest.mark.parametrize("name", ["llama_a", "mistral_a", "qwen2_a"])
+@pytest.mark.parametrize("mode", ["reference", "tokens"])
+def test_generate_matches_oracle_generate(host, name, mode, monkeypatch):
+    """Model<M>::generate (mod.rs:363-463) in fp32: identical token ids; Mistral/Qwen in `reference` mode
+    reproduce the call-counter RoPE offset (quirk C.1)."""
+    monkeypatch.setenv("FASTLLM_POS_MODE", mode)
+    monkeypatch.setenv("FASTLLM_MAX_SEQ", "64")
+    h, cfg, w = make(host, name, dtype=0)
+    om = oracle.OracleModel(cfg, synth.as_f32(w))
+    prompt = synth.prompt_ids(cfg, 8)
+    want = om.generate(om.new_cache(64), prompt, 12, pos_mode=mode)
+    got, forwards = generate(host, h, prompt, 12)
+    np.testing.assert_array_equal(got, want)
+    assert forwards == 1 + 12                      # prefill + one forward per token, incl. the wasted last one (C.5)
+    # a second request starts from a fresh cache (mod.rs:370)
+    got2, _ = generate(host, h, prompt, 12)
+    np.testing.assert_array_equal(got2, want)
+    host.flh_model_destroy(h)
+
+
+def test_eos_stops_before_emitting(host, monkeypatch):
+    monkeypatch.setenv("FASTLLM_MAX_SEQ", "64")
+    h, cfg, w = make(host, "llama_a", dtype=0)
+    prompt = synth.prompt_ids(cfg, 8)
+    full, _ = generate(host, h, prompt, 10)
+    eos = int(full[4])
+    first_hit = int(np.argmax(full == eos))
+    got, forwards = generate(host, h, prompt, 10, eos=eos)
+    np.testing.assert_array_equal(got, full[:first_hit])        # mod.rs:431-436: break before push
+    assert forwards == 1 + first_hit
+    host.flh_model_destroy(h)
+
+
+def test_trait_forward_counter_semantics(host, monkeypatch):
+    """MistralWithConfig::forward ignores pos, uses and advances the per-call counter (mistral.rs:206-236)."""
+    monkeypatch.setenv("FASTLLM_POS_MODE", "reference")
+    monkeypatch.setenv("FASTLLM_MAX_SEQ", "64")
+    h, cfg, w = make(host, "mistral_a", dtype=0)
+    om = oracle.OracleModel(cfg, synth.as_f32(w))
+    oc = om.new_cache(64)
+    ids = synth.prompt_ids(cfg, 7)
+    lg = np.zeros(cfg["vocab_size"], np.float32)
+    n = C.c_size_t(0)
+    assert host.flh_cache_offset(h) == 0
+    assert host.flh_forward(h, ids[:6].ctypes.data, 6, 12345, lg.ctypes.data, C.byref(n)) == 0    # pos is ignored
+    assert n.value == cfg["vocab_size"] and host.flh_cache_offset(h) == 1                        # +1 per call, not +T
+    np.testing.assert_allclose(lg, om.forward(oc, ids[:6], 0), atol=1e-3, rtol=0)
+    assert host.flh_forward(h, ids[6:7].ctypes.data, 1, 999, lg.ctypes.data, C.byref(n)) == 0
+    np.testing.assert_allclose(lg, om.forward(oc, ids[6:7], 1), atol=1e-3, rtol=0)               # rotated as position 1
+    assert host.flh_cache_offset(h) == 2
+    host.flh_cache_reset(h)
+    assert host.flh_cache_offset(h) == 0
+    host.flh_model_destroy(h)
+
+
+def test_rccl_plumbing_single_rank(monkeypatch):
+    """A 1-rank RCCL communicator at the real all-reduce call sites (identity) must not change results."""
+    import fastllm_amd as fa
+    cfg = synth.CONFIGS["llama_a"]
+    w = synth.synth_weights(cfg)
+    ids = synth.prompt_ids(cfg, 10)
+    plain = fa.Model(cfg, w, dtype="f32")
+    c = plain.new_cache(32)
+    a1 = plain.forward(c, ids[:9], 0)
+    a2 = plain.forward(c, ids[9:], 9)
+    monkeypatch.setenv("FL_DEBUG_RCCL_SELF", "1")
+    m = fa.Model(cfg, w, dtype="f32")
+    c = m.new_cache(32)
+    np.testing.assert_array_equal(m.forward(c, ids[:9], 0), a1)
+    np.testing.assert_array_equal(m.forward(c, ids[9:], 9), a2)
+    toks = m.decode_greedy(c, 3, 10, 5)
+    assert len(toks) == 5
