@@ -151,11 +151,11 @@ int fl_profile_end(fl_model *m, fl_kernel_stat *stats, size_t cap, size_t *n_sta
 }
 
 int fl_tune(const char *key, int value) {
-    if (!key || value <= 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "bad tuning key/value");
-    if (!strcmp(key, "gemv_r")) gemv_set_tuning(value, 0, 0, 0);
-    else if (!strcmp(key, "gemv_u")) gemv_set_tuning(0, value, 0, 0);
-    else if (!strcmp(key, "gemv_maxblocks")) gemv_set_tuning(0, 0, value, 0);
-    else if (!strcmp(key, "gemv_maxblocks_norm")) gemv_set_tuning(0, 0, 0, value);
+    if (!key || value < 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "bad tuning key/value");
+    if (!strcmp(key, "gemv_r")) gemv_set_tuning(value, 0, -1, -1);
+    else if (!strcmp(key, "gemv_u")) gemv_set_tuning(0, value, -1, -1);
+    else if (!strcmp(key, "gemv_blocks")) gemv_set_tuning(0, 0, value, -1);        // 0 = automatic
+    else if (!strcmp(key, "gemv_waves")) gemv_set_tuning(0, 0, -1, value);          // 0 = automatic
     else FL_FAIL(FL_ERR_BAD_ARGUMENT, "unknown tuning key %s", key);
     return FL_OK;
 }

@@ -3,18 +3,23 @@
 // bytes are linear-layer weights read exactly once.
 //
 // Streaming (HBM-bound, cdna guide "GEMV / M <= 16" row): each wave owns R rows at a time and
-// reads them 16 B per lane (1 KiB per wave instruction), non-temporal, straight to VGPRs, U
-// chunks of all R rows in flight before the first FMA; fp32 accumulate; 64-lane shuffle reduce.
-// x (the activation vector) is staged once per workgroup in LDS and re-read with ds_read_b128.
+// reads them 16 B per lane (1 KiB per wave instruction), non-temporal, straight to VGPRs -- no
+// LDS round trip for read-once bytes.  The wave's whole work list (its row groups x K blocks) is
+// flattened and software-pipelined through a register double buffer: two blocks of U chunks x R
+// rows (2*U*R KiB per wave) are always in flight, also across row-group boundaries, and the first
+// two blocks are requested BEFORE x is staged so HBM is busy during the prologue.  fp32
+// accumulate; 64-lane shuffle reduce.  x is staged once per workgroup in LDS (ds_read_b128).
+//
+// Geometry: one workgroup per CU (or two), 4..12 waves each, chosen so that every wave gets the
+// same number of row groups (a ragged last round costs 1/rounds of the kernel) and everything is
+// resident at once.
 //
 // Prologue PRO_NORM (fused K2/K9, and K1 for layer 0): RMSNorm is folded around the dot product,
 //     W . (v / m * w)  =  (1/m) * W . (v * w),     v = x_in + delta (or the token's embedding row),
 // so the workgroup stages x' = v * w in LDS with no dependence on m = sqrt(mean(v^2) + eps): the
 // sum of squares rides along in the same pass and is combined behind the SAME barrier as the
-// staging; 1/m is applied to the accumulator in the epilogue.  No separate norm kernel, no xn
-// round trip, no extra barrier.  Workgroup 0 also writes the updated residual v to x_out (a
-// different buffer than x_in: other workgroups still read x_in).  The first weight loads are
-// issued before the staging so HBM is busy from the first cycle.
+// staging; 1/m is applied to the accumulator in the epilogue.  Workgroup 0 also writes the updated
+// residual v to x_out (a different buffer than x_in: other workgroups still read x_in).
 //
 // Epilogues: EPI_F32 (+bias) -> fp32;  EPI_GATEUP: silu(gate)*up on the 16-interleaved layout;
 // EPI_QKV_ROPE (fused K4/K5): rows are paired (j, j+d/2) per head, RoPE is applied with the
@@ -28,52 +33,70 @@
 
 namespace fl {
 
-__device__ inline void load_raw_nt(const bf16_t *p, uint4v (&r)[1]) {
-    r[0] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(p));
+constexpr int kGemvMaxThreads = 768;     // 12 waves: 170 VGPRs per lane available
+
+template <typename WT> struct RawChunk { uint4v v[sizeof(WT) == 2 ? 1 : 2]; };
+
+__device__ inline void load_raw_nt(const bf16_t *p, RawChunk<bf16_t> &r) {
+    r.v[0] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(p));
 }
-__device__ inline void load_raw_nt(const float *p, uint4v (&r)[2]) {
-    r[0] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(p));
-    r[1] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(p + 4));
+__device__ inline void load_raw_nt(const float *p, RawChunk<float> &r) {
+    r.v[0] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(p));
+    r.v[1] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(p + 4));
 }
-template <typename WT> __device__ inline void unpack_raw(const uint4v (&r)[sizeof(WT) == 2 ? 1 : 2], float (&o)[8]) {
-    if constexpr (sizeof(WT) == 2) {
-        unpack8(r[0], o);
-    } else {
+__device__ inline void unpack_raw(const RawChunk<bf16_t> &r, float (&o)[8]) { unpack8(r.v[0], o); }
+__device__ inline void unpack_raw(const RawChunk<float> &r, float (&o)[8]) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) { o[i] = __uint_as_float(r[0][i]); o[4 + i] = __uint_as_float(r[1][i]); }
-    }
+    for (int i = 0; i < 4; i++) { o[i] = __uint_as_float(r.v[0][i]); o[4 + i] = __uint_as_float(r.v[1][i]); }
 }
 
 template <typename WT, typename XT, int R, int U, int PRO>
-__global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
+__global__ __launch_bounds__(kGemvMaxThreads) void gemv_kernel(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __shared__ float red[4];
+    __shared__ float red[kGemvMaxThreads / 64];
     XT *xs = reinterpret_cast<XT *>(lds_raw);
     const WT *__restrict__ W = reinterpret_cast<const WT *>(a.W);
     const int N = a.N, K = a.K, epi = a.epi;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthr = blockDim.x, nwv = nthr >> 6;
     const int nchunk = K >> 3;                       // 8-element chunks; K % 8 == 0
     const int half = a.d >> 1;
     const int ngroups = (N + R - 1) / R;
-    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const int gw = blockIdx.x * nwv + wave, nw = gridDim.x * nwv;
+    const int nblk = (nchunk + 64 * U - 1) / (64 * U);                    // K blocks per row group
+    const int my_groups = gw < ngroups ? (ngroups - gw + nw - 1) / nw : 0;
+    const int total = my_groups * nblk;                                   // this wave's flattened work list
 
     auto row_of = [&](int g, int r) -> int {
         if (epi == EPI_GATEUP) { int q = g * (R / 2) + (r >> 1); return (q >> 4) * 32 + (q & 15) + ((r & 1) << 4); }
         if (epi == EPI_QKV_ROPE) { int q = g * (R / 2) + (r >> 1); int hd = q / half, j = q - hd * half; return hd * a.d + j + (r & 1) * half; }
         return g * R + r;
     };
+    typedef RawChunk<WT> Buf[R][U];
+    auto issue = [&](int idx, Buf &buf) {
+        const int gi = idx / nblk, cb = idx - gi * nblk, g = gw + gi * nw;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int row = row_of(g, r);
+            const WT *wp = W + (size_t)(row < N ? row : N - 1) * K;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int c = (cb * U + u) * 64 + lane;
+                if (c < nchunk) load_raw_nt(wp + (size_t)c * 8, buf[r][u]);
+            }
+        }
+    };
 
-    uint4v pre[R][U][sizeof(WT) == 2 ? 1 : 2];      // raw 16-B loads; unpacked at the FMA
-    bool have_pre = false;
+    Buf bufA, bufB;
     float inv_m = 1.0f;
     if constexpr (PRO == PRO_NORM) {
-        constexpr int NCH = 3;                       // K <= 6144 (host-checked)
+        constexpr int NCH = 3;                       // nthr * NCH * 8 >= K (host-checked)
         float v[NCH][8], wn[NCH][8];
         const WT *erow = nullptr;
         if (a.embed) erow = reinterpret_cast<const WT *>(a.embed) + (size_t)a.st->token * K;
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
-            const int c = tid + 256 * i;
+            const int c = tid + nthr * i;
             if (c < nchunk) {
                 if (erow) load8(erow + c * 8, v[i]); else load8(a.x_in + c * 8, v[i]);
                 load8(a.norm_w + c * 8, wn[i]);
@@ -85,21 +108,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
                 }
             }
         }
-        // first weight block of this wave: in flight while x' is staged
-        if (gw < ngroups && lane + 64 * (U - 1) < nchunk) {
-            have_pre = true;
-#pragma unroll
-            for (int u = 0; u < U; u++)
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    int row = row_of(gw, r);
-                    load_raw_nt(W + (size_t)(row < N ? row : N - 1) * K + (size_t)(lane + 64 * u) * 8, pre[r][u]);
-                }
-        }
+        // the weight stream starts now: issued after the (short) activation loads so that the counted
+        // wait for those does not have to drain the long weight loads
+        if (total > 0) issue(0, bufA);
+        if (total > 1) issue(1, bufB);
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
-            const int c = tid + 256 * i;
+            const int c = tid + nthr * i;
             if (c < nchunk) {
                 float o[8];
 #pragma unroll
@@ -111,12 +127,34 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
         ss = wave_sum(ss);
         if (lane == 0) red[wave] = ss;
         __syncthreads();
-        ss = red[0] + red[1] + red[2] + red[3];
+        ss = 0.f;
+        for (int w = 0; w < nwv; w++) ss += red[w];
         inv_m = 1.0f / sqrtf(ss / (float)K + a.eps);           // candle rms_norm (App. A.2)
     } else {
         const XT *__restrict__ x = reinterpret_cast<const XT *>(a.x);
+        constexpr int NXR = 4;
+        uint4v xr[NXR][sizeof(XT) == 2 ? 1 : 2];
+        // stage x through registers: up to NXR chunks per thread are requested before the weights
+#pragma unroll
+        for (int i = 0; i < NXR; i++) {
+            const int c = tid + nthr * i;
+            if (c < nchunk) {
+                xr[i][0] = *reinterpret_cast<const uint4v *>(x + c * 8);
+                if constexpr (sizeof(XT) == 4) xr[i][1] = *reinterpret_cast<const uint4v *>(x + c * 8 + 4);
+            }
+        }
         if (a.x_scale) inv_m = *a.x_scale;
-        for (int c = tid; c < nchunk; c += 256) {
+        if (total > 0) issue(0, bufA);
+        if (total > 1) issue(1, bufB);
+#pragma unroll
+        for (int i = 0; i < NXR; i++) {
+            const int c = tid + nthr * i;
+            if (c < nchunk) {
+                *reinterpret_cast<uint4v *>(xs + c * 8) = xr[i][0];
+                if constexpr (sizeof(XT) == 4) *reinterpret_cast<uint4v *>(xs + c * 8 + 4) = xr[i][1];
+            }
+        }
+        for (int c = tid + NXR * nthr; c < nchunk; c += nthr) {        // very long K: the rest
             if constexpr (sizeof(XT) == 2) {
                 *reinterpret_cast<uint4v *>(xs + c * 8) = *reinterpret_cast<const uint4v *>(x + c * 8);
             } else {
@@ -127,117 +165,95 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
         __syncthreads();
     }
 
-    for (int g = gw; g < ngroups; g += nw) {
-        int rows[R];
-        const WT *wp[R];
+    float acc[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            rows[r] = row_of(g, r);
-            wp[r] = W + (size_t)(rows[r] < N ? rows[r] : N - 1) * K;
-        }
-        float acc[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = 0.f;
+    for (int r = 0; r < R; r++) acc[r] = 0.f;
 
-        int c0 = lane;
-        if (PRO == PRO_NORM && have_pre && g == gw) {            // consume the prefetched block
+    auto finish_group = [&](int g) {
+        float sum[R];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                float xv[8];
-                load8(xs + (c0 + 64 * u) * 8, xv);
+        for (int r = 0; r < R; r++) { sum[r] = wave_sum(acc[r]) * inv_m; acc[r] = 0.f; }
+        if (lane != 0) return;
+        if (epi == EPI_GATEUP) {
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    float wv[8];
-                    unpack_raw<WT>(pre[r][u], wv);
-#pragma unroll
-                    for (int j = 0; j < 8; j++) acc[r] = fmaf(wv[j], xv[j], acc[r]);
+            for (int r = 0; r < R; r += 2) {
+                const int q = g * (R / 2) + (r >> 1);
+                if (row_of(g, r + 1) < N) {
+                    const float gt = sum[r], up = sum[r + 1];
+                    const float act = gt / (1.0f + expf(-gt)) * up;          // candle silu(g) * u
+                    elem<XT>::st(reinterpret_cast<XT *>(a.out) + q, act);
                 }
             }
-            c0 += 64 * U;
-        }
-        for (; c0 + 64 * (U - 1) < nchunk; c0 += 64 * U) {      // full blocks of U chunks: no predicates
-            uint4v w[R][U][sizeof(WT) == 2 ? 1 : 2];
+        } else if (epi == EPI_QKV_ROPE) {
+            const uint32_t pos = a.st->pos, slot = a.st->len;
+            const uint32_t p = pos < (uint32_t)a.max_pos ? pos : (uint32_t)a.max_pos - 1;
 #pragma unroll
-            for (int u = 0; u < U; u++)
-#pragma unroll
-                for (int r = 0; r < R; r++) load_raw_nt(wp[r] + (size_t)(c0 + 64 * u) * 8, w[r][u]);
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                float xv[8];
-                load8(xs + (c0 + 64 * u) * 8, xv);
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    float wv[8];
-                    unpack_raw<WT>(w[r][u], wv);
-#pragma unroll
-                    for (int j = 0; j < 8; j++) acc[r] = fmaf(wv[j], xv[j], acc[r]);
+            for (int r = 0; r < R; r += 2) {
+                const int r0w = row_of(g, r), r1w = row_of(g, r + 1);
+                if (r1w >= N) continue;
+                const int q = g * (R / 2) + (r >> 1);
+                const int hd = q / half, j = q - hd * half;
+                float x0 = sum[r], x1 = sum[r + 1];
+                if (a.bias) { x0 += a.bias[r0w]; x1 += a.bias[r1w]; }
+                XT *dst;
+                if (hd < a.H + a.Hkv) {                                   // rotate-half RoPE (App. A.4)
+                    const float c = a.cos_tab[(size_t)p * half + j], s = a.sin_tab[(size_t)p * half + j];
+                    const float t0 = x0 * c - x1 * s, t1 = x0 * s + x1 * c;
+                    x0 = t0; x1 = t1;
+                    dst = hd < a.H ? reinterpret_cast<XT *>(a.q_out) + (size_t)hd * a.d
+                                   : reinterpret_cast<XT *>(a.k_cache) + ((size_t)(hd - a.H) * a.max_seq + slot) * a.d;
+                } else {
+                    dst = reinterpret_cast<XT *>(a.v_cache) + ((size_t)(hd - a.H - a.Hkv) * a.max_seq + slot) * a.d;
                 }
+                elem<XT>::st(dst + j, x0);
+                elem<XT>::st(dst + j + half, x1);
             }
-        }
-        for (; c0 < nchunk; c0 += 64) {                          // tail
-            float xv[8];
-            load8(xs + c0 * 8, xv);
+        } else {
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                float w[8];
-                load8_nt(wp[r] + (size_t)c0 * 8, w);
-#pragma unroll
-                for (int j = 0; j < 8; j++) acc[r] = fmaf(w[j], xv[j], acc[r]);
+                const int row = row_of(g, r);
+                if (row < N) reinterpret_cast<float *>(a.out)[row] = sum[r] + (a.bias ? a.bias[row] : 0.f);
             }
         }
+    };
+    auto compute = [&](int idx, Buf &buf) {
+        const int gi = idx / nblk, cb = idx - gi * nblk;
 #pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]) * inv_m;
-        if (lane == 0) {
-            if (epi == EPI_GATEUP) {
+        for (int u = 0; u < U; u++) {
+            const int c = (cb * U + u) * 64 + lane;
+            if (c < nchunk) {
+                float xv[8];
+                load8(xs + c * 8, xv);
 #pragma unroll
-                for (int r = 0; r < R; r += 2) {
-                    const int q = g * (R / 2) + (r >> 1);
-                    if (rows[r + 1] < N) {
-                        const float gt = acc[r], up = acc[r + 1];
-                        const float act = gt / (1.0f + expf(-gt)) * up;          // candle silu(g) * u
-                        elem<XT>::st(reinterpret_cast<XT *>(a.out) + q, act);
-                    }
+                for (int r = 0; r < R; r++) {
+                    float wv[8];
+                    unpack_raw(buf[r][u], wv);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[r] = fmaf(wv[j], xv[j], acc[r]);
                 }
-            } else if (epi == EPI_QKV_ROPE) {
-                const uint32_t pos = a.st->pos, slot = a.st->len;
-                const uint32_t p = pos < (uint32_t)a.max_pos ? pos : (uint32_t)a.max_pos - 1;
-#pragma unroll
-                for (int r = 0; r < R; r += 2) {
-                    if (rows[r + 1] >= N) continue;
-                    const int q = g * (R / 2) + (r >> 1);
-                    const int hd = q / half, j = q - hd * half;
-                    float x0 = acc[r], x1 = acc[r + 1];
-                    if (a.bias) { x0 += a.bias[rows[r]]; x1 += a.bias[rows[r + 1]]; }
-                    XT *dst;
-                    if (hd < a.H + a.Hkv) {                                   // rotate-half RoPE (App. A.4)
-                        const float c = a.cos_tab[(size_t)p * half + j], s = a.sin_tab[(size_t)p * half + j];
-                        const float r0 = x0 * c - x1 * s, r1 = x0 * s + x1 * c;
-                        x0 = r0; x1 = r1;
-                        dst = hd < a.H ? reinterpret_cast<XT *>(a.q_out) + (size_t)hd * a.d
-                                       : reinterpret_cast<XT *>(a.k_cache) + ((size_t)(hd - a.H) * a.max_seq + slot) * a.d;
-                    } else {
-                        dst = reinterpret_cast<XT *>(a.v_cache) + ((size_t)(hd - a.H - a.Hkv) * a.max_seq + slot) * a.d;
-                    }
-                    elem<XT>::st(dst + j, x0);
-                    elem<XT>::st(dst + j + half, x1);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < R; r++)
-                    if (rows[r] < N) reinterpret_cast<float *>(a.out)[rows[r]] = acc[r] + (a.bias ? a.bias[rows[r]] : 0.f);
             }
+        }
+        if (cb == nblk - 1) finish_group(gw + gi * nw);
+    };
+
+    for (int idx = 0; idx < total; idx += 2) {
+        compute(idx, bufA);
+        if (idx + 2 < total) issue(idx + 2, bufA);
+        if (idx + 1 < total) {
+            compute(idx + 1, bufB);
+            if (idx + 3 < total) issue(idx + 3, bufB);
         }
     }
 }
 
-static std::atomic<int> g_gemv_r{0}, g_gemv_u{0}, g_gemv_maxblocks{0}, g_gemv_maxblocks_norm{0};
+static std::atomic<int> g_gemv_r{0}, g_gemv_u{0}, g_force_blocks{0}, g_force_waves{0};
 static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
 
-void gemv_set_tuning(int R, int U, int maxblocks, int maxblocks_norm) {
+void gemv_set_tuning(int R, int U, int blocks, int waves) {
     if (R > 0) g_gemv_r = R;
     if (U > 0) g_gemv_u = U;
-    if (maxblocks > 0) g_gemv_maxblocks = maxblocks;
-    if (maxblocks_norm > 0) g_gemv_maxblocks_norm = maxblocks_norm;
+    if (blocks >= 0) g_force_blocks = blocks;
+    if (waves >= 0) g_force_waves = waves;
 }
 
 bool gemv_supported(int dtype, int64_t N, int64_t K) {
@@ -246,7 +262,46 @@ bool gemv_supported(int dtype, int64_t N, int64_t K) {
     size_t lds = (size_t)K * (dtype == FL_DTYPE_BF16 ? 2 : 4);
     return K % 8 == 0 && K >= 8 && lds <= 160 * 1024 - 256;
 }
+// fused-norm prologue: every staging thread holds at most 3 chunks of 8 in registers, and the
+// smallest workgroup is 256 threads
 bool gemv_norm_supported(int dtype, int64_t N, int64_t K) { return gemv_supported(dtype, N, K) && K <= 6144; }
+
+static int cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0; hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// Pick (workgroups, waves per workgroup): equal row groups per wave, everything resident at once
+// (<= 12 waves per CU at 170 VGPRs), as many waves per CU as that allows.
+static void pick_geometry(int64_t ngroups, size_t lds_bytes, int *blocks_out, int *waves_out) {
+    const int cus = cu_count();
+    int fb = g_force_blocks.load(), fw = g_force_waves.load();
+    if (fb > 0 && fw > 0) { *blocks_out = fb; *waves_out = fw; return; }
+    if (ngroups <= (int64_t)cus * 4) {                 // small matrix: 4-wave workgroups, one group per wave
+        *waves_out = 4; *blocks_out = (int)((ngroups + 3) / 4);
+        return;
+    }
+    static const int kWaves[] = {12, 11, 10, 9, 8, 7, 6, 5, 4};
+    double best = -1.0; int bb = cus, bw = 8;
+    for (int mult = 1; mult <= 2; mult++) {
+        for (int w : kWaves) {
+            if (mult * w > 12) continue;
+            if ((size_t)mult * lds_bytes > 150 * 1024) continue;
+            const int64_t wt = (int64_t)cus * mult * w;
+            const int64_t per = (ngroups + wt - 1) / wt;
+            const double eff = (double)ngroups / (double)(per * wt);
+            // prefer balance, then more waves per CU (latency hiding), then fewer workgroups
+            const double score = eff + 1e-3 * (mult * w) / 12.0 - 1e-4 * mult;
+            if (score > best) { best = score; bb = cus * mult; bw = w; }
+        }
+    }
+    *blocks_out = bb; *waves_out = bw;
+}
 
 template <typename WT, typename XT, int R, int U, int PRO>
 static int launch_gemv_t(Launcher &L, const GemvArgs &a) {
@@ -260,25 +315,13 @@ static int launch_gemv_t(Launcher &L, const GemvArgs &a) {
             raised.store(lds);
         }
     }
-    // Grid: every wave should get the same number of row groups (a ragged last round costs up to
-    // 1/rounds of the kernel), and all workgroups should be resident at once (<= cap).
     const int64_t ngroups = (N + R - 1) / R;
-    int mb = g_gemv_maxblocks.load(), mbn = g_gemv_maxblocks_norm.load();
-    if (!mb) { mb = env_int("FL_GEMV_MAXBLOCKS", 768); g_gemv_maxblocks = mb; }
-    if (!mbn) { mbn = env_int("FL_GEMV_MAXBLOCKS_NORM", 768); g_gemv_maxblocks_norm = mbn; }
-    const int64_t cap = PRO == PRO_NORM ? mbn : mb;
-    int64_t blocks = (ngroups + 3) / 4;
-    if (blocks > cap) {
-        double best_eff = 0.0; int64_t best_b = cap;
-        for (int64_t b = cap; b >= cap / 2 && b >= 1; b--) {
-            const int64_t per_wave = (ngroups + 4 * b - 1) / (4 * b);
-            const double eff = (double)ngroups / (double)(per_wave * 4 * b);
-            if (eff > best_eff + 1e-9) { best_eff = eff; best_b = b; }
-        }
-        blocks = best_b;
-    }
+    int blocks = 1, waves = 4;
+    pick_geometry(ngroups, lds, &blocks, &waves);
+    if (PRO == PRO_NORM && (int64_t)waves * 64 * 3 * 8 < K) waves = (int)((K + 64 * 3 * 8 - 1) / (64 * 3 * 8));   // staging capacity
+    if (waves < 4) waves = 4;
     double bytes = (double)N * K * sizeof(WT);
-    return L.launch(KC_GEMV, bytes, 2.0 * N * K, kern, dim3((unsigned)blocks), dim3(256), lds, a);
+    return L.launch(KC_GEMV, bytes, 2.0 * N * K, kern, dim3((unsigned)blocks), dim3((unsigned)waves * 64), lds, a);
 }
 
 template <typename WT, typename XT, int PRO>
@@ -287,7 +330,6 @@ static int launch_gemv_ru(Launcher &L, const GemvArgs &a) {
     if (!R) { R = env_int("FL_GEMV_R", 2); g_gemv_r = R; }
     if (!U) { U = env_int("FL_GEMV_U", 4); g_gemv_u = U; }
     if (R == 4 && U == 2) return launch_gemv_t<WT, XT, 4, 2, PRO>(L, a);
-    if (R == 4 && U == 4) return launch_gemv_t<WT, XT, 4, 4, PRO>(L, a);
     if (R == 2 && U == 8) return launch_gemv_t<WT, XT, 2, 8, PRO>(L, a);
     if (R == 2 && U == 2) return launch_gemv_t<WT, XT, 2, 2, PRO>(L, a);
     return launch_gemv_t<WT, XT, 2, 4, PRO>(L, a);

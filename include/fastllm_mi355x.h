@@ -198,8 +198,8 @@ int fl_profile_begin(fl_model *m);
 int fl_profile_end(fl_model *m, fl_kernel_stat *stats, size_t cap, size_t *n_stats);
 
 /* Tuning knobs of the decode weight-streaming kernel (sweeps in tools/; not needed in normal use):
- * "gemv_r" rows per wave pass (2|4), "gemv_u" 512-element chunks in flight (2|4|8),
- * "gemv_maxblocks", "gemv_maxblocks_norm" grid caps (plain / fused-norm kernels). */
+ * "gemv_r" rows per wave pass (2|4), "gemv_u" 512-element chunks per pipeline block (2|4|8),
+ * "gemv_blocks" / "gemv_waves": force the grid and the waves per workgroup (0 = automatic). */
 int fl_tune(const char *key, int value);
 
 /* y[T,N] = x[T,K] . W[N,K]^T (+bias): the projection kernel family on host buffers, for unit

@@ -21,18 +21,15 @@ def main():
         w = (w & 0x807F) | 0x3C00                                        # |w| in [1/64.. ) small, finite
         x = (rs.randint(0, 65536, size=(1, K), dtype=np.uint16) & 0x807F) | 0x3C00
         best = None
-        for R in (2, 4):
-            for U in (2, 4, 8):
-                if R == 4 and U == 8:
-                    continue
-                for mb in (512, 1024, 2048, 4096):
-                    fa.tune("gemv_r", R); fa.tune("gemv_u", U); fa.tune("gemv_maxblocks", mb)
-                    _, ms = fa.op_linear(x, w, None, epilogue=epi, iters=50)
-                    gbs = N * K * 2 / ms / 1e6
-                    print("%-18s N=%6d K=%6d R=%d U=%d maxblocks=%4d  %8.2f us  %7.1f GB/s" % (name, N, K, R, U, mb, ms * 1e3, gbs), flush=True)
-                    if best is None or gbs > best[0]:
-                        best = (gbs, R, U, mb)
-        print("BEST %-18s %7.1f GB/s R=%d U=%d maxblocks=%d" % ((name,) + best), flush=True)
+        for R, U in ((2, 2), (2, 4), (2, 8), (4, 2)):
+            for blocks, waves in ((0, 0), (256, 4), (256, 8), (256, 12), (512, 4), (512, 6), (768, 4), (1024, 4)):
+                fa.tune("gemv_r", R); fa.tune("gemv_u", U); fa.tune("gemv_blocks", blocks); fa.tune("gemv_waves", waves)
+                _, ms = fa.op_linear(x, w, None, epilogue=epi, iters=50)
+                gbs = N * K * 2 / ms / 1e6
+                print("%-18s N=%6d K=%6d R=%d U=%d blocks=%4d waves=%2d  %8.2f us  %7.1f GB/s" % (name, N, K, R, U, blocks, waves, ms * 1e3, gbs), flush=True)
+                if best is None or gbs > best[0]:
+                    best = (gbs, R, U, blocks, waves)
+        print("BEST %-18s %7.1f GB/s R=%d U=%d blocks=%d waves=%d" % ((name,) + best), flush=True)
 
 
 if __name__ == "__main__":
