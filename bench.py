@@ -204,7 +204,9 @@ def main():
         tok_s = K / elapsed
         kv_mid = T + K // 2
         b_tok = decode_bytes_per_token(cfg, kv_mid)
-        gemv = next((s for s in stats if s["name"] == "gemv"), None)
+        gv = [s for s in stats if s["name"].startswith("gemv")]
+        gemv = dict(launches=sum(s["launches"] for s in gv), total_ms=sum(s["total_ms"] for s in gv),
+                    bytes=sum(s["bytes"] for s in gv)) if gv else None
         roof = None
         if gemv and gemv["launches"]:
             avg_ms = gemv["total_ms"] / gemv["launches"]
@@ -229,6 +231,8 @@ def main():
                         "mfma_frac_of_2.5PF": round(prefill_flops(cfg, T) / t_prefill / world / 2.5e15, 4)},
             "kernels": [{"name": s["name"], "launches_per_step": s["launches"] / n_prof,
                          "us_per_step": round(s["total_ms"] * 1e3 / n_prof, 2),
+                         "us_per_launch": round(s["total_ms"] * 1e3 / s["launches"], 2),
+                         "GBps": round(s["bytes"] / s["total_ms"] / 1e6, 1) if s["total_ms"] else None,
                          "share": round(s["total_ms"] / total_prof_ms, 4) if total_prof_ms else None} for s in stats],
             "hbm_allocated_gb": round(info.hbm_bytes_allocated / 1e9, 2),
         }

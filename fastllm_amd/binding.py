@@ -221,11 +221,11 @@ class Model:
         _check(lib().fl_profile_begin(self._h))
 
     def profile_end(self):
-        stats = (FlKernelStat * 32)()
+        stats = (FlKernelStat * 64)()
         n = C.c_size_t(0)
-        _check(lib().fl_profile_end(self._h, stats, 32, C.byref(n)))
+        _check(lib().fl_profile_end(self._h, stats, 64, C.byref(n)))
         return [dict(name=stats[i].name.decode(), launches=stats[i].launches, total_ms=stats[i].total_ms,
-                     bytes=stats[i].bytes, flops=stats[i].flops) for i in range(min(n.value, 32))]
+                     bytes=stats[i].bytes, flops=stats[i].flops) for i in range(min(n.value, 64))]
 
     def close(self):
         if getattr(self, "_h", None):

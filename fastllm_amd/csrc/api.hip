@@ -128,22 +128,23 @@ int fl_profile_end(fl_model *m, fl_kernel_stat *stats, size_t cap, size_t *n_sta
     std::lock_guard<std::mutex> lock(mm->mu);
     mm->profiling = false;
     for (auto &sh : mm->shards) { FL_HIP(hipSetDevice(sh.device)); FL_HIP(hipStreamSynchronize(sh.stream)); }
-    fl_kernel_stat acc[KC_COUNT];
-    memset(acc, 0, sizeof acc);
+    std::vector<fl_kernel_stat> acc;
     for (auto &r : mm->prof) {
         float ms = 0.f;
         FL_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
-        acc[r.kc].launches++; acc[r.kc].total_ms += ms; acc[r.kc].bytes += r.bytes; acc[r.kc].flops += r.flops;
+        char name[48];
+        if (r.tag[0]) snprintf(name, sizeof name, "%s[%s]", kernel_class_name(r.kc), r.tag);
+        else snprintf(name, sizeof name, "%s", kernel_class_name(r.kc));
+        fl_kernel_stat *st = nullptr;
+        for (auto &e : acc) if (!strcmp(e.name, name)) { st = &e; break; }
+        if (!st) { fl_kernel_stat e; memset(&e, 0, sizeof e); snprintf(e.name, sizeof e.name, "%s", name); acc.push_back(e); st = &acc.back(); }
+        st->launches++; st->total_ms += ms; st->bytes += r.bytes; st->flops += r.flops;
     }
     for (auto &r : mm->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     mm->prof.clear();
     size_t n = 0;
-    for (int k = 0; k < KC_COUNT; k++) {
-        if (!acc[k].launches) continue;
-        if (stats && n < cap) {
-            stats[n] = acc[k];
-            snprintf(stats[n].name, sizeof stats[n].name, "%s", kernel_class_name(k));
-        }
+    for (auto &e : acc) {
+        if (stats && n < cap) stats[n] = e;
         n++;
     }
     *n_stats = n;

@@ -4,11 +4,11 @@
 //
 // Streaming (HBM-bound, cdna guide "GEMV / M <= 16" row): each wave owns R rows at a time and
 // reads them 16 B per lane (1 KiB per wave instruction), non-temporal, straight to VGPRs -- no
-// LDS round trip for read-once bytes.  The wave's whole work list (its row groups x K blocks) is
-// flattened and software-pipelined through a register double buffer: two blocks of U chunks x R
-// rows (2*U*R KiB per wave) are always in flight, also across row-group boundaries, and the first
-// two blocks are requested BEFORE x is staged so HBM is busy during the prologue.  fp32
-// accumulate; 64-lane shuffle reduce.  x is staged once per workgroup in LDS (ds_read_b128).
+// LDS round trip for read-once bytes.  U chunks x R rows (U*R KiB per wave) are requested before
+// the first FMA of a block (straight-line code, so hipcc emits counted vmcnt waits), 8..12 waves
+// per CU overlap each other's load and FMA phases, and the first block is requested BEFORE x is
+// staged so HBM is busy during the prologue.  fp32 accumulate; 64-lane shuffle reduce.  x is
+// staged once per workgroup in LDS (ds_read_b128).
 //
 // Geometry: one workgroup per CU (or two), 4..12 waves each, chosen so that every wave gets the
 // same number of row groups (a ragged last round costs 1/rounds of the kernel) and everything is
@@ -50,8 +50,9 @@ __device__ inline void unpack_raw(const RawChunk<float> &r, float (&o)[8]) {
     for (int i = 0; i < 4; i++) { o[i] = __uint_as_float(r.v[0][i]); o[4 + i] = __uint_as_float(r.v[1][i]); }
 }
 
-template <typename WT, typename XT, int R, int U, int PRO>
-__global__ __launch_bounds__(kGemvMaxThreads) void gemv_kernel(const GemvArgs a) {
+// MAXT = 768: up to 12 waves per workgroup (170 VGPRs per lane).
+template <typename WT, typename XT, int R, int U, int PRO, int MAXT>
+__global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float red[kGemvMaxThreads / 64];
     XT *xs = reinterpret_cast<XT *>(lds_raw);
@@ -63,9 +64,6 @@ __global__ __launch_bounds__(kGemvMaxThreads) void gemv_kernel(const GemvArgs a)
     const int half = a.d >> 1;
     const int ngroups = (N + R - 1) / R;
     const int gw = blockIdx.x * nwv + wave, nw = gridDim.x * nwv;
-    const int nblk = (nchunk + 64 * U - 1) / (64 * U);                    // K blocks per row group
-    const int my_groups = gw < ngroups ? (ngroups - gw + nw - 1) / nw : 0;
-    const int total = my_groups * nblk;                                   // this wave's flattened work list
 
     auto row_of = [&](int g, int r) -> int {
         if (epi == EPI_GATEUP) { int q = g * (R / 2) + (r >> 1); return (q >> 4) * 32 + (q & 15) + ((r & 1) << 4); }
@@ -73,21 +71,26 @@ __global__ __launch_bounds__(kGemvMaxThreads) void gemv_kernel(const GemvArgs a)
         return g * R + r;
     };
     typedef RawChunk<WT> Buf[R][U];
-    auto issue = [&](int idx, Buf &buf) {
-        const int gi = idx / nblk, cb = idx - gi * nblk, g = gw + gi * nw;
+    // first K block of this wave's first row group: requested before x is staged, so HBM is busy
+    // during the prologue
+    constexpr int NPRE = 1;                          // K blocks requested ahead of the prologue (2 spills: measured slower)
+    Buf pre[NPRE];
+    bool have_pre[NPRE];
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int row = row_of(g, r);
-            const WT *wp = W + (size_t)(row < N ? row : N - 1) * K;
+    for (int i = 0; i < NPRE; i++) have_pre[i] = gw < ngroups && lane + 64 * (U * (i + 1) - 1) < nchunk;
+    auto prefetch = [&]() {
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int c = (cb * U + u) * 64 + lane;
-                if (c < nchunk) load_raw_nt(wp + (size_t)c * 8, buf[r][u]);
+        for (int i = 0; i < NPRE; i++) {
+            if (!have_pre[i]) continue;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int row = row_of(gw, r);
+                const WT *wp = W + (size_t)(row < N ? row : N - 1) * K;
+#pragma unroll
+                for (int u = 0; u < U; u++) load_raw_nt(wp + (size_t)(lane + 64 * (U * i + u)) * 8, pre[i][r][u]);
             }
         }
     };
-
-    Buf bufA, bufB;
     float inv_m = 1.0f;
     if constexpr (PRO == PRO_NORM) {
         constexpr int NCH = 3;                       // nthr * NCH * 8 >= K (host-checked)
@@ -110,8 +113,7 @@ __global__ __launch_bounds__(kGemvMaxThreads) void gemv_kernel(const GemvArgs a)
         }
         // the weight stream starts now: issued after the (short) activation loads so that the counted
         // wait for those does not have to drain the long weight loads
-        if (total > 0) issue(0, bufA);
-        if (total > 1) issue(1, bufB);
+        prefetch();
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
@@ -144,8 +146,7 @@ __global__ __launch_bounds__(kGemvMaxThreads) void gemv_kernel(const GemvArgs a)
             }
         }
         if (a.x_scale) inv_m = *a.x_scale;
-        if (total > 0) issue(0, bufA);
-        if (total > 1) issue(1, bufB);
+        prefetch();
 #pragma unroll
         for (int i = 0; i < NXR; i++) {
             const int c = tid + nthr * i;
@@ -216,33 +217,57 @@ __global__ __launch_bounds__(kGemvMaxThreads) void gemv_kernel(const GemvArgs a)
             }
         }
     };
-    auto compute = [&](int idx, Buf &buf) {
-        const int gi = idx / nblk, cb = idx - gi * nblk;
+    auto fma_block = [&](const Buf &buf, int c0) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int c = (cb * U + u) * 64 + lane;
-            if (c < nchunk) {
-                float xv[8];
-                load8(xs + c * 8, xv);
+            float xv[8];
+            load8(xs + (c0 + 64 * u) * 8, xv);
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    float wv[8];
-                    unpack_raw(buf[r][u], wv);
+            for (int r = 0; r < R; r++) {
+                float wv[8];
+                unpack_raw(buf[r][u], wv);
 #pragma unroll
-                    for (int j = 0; j < 8; j++) acc[r] = fmaf(wv[j], xv[j], acc[r]);
-                }
+                for (int j = 0; j < 8; j++) acc[r] = fmaf(wv[j], xv[j], acc[r]);
             }
         }
-        if (cb == nblk - 1) finish_group(gw + gi * nw);
     };
 
-    for (int idx = 0; idx < total; idx += 2) {
-        compute(idx, bufA);
-        if (idx + 2 < total) issue(idx + 2, bufA);
-        if (idx + 1 < total) {
-            compute(idx + 1, bufB);
-            if (idx + 3 < total) issue(idx + 3, bufB);
+#pragma nounroll
+    for (int g = gw; g < ngroups; g += nw) {
+        const WT *wp[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int row = row_of(g, r);
+            wp[r] = W + (size_t)(row < N ? row : N - 1) * K;
         }
+        int c0 = lane;
+        if (g == gw) {
+#pragma unroll
+            for (int i = 0; i < NPRE; i++)
+                if (have_pre[i]) { fma_block(pre[i], c0); c0 += 64 * U; }
+        }
+#pragma nounroll
+        for (; c0 + 64 * (U - 1) < nchunk; c0 += 64 * U) {      // full blocks of U chunks: straight-line, counted waits
+            Buf w;
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int r = 0; r < R; r++) load_raw_nt(wp[r] + (size_t)(c0 + 64 * u) * 8, w[r][u]);
+            fma_block(w, c0);
+        }
+#pragma nounroll
+        for (; c0 < nchunk; c0 += 64) {                          // ragged tail of K
+            float xv[8];
+            load8(xs + c0 * 8, xv);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                float wv[8];
+                load8_nt(wp[r] + (size_t)c0 * 8, wv);
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[r] = fmaf(wv[j], xv[j], acc[r]);
+            }
+        }
+        finish_group(g);
     }
 }
 
@@ -303,11 +328,9 @@ static void pick_geometry(int64_t ngroups, size_t lds_bytes, int *blocks_out, in
     *blocks_out = bb; *waves_out = bw;
 }
 
-template <typename WT, typename XT, int R, int U, int PRO>
-static int launch_gemv_t(Launcher &L, const GemvArgs &a) {
-    auto kern = gemv_kernel<WT, XT, R, U, PRO>;
-    const int64_t N = a.N, K = a.K;
-    size_t lds = ((size_t)K * sizeof(XT) + 15) & ~(size_t)15;
+template <typename WT, typename XT, int R, int U, int PRO, int MAXT>
+static int launch_gemv_k(Launcher &L, const GemvArgs &a, int blocks, int waves, size_t lds) {
+    auto kern = gemv_kernel<WT, XT, R, U, PRO, MAXT>;
     if (lds > 64 * 1024) {
         static std::atomic<size_t> raised{0};      // per instantiation, process-wide
         if (raised.load() < lds) {
@@ -315,13 +338,23 @@ static int launch_gemv_t(Launcher &L, const GemvArgs &a) {
             raised.store(lds);
         }
     }
+    double bytes = (double)a.N * a.K * sizeof(WT);
+    char tag[32];
+    snprintf(tag, sizeof tag, "%dx%d%s%s", a.N, a.K, PRO == PRO_NORM ? ",norm" : "", a.epi == EPI_GATEUP ? ",glu" : (a.epi == EPI_QKV_ROPE ? ",rope" : ""));
+    Launcher LL = L; LL.tag = tag;
+    return LL.launch(KC_GEMV, bytes, 2.0 * a.N * a.K, kern, dim3((unsigned)blocks), dim3((unsigned)waves * 64), lds, a);
+}
+
+template <typename WT, typename XT, int R, int U, int PRO>
+static int launch_gemv_t(Launcher &L, const GemvArgs &a) {
+    const int64_t N = a.N, K = a.K;
+    size_t lds = ((size_t)K * sizeof(XT) + 15) & ~(size_t)15;
     const int64_t ngroups = (N + R - 1) / R;
     int blocks = 1, waves = 4;
     pick_geometry(ngroups, lds, &blocks, &waves);
     if (PRO == PRO_NORM && (int64_t)waves * 64 * 3 * 8 < K) waves = (int)((K + 64 * 3 * 8 - 1) / (64 * 3 * 8));   // staging capacity
     if (waves < 4) waves = 4;
-    double bytes = (double)N * K * sizeof(WT);
-    return L.launch(KC_GEMV, bytes, 2.0 * N * K, kern, dim3((unsigned)blocks), dim3((unsigned)waves * 64), lds, a);
+    return launch_gemv_k<WT, XT, R, U, PRO, 768>(L, a, blocks, waves, lds);
 }
 
 template <typename WT, typename XT, int PRO>

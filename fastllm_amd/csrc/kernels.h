@@ -13,19 +13,21 @@ enum KernelClass {
 };
 const char *kernel_class_name(int kc);
 
-struct ProfRecord { int kc; double bytes, flops; hipEvent_t e0, e1; };
+struct ProfRecord { int kc; double bytes, flops; hipEvent_t e0, e1; char tag[32]; };
 
 // Launch context: the stream a kernel goes to and, while profiling, where its event pair is kept.
 struct Launcher {
     hipStream_t stream = nullptr;
     std::vector<ProfRecord> *prof = nullptr;   // non-null: bracket every launch with HIP events
+    const char *tag = "";                      // optional sub-class label for the profile (shape, variant)
 
     template <typename... KArgs, typename... Args>
     int launch(int kc, double bytes, double flops, void (*kernel)(KArgs...), dim3 grid, dim3 block,
                size_t lds, Args... args) {
         if (grid.x == 0 || grid.y == 0 || grid.z == 0) return FL_OK;
         if (prof) {
-            ProfRecord r{kc, bytes, flops, nullptr, nullptr};
+            ProfRecord r{kc, bytes, flops, nullptr, nullptr, {0}};
+            snprintf(r.tag, sizeof r.tag, "%s", tag ? tag : "");
             FL_HIP(hipEventCreate(&r.e0));
             FL_HIP(hipEventCreate(&r.e1));
             hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, stream, r.e0, r.e1, 0, static_cast<KArgs>(args)...);
@@ -99,7 +101,10 @@ int launch_argmax_advance(Launcher &L, const float *logits, int64_t V, StepState
 int launch_reduce_shards(Launcher &L, float *const *bufs_dev, int nshards, int64_t n);
 
 // ---- attention -----------------------------------------------------------------------------
-struct AttnScratch { float *part_m, *part_l, *part_o; unsigned *counters; int nsplit; int64_t kv_len_hint; };
+struct AttnScratch {
+    float *part_m, *part_l, *part_o; unsigned *counters; int nsplit; int64_t kv_len_hint;
+    const void *pf_ptr = nullptr; int64_t pf_bytes = 0;     // optional: bytes to pull into the Infinity Cache meanwhile
+};
 // decode: one query token over len+1 cached keys, no mask (App. A.5)
 int launch_attn_decode(Launcher &L, int dtype, const void *q, const void *k_cache, const void *v_cache,
                        const StepState *st, void *out, const AttnScratch &sc, int64_t H, int64_t Hkv,

@@ -209,8 +209,10 @@ static int build_weights(Builder &B) {
         for (auto &ly : sh.layers) {
             FL_TRY(dev_alloc(sh.allocs, &ly.wqkv, (size_t)nq * D.h * es, &m->hbm_bytes));
             if (D.qkv_bias) FL_TRY(dev_alloc(sh.allocs, (void **)&ly.bqkv, (size_t)nq * 4, &m->hbm_bytes));
-            FL_TRY(dev_alloc(sh.allocs, &ly.wo, (size_t)D.h * sh.Hs * D.d * es, &m->hbm_bytes));
-            FL_TRY(dev_alloc(sh.allocs, &ly.wgu, (size_t)2 * sh.Ip * D.h * es, &m->hbm_bytes));
+            // wo and wgu share one allocation (decode attention prefetches them as one range)
+            const size_t wo_bytes = (size_t)D.h * sh.Hs * D.d * es;
+            FL_TRY(dev_alloc(sh.allocs, &ly.wo, wo_bytes + (size_t)2 * sh.Ip * D.h * es, &m->hbm_bytes));
+            ly.wgu = (char *)ly.wo + wo_bytes;
             FL_TRY(dev_alloc(sh.allocs, &ly.wd, (size_t)D.h * sh.Ip * es, &m->hbm_bytes));
             FL_TRY(dev_alloc(sh.allocs, (void **)&ly.ln1, (size_t)D.h * 4, &m->hbm_bytes));
             FL_TRY(dev_alloc(sh.allocs, (void **)&ly.ln2, (size_t)D.h * 4, &m->hbm_bytes));
@@ -534,6 +536,13 @@ static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
             a.H = (int)sh.Hs; a.Hkv = (int)sh.Hkvs; a.d = (int)D.d; a.max_seq = (int)c->max_seq; a.max_pos = (int)D.max_pos;
             FL_TRY(launch_gemv(L, dt, a));
             AttnScratch as{cs.part_m, cs.part_l, cs.part_o, cs.counters, c->nsplit, len_hint + 1};
+            // weights are laid out wo | wgu back to back per layer (one allocation), so one range covers
+            // o_proj and the head of gate/up
+            static const int64_t pf_mb = env_int("FL_PREFETCH_MB", 0);   // measured: no gain on MI355X (profiles/r01/NOTES.md)
+            if (pf_mb > 0 && ly.wgu == (char *)ly.wo + (size_t)D.h * sh.Hs * D.d * m->esize()) {
+                as.pf_ptr = ly.wo;
+                as.pf_bytes = std::min<int64_t>(pf_mb << 20, (int64_t)((size_t)D.h * sh.Hs * D.d + (size_t)2 * sh.Ip * D.h) * (int64_t)m->esize());
+            }
             FL_TRY(launch_attn_decode(L, dt, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->max_seq, D.scale));
             FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, 1, D.h, sh.Hs * D.d, EPI_F32));
         }

@@ -1,0 +1,6 @@
+#!/usr/bin/env python3
+import json, sys
+d = json.load(open(sys.argv[1]))
+print(d["config"]["workload"], "->", d["value"], d["unit"], "| gemv", d["roofline"]["achieved"] if d.get("roofline") else None, "GB/s | prefill", d["prefill"]["tokens_per_sec"])
+for k in d["kernels"]:
+    print("   %-34s x%-5g %9.2f us/step %8.2f us/launch %8s GB/s" % (k["name"], k["launches_per_step"], k["us_per_step"], k.get("us_per_launch", 0), k.get("GBps")))
