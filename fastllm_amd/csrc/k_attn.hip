@@ -14,7 +14,7 @@
 
 #include <algorithm>
 
-#include "kernels.h"
+#include "attn_common.h"
 
 namespace fl {
 
@@ -123,24 +123,6 @@ __device__ inline void merge_to_lds(AttnState<GMAX> &s, int G, float *lds, int w
     __syncthreads();
 }
 
-// combine the NW wave slabs in LDS for (head g, 4 d-elements at j4): returns M, L and O[4] (unnormalised)
-template <int D, int GMAX, int NW>
-__device__ inline void combine_lds(const float *lds, int g, int j4, float &M, float &L, float (&O)[4]) {
-    constexpr int STR = D + 2;
-    M = -INFINITY;
-#pragma unroll
-    for (int w = 0; w < NW; w++) M = fmaxf(M, lds[((size_t)w * GMAX + g) * STR + D]);
-    L = 0.f; O[0] = O[1] = O[2] = O[3] = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; w++) {
-        const float *p = lds + ((size_t)w * GMAX + g) * STR;
-        const float wt = p[D] == -INFINITY ? 0.f : __expf(p[D] - M);
-        L += p[D + 1] * wt;
-#pragma unroll
-        for (int j = 0; j < 4; j++) O[j] += p[j4 + j] * wt;
-    }
-}
-
 template <typename CT, int D, int GMAX>
 __device__ inline void load_q(float (&q)[GMAX][8], const CT *__restrict__ qrow, int hq0, int G, int lane, float scale) {
     constexpr int LPK = D / 8;
@@ -175,32 +157,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const CT *__restri
                                                               float *__restrict__ part_m, float *__restrict__ part_l,
                                                               float *__restrict__ part_o, unsigned *__restrict__ counters,
                                                               CT *__restrict__ out, int H, int Hkv, int max_seq,
-                                                              float scale, int nsplit,
-                                                              const unsigned char *__restrict__ pf_ptr, long long pf_bytes) {
+                                                              float scale, int nsplit) {
     __shared__ float lds[NW * GMAX * (D + 2)];
     __shared__ int is_last;
     constexpr int LPK = D / 8, KPI = 64 / LPK, UNR = 2;
-    if ((int)blockIdx.y >= nsplit) {
-        // Prefetch role.  Decode attention is latency-bound and leaves HBM idle, so the spare
-        // workgroups of this launch pull the next kernels' weights (o_proj, then the head of
-        // gate/up) into the memory-side Infinity Cache with plain loads; the GEMVs that follow
-        // then find those lines on-die.  Pure hint: results never depend on it.
-        if (blockIdx.z != 0) return;
-        const long long nblk = (long long)(gridDim.y - nsplit) * gridDim.x;
-        const long long bid = (long long)(blockIdx.y - nsplit) * gridDim.x + blockIdx.x;
-        const long long per = ((pf_bytes / nblk) + 4095) / 4096 * 4096;
-        const long long lo = bid * per, hi = min(pf_bytes, lo + per);
-        uint4v accv = {0, 0, 0, 0};
-        for (long long off = lo + (long long)threadIdx.x * 16; off + 16 <= hi; off += (long long)NW * 64 * 16 * 4) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const long long o2 = off + (long long)u * NW * 64 * 16;
-                if (o2 + 16 <= hi) { uint4v t = *reinterpret_cast<const uint4v *>(pf_ptr + o2); accv[0] ^= t[0]; }
-            }
-        }
-        asm volatile("" :: "v"(accv[0]));
-        return;
-    }
     const int hk = blockIdx.x, split = blockIdx.y;
     const int Gall = H / Hkv, g0 = blockIdx.z * GMAX;
     const int G = min(GMAX, Gall - g0);
@@ -218,70 +178,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const CT *__restri
         attend_range<CT, D, GMAX, NW, UNR>(s, qv, G, kc + (size_t)hk * max_seq * D, vc + (size_t)hk * max_seq * D, lo, hi, wave, lane);
     merge_to_lds<D, GMAX, NW>(s, G, lds, wave, lane);
 
-    if (nsplit == 1) {
-        for (int e = threadIdx.x; e < G * (D / 4); e += NW * 64) {
-            const int g = e / (D / 4), j4 = (e % (D / 4)) * 4;
-            float M, L, O[4];
-            combine_lds<D, GMAX, NW>(lds, g, j4, M, L, O);
-            const float inv = 1.0f / L;
-#pragma unroll
-            for (int j = 0; j < 4; j++) elem<CT>::st(out + (size_t)(hq0 + g) * D + j4 + j, O[j] * inv);
-        }
-        return;
-    }
-    // ---- publish this split's slab
-    for (int e = threadIdx.x; e < G * (D / 4); e += NW * 64) {
-        const int g = e / (D / 4), j4 = (e % (D / 4)) * 4;
-        float M, L, O[4];
-        combine_lds<D, GMAX, NW>(lds, g, j4, M, L, O);
-        const size_t idx = (size_t)(hq0 + g) * nsplit + split;
-        *reinterpret_cast<float4v *>(part_o + idx * D + j4) = float4v{O[0], O[1], O[2], O[3]};
-        if (j4 == 0) { part_m[idx] = M; part_l[idx] = L; }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned *cnt = counters + (size_t)hk * gridDim.z + blockIdx.z;
-        const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = t == (unsigned)nsplit - 1;
-        if (last) {
-            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everyone has arrived
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        is_last = last;
-    }
-    __syncthreads();
-    if (!is_last) return;
-    // ---- last arriver: stage the (m, l) of all splits in LDS, then combine the o slabs in parallel
-    float *lm = lds, *ll = lds + GMAX * nsplit;                       // nsplit <= NW * (D + 2) / 2 (host-checked)
-    for (int e = threadIdx.x; e < G * nsplit; e += NW * 64) {
-        const int g = e / nsplit, sp = e % nsplit;
-        const size_t idx = (size_t)(hq0 + g) * nsplit + sp;
-        lm[g * nsplit + sp] = part_m[idx]; ll[g * nsplit + sp] = part_l[idx];
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < G * (D / 4); e += NW * 64) {
-        const int g = e / (D / 4), j4 = (e % (D / 4)) * 4;
-        const size_t hb = (size_t)(hq0 + g) * nsplit;
-        float M = -INFINITY;
-        for (int sp = 0; sp < nsplit; sp++) M = fmaxf(M, lm[g * nsplit + sp]);
-        float L = 0.f, O[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int sp = 0; sp < nsplit; sp++) {
-            const float mm = lm[g * nsplit + sp];
-            const float w = mm == -INFINITY ? 0.f : __expf(mm - M);
-            L += ll[g * nsplit + sp] * w;
-            const float4v o4 = *reinterpret_cast<const float4v *>(part_o + (hb + sp) * D + j4);
-#pragma unroll
-            for (int j = 0; j < 4; j++) O[j] += o4[j] * w;
-        }
-        const float inv = 1.0f / L;
-#pragma unroll
-        for (int j = 0; j < 4; j++) elem<CT>::st(out + (size_t)(hq0 + g) * D + j4 + j, O[j] * inv);
-    }
+    decode_tail<CT, D, GMAX, NW>(lds, &is_last, G, hq0, hk * (int)gridDim.z + (int)blockIdx.z, split, nsplit, part_m, part_l,
+                                 part_o, counters, out);
 }
 
 template <typename CT, int D, int GMAX, int NW>
@@ -289,18 +187,12 @@ static int launch_decode_t(Launcher &L, const void *q, const void *kc, const voi
                            void *out, const AttnScratch &sc, int64_t H, int64_t Hkv, int64_t max_seq, float scale) {
     const int G = (int)(H / Hkv);
     if (sc.nsplit > 64) FL_FAIL(FL_ERR_BAD_ARGUMENT, "attention: at most 64 splits");
-    int npf_y = 0;
-    if (sc.pf_ptr && sc.pf_bytes > 0) {                      // ~256 KiB per prefetch workgroup
-        long long want = (sc.pf_bytes + 256 * 1024 - 1) / (256 * 1024);
-        npf_y = (int)std::min<long long>((want + Hkv - 1) / Hkv, 256);
-    }
-    dim3 grid((unsigned)Hkv, (unsigned)(sc.nsplit + npf_y), (unsigned)((G + GMAX - 1) / GMAX));
+    dim3 grid((unsigned)Hkv, (unsigned)sc.nsplit, (unsigned)((G + GMAX - 1) / GMAX));
     // the KV length lives on the device; the caller passes its host copy for the byte accounting
     double kvbytes = 2.0 * (double)sc.kv_len_hint * Hkv * D * sizeof(CT);
     return L.launch(KC_ATTN_DECODE, kvbytes, 4.0 * (double)sc.kv_len_hint * H * D, attn_decode_kernel<CT, D, GMAX, NW>, grid,
                     dim3(NW * 64), 0, (const CT *)q, (const CT *)kc, (const CT *)vc, st, sc.part_m, sc.part_l, sc.part_o,
-                    sc.counters, (CT *)out, (int)H, (int)Hkv, (int)max_seq, scale, sc.nsplit,
-                    (const unsigned char *)sc.pf_ptr, (long long)sc.pf_bytes);
+                    sc.counters, (CT *)out, (int)H, (int)Hkv, (int)max_seq, scale, sc.nsplit);
 }
 
 int launch_attn_decode(Launcher &L, int dtype, const void *q, const void *k_cache, const void *v_cache,

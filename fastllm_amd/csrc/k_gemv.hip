@@ -197,17 +197,21 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
                 float x0 = sum[r], x1 = sum[r + 1];
                 if (a.bias) { x0 += a.bias[r0w]; x1 += a.bias[r1w]; }
                 XT *dst;
+                size_t stride = 1;                                        // element stride between j and j+1
                 if (hd < a.H + a.Hkv) {                                   // rotate-half RoPE (App. A.4)
                     const float c = a.cos_tab[(size_t)p * half + j], s = a.sin_tab[(size_t)p * half + j];
                     const float t0 = x0 * c - x1 * s, t1 = x0 * s + x1 * c;
                     x0 = t0; x1 = t1;
                     dst = hd < a.H ? reinterpret_cast<XT *>(a.q_out) + (size_t)hd * a.d
                                    : reinterpret_cast<XT *>(a.k_cache) + ((size_t)(hd - a.H) * a.max_seq + slot) * a.d;
+                } else if (a.v_ld > 0) {                                  // transposed value cache [Hkv][d][v_ld]
+                    dst = reinterpret_cast<XT *>(a.v_cache) + (size_t)(hd - a.H - a.Hkv) * a.d * a.v_ld + slot;
+                    stride = (size_t)a.v_ld;
                 } else {
                     dst = reinterpret_cast<XT *>(a.v_cache) + ((size_t)(hd - a.H - a.Hkv) * a.max_seq + slot) * a.d;
                 }
-                elem<XT>::st(dst + j, x0);
-                elem<XT>::st(dst + j + half, x1);
+                elem<XT>::st(dst + (size_t)j * stride, x0);
+                elem<XT>::st(dst + (size_t)(j + half) * stride, x1);
             }
         } else {
 #pragma unroll

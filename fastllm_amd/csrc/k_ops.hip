@@ -89,7 +89,8 @@ template <typename CT>
 __global__ __launch_bounds__(256) void rope_kv_kernel(const float *__restrict__ qkv, const StepState *__restrict__ st,
                                                       const float *__restrict__ cos_tab, const float *__restrict__ sin_tab,
                                                       int max_pos, CT *__restrict__ q_out, CT *__restrict__ kc,
-                                                      CT *__restrict__ vc, int T, int H, int Hkv, int d, int max_seq) {
+                                                      CT *__restrict__ vc, int T, int H, int Hkv, int d, int max_seq,
+                                                      int v_transposed) {
     const int half = d >> 1;
     const int nheads = H + 2 * Hkv;
     const int per_t = nheads * half;
@@ -111,6 +112,9 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(const float *__restrict__ 
             CT *o = kc + ((size_t)(hd - H) * max_seq + slot) * d;
             elem<CT>::st(o + j, ra); elem<CT>::st(o + j + half, rb);
         }
+    } else if (v_transposed) {                     // [Hkv][d][max_seq]: one key column per token
+        CT *o = vc + (size_t)(hd - H - Hkv) * d * max_seq + slot;
+        elem<CT>::st(o + (size_t)j * max_seq, a); elem<CT>::st(o + (size_t)(j + half) * max_seq, b);
     } else {
         CT *o = vc + ((size_t)(hd - H - Hkv) * max_seq + slot) * d;
         elem<CT>::st(o + j, a); elem<CT>::st(o + j + half, b);
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(const float *__restrict__ 
 
 int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st, const float *cos_tab,
                    const float *sin_tab, int64_t max_pos, void *q_out, void *k_cache, void *v_cache,
-                   int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t max_seq) {
+                   int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t max_seq, bool v_transposed) {
     const int64_t total = T * (H + 2 * Hkv) * (d / 2);
     const unsigned blocks = (unsigned)((total + 255) / 256);
     const int es = dtype == FL_DTYPE_BF16 ? 2 : 4;
@@ -127,10 +131,10 @@ int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st
     if (dtype == FL_DTYPE_BF16)
         return L.launch(KC_ROPE_KV, bytes, 0, rope_kv_kernel<bf16_t>, dim3(blocks), dim3(256), 0, qkv, st, cos_tab,
                         sin_tab, (int)max_pos, (bf16_t *)q_out, (bf16_t *)k_cache, (bf16_t *)v_cache, (int)T, (int)H,
-                        (int)Hkv, (int)d, (int)max_seq);
+                        (int)Hkv, (int)d, (int)max_seq, (int)v_transposed);
     return L.launch(KC_ROPE_KV, bytes, 0, rope_kv_kernel<float>, dim3(blocks), dim3(256), 0, qkv, st, cos_tab,
                     sin_tab, (int)max_pos, (float *)q_out, (float *)k_cache, (float *)v_cache, (int)T, (int)H,
-                    (int)Hkv, (int)d, (int)max_seq);
+                    (int)Hkv, (int)d, (int)max_seq, (int)v_transposed);
 }
 
 // ------------------------------------------------------------------------------- argmax + advance

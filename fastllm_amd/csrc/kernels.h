@@ -61,6 +61,7 @@ struct GemvArgs {
     const float *cos_tab = nullptr, *sin_tab = nullptr;
     void *q_out = nullptr, *k_cache = nullptr, *v_cache = nullptr;
     int H = 0, Hkv = 0, d = 0, max_seq = 0, max_pos = 0;
+    int v_ld = 0;                   // > 0: value cache is transposed [Hkv][d][v_ld] (MFMA attention layout)
 };
 int launch_gemv(Launcher &L, int dtype, const GemvArgs &a);
 bool gemv_norm_supported(int dtype, int64_t N, int64_t K);
@@ -91,9 +92,10 @@ int launch_embed(Launcher &L, int dtype, const void *E, const uint32_t *ids, con
 int launch_rmsnorm_add(Launcher &L, int dtype, float *x_res, const float *delta, const float *w,
                        float eps, void *xs, float *inv_rms, int64_t T, int64_t h);
 // RoPE(q,k) + KV append.  qkv fp32 [T, (H+2Hkv)*d]; q_out XT [T,H*d]; caches XT [Hkv][max_seq][d]
+// v_transposed: value cache laid out [Hkv][d][max_seq] instead of [Hkv][max_seq][d]
 int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st, const float *cos_tab,
                    const float *sin_tab, int64_t max_pos, void *q_out, void *k_cache, void *v_cache,
-                   int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t max_seq);
+                   int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t max_seq, bool v_transposed);
 // logits[V] -> st->token (ties: last max index), out_tokens[st->step]; advances pos/len/step
 int launch_argmax_advance(Launcher &L, const float *logits, int64_t V, StepState *st, uint32_t *out_tokens,
                           int advance);
@@ -101,10 +103,7 @@ int launch_argmax_advance(Launcher &L, const float *logits, int64_t V, StepState
 int launch_reduce_shards(Launcher &L, float *const *bufs_dev, int nshards, int64_t n);
 
 // ---- attention -----------------------------------------------------------------------------
-struct AttnScratch {
-    float *part_m, *part_l, *part_o; unsigned *counters; int nsplit; int64_t kv_len_hint;
-    const void *pf_ptr = nullptr; int64_t pf_bytes = 0;     // optional: bytes to pull into the Infinity Cache meanwhile
-};
+struct AttnScratch { float *part_m, *part_l, *part_o; unsigned *counters; int nsplit; int64_t kv_len_hint; };
 // decode: one query token over len+1 cached keys, no mask (App. A.5)
 int launch_attn_decode(Launcher &L, int dtype, const void *q, const void *k_cache, const void *v_cache,
                        const StepState *st, void *out, const AttnScratch &sc, int64_t H, int64_t Hkv,
@@ -113,6 +112,15 @@ int launch_attn_decode(Launcher &L, int dtype, const void *q, const void *k_cach
 int launch_attn_prefill(Launcher &L, int dtype, const void *q, const void *k_cache, const void *v_cache,
                         const StepState *st, void *out, int64_t T, int64_t H, int64_t Hkv, int64_t d,
                         int64_t max_seq, float scale, int64_t window);
+
+// bf16 MFMA attention (k_attn_mfma.hip): needs the transposed value cache [Hkv][d][seq_alloc], seq_alloc % 32 == 0
+bool attn_mfma_supported(int dtype, int64_t H, int64_t Hkv, int64_t d);
+int launch_attn_decode_mfma(Launcher &L, const void *q, const void *k_cache, const void *v_cache_T, const StepState *st,
+                            void *out, const AttnScratch &sc, int64_t H, int64_t Hkv, int64_t d, int64_t seq_alloc,
+                            float scale);
+int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, const void *v_cache_T, const StepState *st,
+                             void *out, int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t seq_alloc, float scale,
+                             int64_t window);
 
 // ---- weight conversion at model build ---------------------------------------------------------
 // dst[row_map(r)][c] = cvt(src[r0+r][c0+c]); row_mode 0: dst_row0+r, 1: gate rows, 2: up rows

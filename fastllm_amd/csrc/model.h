@@ -98,6 +98,8 @@ constexpr size_t kOutTokensCap = 4096;
 struct Cache {
     Model *m = nullptr;
     size_t max_seq = 0, len = 0;
+    size_t seq_alloc = 0;        // max_seq rounded up to 32: row stride of K / column stride of V^T
+    bool v_transposed = false;   // bf16 MFMA attention: value cache stored [Hkvs][d][seq_alloc]
     int nsplit = 1;
     int warm_steps = 0;          // eager decode steps done (graph is captured after the first)
     bool graph_failed = false;

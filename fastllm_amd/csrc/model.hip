@@ -209,10 +209,8 @@ static int build_weights(Builder &B) {
         for (auto &ly : sh.layers) {
             FL_TRY(dev_alloc(sh.allocs, &ly.wqkv, (size_t)nq * D.h * es, &m->hbm_bytes));
             if (D.qkv_bias) FL_TRY(dev_alloc(sh.allocs, (void **)&ly.bqkv, (size_t)nq * 4, &m->hbm_bytes));
-            // wo and wgu share one allocation (decode attention prefetches them as one range)
-            const size_t wo_bytes = (size_t)D.h * sh.Hs * D.d * es;
-            FL_TRY(dev_alloc(sh.allocs, &ly.wo, wo_bytes + (size_t)2 * sh.Ip * D.h * es, &m->hbm_bytes));
-            ly.wgu = (char *)ly.wo + wo_bytes;
+            FL_TRY(dev_alloc(sh.allocs, &ly.wo, (size_t)D.h * sh.Hs * D.d * es, &m->hbm_bytes));
+            FL_TRY(dev_alloc(sh.allocs, &ly.wgu, (size_t)2 * sh.Ip * D.h * es, &m->hbm_bytes));
             FL_TRY(dev_alloc(sh.allocs, &ly.wd, (size_t)D.h * sh.Ip * es, &m->hbm_bytes));
             FL_TRY(dev_alloc(sh.allocs, (void **)&ly.ln1, (size_t)D.h * 4, &m->hbm_bytes));
             FL_TRY(dev_alloc(sh.allocs, (void **)&ly.ln2, (size_t)D.h * 4, &m->hbm_bytes));
@@ -428,18 +426,24 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
     const Dims &D = m->D;
     std::unique_ptr<Cache> c(new Cache());
     c->m = m; c->max_seq = max_seq; c->len = 0;
+    c->seq_alloc = (max_seq + 31) / 32 * 32;
+    c->v_transposed = env_int("FL_ATTN_MFMA", 1) != 0 && attn_mfma_supported(m->dtype, m->shards[0].Hs, m->shards[0].Hkvs, D.d);
     // decode attention splits S so that the K/V stream of one kv head is spread over many CUs
     // (~64 cached positions per 4-wave workgroup at full length); partials are combined in-launch
-    int64_t ns = (int64_t)((max_seq + 63) / 64);
+    // MFMA kernel: 128 keys (four 32-key wave steps) per workgroup; VALU kernel: 64
+    int64_t ns = (int64_t)((max_seq + (c->v_transposed ? 127 : 63)) / (c->v_transposed ? 128 : 64));
     c->nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(ns, 64));
     c->nsplit = env_int("FL_ATTN_NSPLIT", c->nsplit);
     c->shards.resize(m->shards.size());
     for (size_t i = 0; i < m->shards.size(); i++) {
         Shard &sh = m->shards[i]; CacheShard &cs = c->shards[i];
         FL_HIP(hipSetDevice(sh.device));
-        const size_t kvb = (size_t)D.L * sh.Hkvs * max_seq * D.d * m->esize();
+        const size_t kvb = (size_t)D.L * sh.Hkvs * c->seq_alloc * D.d * m->esize();
         FL_TRY(dev_alloc(cs.allocs, &cs.k, kvb, nullptr));
         FL_TRY(dev_alloc(cs.allocs, &cs.v, kvb, nullptr));
+        // finite contents everywhere: the MFMA kernel multiplies masked keys' values by p = 0
+        FL_HIP(hipMemset(cs.k, 0, kvb));
+        FL_HIP(hipMemset(cs.v, 0, kvb));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.st, sizeof(StepState), nullptr));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.out_tokens, kOutTokensCap * 4, nullptr));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.part_m, (size_t)sh.Hs * c->nsplit * 4, nullptr));
@@ -525,7 +529,7 @@ static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
             Shard &sh = m->shards[i]; Scratch &sc = sh.dec; CacheShard &cs = c->shards[i]; LayerW &ly = sh.layers[l];
             FL_HIP(hipSetDevice(sh.device));
             Launcher L = make_launcher(m, sh);
-            const size_t kv_layer = (size_t)l * sh.Hkvs * c->max_seq * D.d * m->esize();
+            const size_t kv_layer = (size_t)l * sh.Hkvs * c->seq_alloc * D.d * m->esize();
             void *kc = (char *)cs.k + kv_layer, *vc = (char *)cs.v + kv_layer;
             GemvArgs a;
             a.W = ly.wqkv; a.bias = ly.bqkv; a.N = (int)((sh.Hs + 2 * sh.Hkvs) * D.d); a.K = (int)D.h;
@@ -533,17 +537,12 @@ static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
             if (l == 0) { a.embed = sh.embed; a.x_out = sc.x_res2; }
             else { a.x_in = sc.x_res; a.delta = sc.delta; a.x_out = sc.x_res2; }
             a.cos_tab = sh.cos_tab; a.sin_tab = sh.sin_tab; a.q_out = sc.q; a.k_cache = kc; a.v_cache = vc;
-            a.H = (int)sh.Hs; a.Hkv = (int)sh.Hkvs; a.d = (int)D.d; a.max_seq = (int)c->max_seq; a.max_pos = (int)D.max_pos;
+            a.H = (int)sh.Hs; a.Hkv = (int)sh.Hkvs; a.d = (int)D.d; a.max_seq = (int)c->seq_alloc; a.max_pos = (int)D.max_pos;
+            a.v_ld = c->v_transposed ? (int)c->seq_alloc : 0;
             FL_TRY(launch_gemv(L, dt, a));
             AttnScratch as{cs.part_m, cs.part_l, cs.part_o, cs.counters, c->nsplit, len_hint + 1};
-            // weights are laid out wo | wgu back to back per layer (one allocation), so one range covers
-            // o_proj and the head of gate/up
-            static const int64_t pf_mb = env_int("FL_PREFETCH_MB", 0);   // measured: no gain on MI355X (profiles/r01/NOTES.md)
-            if (pf_mb > 0 && ly.wgu == (char *)ly.wo + (size_t)D.h * sh.Hs * D.d * m->esize()) {
-                as.pf_ptr = ly.wo;
-                as.pf_bytes = std::min<int64_t>(pf_mb << 20, (int64_t)((size_t)D.h * sh.Hs * D.d + (size_t)2 * sh.Ip * D.h) * (int64_t)m->esize());
-            }
-            FL_TRY(launch_attn_decode(L, dt, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->max_seq, D.scale));
+            if (c->v_transposed) FL_TRY(launch_attn_decode_mfma(L, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->seq_alloc, D.scale));
+            else FL_TRY(launch_attn_decode(L, dt, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->seq_alloc, D.scale));
             FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, 1, D.h, sh.Hs * D.d, EPI_F32));
         }
         FL_TRY(all_reduce_delta(m, false, D.h));
@@ -591,16 +590,20 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             FL_HIP(hipSetDevice(sh.device));
             Launcher L = make_launcher(m, sh);
             const int64_t nq = (sh.Hs + 2 * sh.Hkvs) * D.d;
-            const size_t kv_layer = (size_t)l * sh.Hkvs * c->max_seq * D.d * m->esize();
+            const size_t kv_layer = (size_t)l * sh.Hkvs * c->seq_alloc * D.d * m->esize();
             void *kc = (char *)cs.k + kv_layer, *vc = (char *)cs.v + kv_layer;
             FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, l == 0 ? nullptr : sc.delta, ly.ln1, D.eps, sc.xn, sc.inv_rms, T, D.h));
             FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, ly.bqkv, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms));
-            FL_TRY(launch_rope_kv(L, dt, sc.qkv, cs.st, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, kc, vc, T, sh.Hs, sh.Hkvs, D.d, (int64_t)c->max_seq));
+            const int64_t sa = (int64_t)c->seq_alloc;
+            FL_TRY(launch_rope_kv(L, dt, sc.qkv, cs.st, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, kc, vc, T, sh.Hs, sh.Hkvs, D.d, sa, c->v_transposed));
             if (T == 1) {
                 AttnScratch as{cs.part_m, cs.part_l, cs.part_o, cs.counters, c->nsplit, len_hint + 1};
-                FL_TRY(launch_attn_decode(L, dt, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->max_seq, D.scale));
+                if (c->v_transposed) FL_TRY(launch_attn_decode_mfma(L, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, sa, D.scale));
+                else FL_TRY(launch_attn_decode(L, dt, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, sa, D.scale));
+            } else if (c->v_transposed) {
+                FL_TRY(launch_attn_prefill_mfma(L, sc.q, kc, vc, cs.st, sc.ao, T, sh.Hs, sh.Hkvs, D.d, sa, D.scale, D.window));
             } else {
-                FL_TRY(launch_attn_prefill(L, dt, sc.q, kc, vc, cs.st, sc.ao, T, sh.Hs, sh.Hkvs, D.d, (int64_t)c->max_seq, D.scale, D.window));
+                FL_TRY(launch_attn_prefill(L, dt, sc.q, kc, vc, cs.st, sc.ao, T, sh.Hs, sh.Hkvs, D.d, sa, D.scale, D.window));
             }
             FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, T, D.h, sh.Hs * D.d, EPI_F32));
         }
