@@ -93,14 +93,13 @@ __device__ inline void attn_tile(MfmaAttnState<D> &s, const bf16x8 (&qf)[D / 32]
 }
 
 // ------------------------------------------------------------------------------- decode
-template <int D, int GMAX>
-__global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
+template <int D, int GMAX, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
                                                                const bf16_t *__restrict__ vT, const StepState *__restrict__ st,
                                                                float *__restrict__ part_m, float *__restrict__ part_l,
                                                                float *__restrict__ part_o, unsigned *__restrict__ counters,
                                                                bf16_t *__restrict__ out, int H, int Hkv, int seq_alloc,
                                                                float scale, int nsplit) {
-    constexpr int NW = 4;
     __shared__ float lds[NW * GMAX * (D + 2)];
     __shared__ int is_last;
     const int hk = blockIdx.x, split = blockIdx.y;
@@ -149,13 +148,13 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const bf16_t *__r
     decode_tail<bf16_t, D, GMAX, NW>(lds, &is_last, G, hq0, hk, split, nsplit, part_m, part_l, part_o, counters, out);
 }
 
-template <int D, int GMAX>
+template <int D, int GMAX, int NW>
 static int launch_decode_mfma_t(Launcher &L, const void *q, const void *kc, const void *vT, const StepState *st, void *out,
                                 const AttnScratch &sc, int64_t H, int64_t Hkv, int64_t seq_alloc, float scale) {
     dim3 grid((unsigned)Hkv, (unsigned)sc.nsplit, 1);
     double kvbytes = 2.0 * (double)sc.kv_len_hint * Hkv * D * 2;
-    return L.launch(KC_ATTN_DECODE, kvbytes, 4.0 * (double)sc.kv_len_hint * H * D, attn_decode_mfma_kernel<D, GMAX>, grid,
-                    dim3(256), 0, (const bf16_t *)q, (const bf16_t *)kc, (const bf16_t *)vT, st, sc.part_m, sc.part_l,
+    return L.launch(KC_ATTN_DECODE, kvbytes, 4.0 * (double)sc.kv_len_hint * H * D, attn_decode_mfma_kernel<D, GMAX, NW>, grid,
+                    dim3(NW * 64), 0, (const bf16_t *)q, (const bf16_t *)kc, (const bf16_t *)vT, st, sc.part_m, sc.part_l,
                     sc.part_o, sc.counters, (bf16_t *)out, (int)H, (int)Hkv, (int)seq_alloc, scale, sc.nsplit);
 }
 
@@ -168,10 +167,15 @@ int launch_attn_decode_mfma(Launcher &L, const void *q, const void *k_cache, con
                             float scale) {
     const int G = (int)(H / Hkv);
     if (sc.nsplit > 64) FL_FAIL(FL_ERR_BAD_ARGUMENT, "attention: at most 64 splits");
+    // nsplit == 1: one wide workgroup per kv head (no cross-workgroup combine); else 4-wave workgroups
+    const bool wide = sc.nsplit == 1;
 #define FL_GO(DD)                                                                                                   \
-    if (G <= 4) return launch_decode_mfma_t<DD, 4>(L, q, k_cache, v_cache_T, st, out, sc, H, Hkv, seq_alloc, scale);  \
-    if (G <= 8) return launch_decode_mfma_t<DD, 8>(L, q, k_cache, v_cache_T, st, out, sc, H, Hkv, seq_alloc, scale);  \
-    return launch_decode_mfma_t<DD, 16>(L, q, k_cache, v_cache_T, st, out, sc, H, Hkv, seq_alloc, scale);
+    if (G <= 4) return wide ? launch_decode_mfma_t<DD, 4, 16>(L, q, k_cache, v_cache_T, st, out, sc, H, Hkv, seq_alloc, scale)  \
+                            : launch_decode_mfma_t<DD, 4, 4>(L, q, k_cache, v_cache_T, st, out, sc, H, Hkv, seq_alloc, scale);  \
+    if (G <= 8) return wide ? launch_decode_mfma_t<DD, 8, 16>(L, q, k_cache, v_cache_T, st, out, sc, H, Hkv, seq_alloc, scale)  \
+                            : launch_decode_mfma_t<DD, 8, 4>(L, q, k_cache, v_cache_T, st, out, sc, H, Hkv, seq_alloc, scale);  \
+    return wide ? launch_decode_mfma_t<DD, 16, 8>(L, q, k_cache, v_cache_T, st, out, sc, H, Hkv, seq_alloc, scale)              \
+                : launch_decode_mfma_t<DD, 16, 4>(L, q, k_cache, v_cache_T, st, out, sc, H, Hkv, seq_alloc, scale);
     if (d == 128) { FL_GO(128) }
     if (d == 64) { FL_GO(64) }
 #undef FL_GO

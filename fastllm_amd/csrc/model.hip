@@ -430,8 +430,11 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
     c->v_transposed = env_int("FL_ATTN_MFMA", 1) != 0 && attn_mfma_supported(m->dtype, m->shards[0].Hs, m->shards[0].Hkvs, D.d);
     // decode attention splits S so that the K/V stream of one kv head is spread over many CUs
     // (~64 cached positions per 4-wave workgroup at full length); partials are combined in-launch
-    // MFMA kernel: 128 keys (four 32-key wave steps) per workgroup; VALU kernel: 64
+    // MFMA kernel: 128 keys (four 32-key wave steps) per workgroup; VALU kernel: 64.  One CU pulls only
+    // ~25-50 GB/s from HBM, so a kv head's K/V stream must be spread over many CUs -- except when it is
+    // small (<= 96 KB per head): then one wide workgroup per head with no cross-workgroup combine wins.
     int64_t ns = (int64_t)((max_seq + (c->v_transposed ? 127 : 63)) / (c->v_transposed ? 128 : 64));
+    if (c->v_transposed && max_seq * (size_t)D.d * 4 <= 96 * 1024) ns = 1;
     c->nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(ns, 64));
     c->nsplit = env_int("FL_ATTN_NSPLIT", c->nsplit);
     c->shards.resize(m->shards.size());
