@@ -181,6 +181,13 @@ def main():
     model.synchronize(); barrier()
     t_prefill = time.perf_counter() - t0
 
+    # ---- per-kernel breakdown of the same prefill (eager, HIP-event pair per launch) ----
+    cache.reset()
+    model.profile_begin()
+    model.forward_argmax(cache, prompt, 0)
+    pstats = model.profile_end()
+    barrier()
+
     # ---- timed region: exactly K decode steps ----
     barrier(); model.synchronize(); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -228,7 +235,10 @@ def main():
             "e2e_hbm": {"bytes_per_token": b_tok, "achieved_GBps": round(tok_s * b_tok / world / 1e9, 1),
                         "frac_of_8TBps_per_gpu": round(tok_s * b_tok / world / 8e12, 4)},
             "prefill": {"tokens": T, "tokens_per_sec": round(T / t_prefill, 1), "ms": round(t_prefill * 1e3, 2),
-                        "mfma_frac_of_2.5PF": round(prefill_flops(cfg, T) / t_prefill / world / 2.5e15, 4)},
+                        "mfma_frac_of_2.5PF": round(prefill_flops(cfg, T) / t_prefill / world / 2.5e15, 4),
+                        "kernels": [{"name": s["name"], "launches": s["launches"], "ms": round(s["total_ms"], 3),
+                                     "TFLOPs": round(s["flops"] / s["total_ms"] / 1e9, 1) if s["total_ms"] and s["flops"] else None}
+                                    for s in pstats]},
             "kernels": [{"name": s["name"], "launches_per_step": s["launches"] / n_prof,
                          "us_per_step": round(s["total_ms"] * 1e3 / n_prof, 2),
                          "us_per_launch": round(s["total_ms"] * 1e3 / s["launches"], 2),

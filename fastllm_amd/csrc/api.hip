@@ -183,7 +183,9 @@ int fl_op_linear(const void *x, const void *w, const float *bias, int64_t T, int
     FL_HIP(hipMalloc(&B.x, (size_t)T * K * es));
     FL_HIP(hipMalloc(&B.w, (size_t)Nw * K * es));
     const size_t ybytes = (size_t)T * Ny * (epilogue == EPI_GATEUP ? es : 4);
-    FL_HIP(hipMalloc(&B.y, ybytes));
+    const int max_split = (epilogue == EPI_F32 && !bias) ? 4 : 1;      // exercise split-K where the model would
+    int nsplit = 1;
+    FL_HIP(hipMalloc(&B.y, ybytes * max_split));
     FL_HIP(hipMemcpy(B.x, x, (size_t)T * K * es, hipMemcpyHostToDevice));
     Launcher L; L.stream = B.s;
     if (epilogue == EPI_GATEUP) {
@@ -199,12 +201,12 @@ int fl_op_linear(const void *x, const void *w, const float *bias, int64_t T, int
             FL_HIP(hipMemcpy(B.b, bias, (size_t)N * 4, hipMemcpyHostToDevice));
         }
     }
-    FL_TRY(launch_linear(L, dtype, B.w, B.x, B.b, B.y, T, Nw, K, epilogue));
+    FL_TRY(launch_linear(L, dtype, B.w, B.x, B.b, B.y, T, Nw, K, epilogue, nullptr, max_split, &nsplit));
     FL_HIP(hipStreamSynchronize(B.s));
     if (iters > 0 && ms_out) {
         FL_HIP(hipEventCreate(&B.e0)); FL_HIP(hipEventCreate(&B.e1));
         FL_HIP(hipEventRecord(B.e0, B.s));
-        for (int i = 0; i < iters; i++) FL_TRY(launch_linear(L, dtype, B.w, B.x, B.b, B.y, T, Nw, K, epilogue));
+        for (int i = 0; i < iters; i++) FL_TRY(launch_linear(L, dtype, B.w, B.x, B.b, B.y, T, Nw, K, epilogue, nullptr, max_split, &nsplit));
         FL_HIP(hipEventRecord(B.e1, B.s));
         FL_HIP(hipEventSynchronize(B.e1));
         float ms = 0.f; FL_HIP(hipEventElapsedTime(&ms, B.e0, B.e1));
@@ -221,6 +223,13 @@ int fl_op_linear(const void *x, const void *w, const float *bias, int64_t T, int
             }
     } else {
         FL_HIP(hipMemcpy(y, B.y, ybytes, hipMemcpyDeviceToHost));
+        if (nsplit > 1) {                                   // sum the split-K slabs in slab order, like rmsnorm_add does
+            std::unique_ptr<float[]> tmp(new float[(size_t)T * Ny]);
+            for (int sl = 1; sl < nsplit; sl++) {
+                FL_HIP(hipMemcpy(tmp.get(), (char *)B.y + (size_t)sl * ybytes, ybytes, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < (size_t)T * Ny; i++) y[i] += tmp[i];
+            }
+        }
     }
     return FL_OK;
 }

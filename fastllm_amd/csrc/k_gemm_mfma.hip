@@ -12,6 +12,8 @@
 //
 // Epilogues: fp32 store (+bias) or SiLU-gate on the 16-interleaved gate/up layout (tile column
 // blocks alternate gate/up, so one lane holds gate[j] and up[j]).
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace fl {
@@ -48,7 +50,7 @@ __device__ inline bf16x8 read_frag(const unsigned char *lds_tile, int row, int c
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
                                                         const float *__restrict__ bias, void *__restrict__ out,
                                                         int T, int N, int K, int epi, int tiles_m, int tiles_n,
-                                                        const float *__restrict__ row_scale) {
+                                                        const float *__restrict__ row_scale, int ksplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2 buffers][X tile | W tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -66,7 +68,11 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const bf16_t *__restrict
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / BK;
+    // split-K: blockIdx.y owns K tiles [kt0, kt0 + nk) and writes its own fp32 slab (summed by the consumer)
+    const int nk_all = K / BK, kz = blockIdx.y;
+    const int kt0 = (int)((long long)nk_all * kz / ksplit), nk = (int)((long long)nk_all * (kz + 1) / ksplit) - kt0;
+    X += (size_t)kt0 * BK; W += (size_t)kt0 * BK;
+    if (ksplit > 1) out = reinterpret_cast<float *>(out) + (size_t)kz * T * N;
     stage_tile(X, T, K, m0, 0, lds, wave, lane);
     stage_tile(W, N, K, n0, 0, lds + TILE_BYTES, wave, lane);
     for (int kt = 0; kt < nk; kt++) {
@@ -130,9 +136,19 @@ bool gemm_mfma_supported(int dtype, int64_t T, int64_t N, int64_t K) {
     return dtype == FL_DTYPE_BF16 && T > 1 && K % BK == 0 && K >= BK && N >= 1;
 }
 
+// how many K splits the launcher will use for this shape when the caller allows up to max_split slabs
+int gemm_mfma_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
+    const int64_t tiles = ((T + BM - 1) / BM) * ((N + BN - 1) / BN);
+    if (epi != EPI_F32 || max_split <= 1 || tiles >= 256 || K < 2048) return 1;
+    int ks = (int)std::min<int64_t>(max_split, 512 / tiles);
+    while (ks > 1 && (K / BK) / ks < 8) ks--;
+    return ks < 1 ? 1 : ks;
+}
+
 int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bias, void *y,
-                     int64_t T, int64_t N, int64_t K, int epi, const float *row_scale) {
+                     int64_t T, int64_t N, int64_t K, int epi, const float *row_scale, int ksplit) {
     const int tiles_m = (int)((T + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
+    if (ksplit > 1 && bias) FL_FAIL(FL_ERR_BAD_ARGUMENT, "split-K GEMM cannot add a bias");
     const size_t lds = 4 * TILE_BYTES;     // 64 KiB
     static bool attr_set = false;
     if (!attr_set) {
@@ -141,9 +157,9 @@ int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bia
         attr_set = true;
     }
     double bytes = ((double)N * K + (double)T * K) * 2.0;
-    return L.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, gemm_mfma_kernel, dim3((unsigned)(tiles_m * tiles_n)),
+    return L.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, gemm_mfma_kernel, dim3((unsigned)(tiles_m * tiles_n), (unsigned)ksplit),
                     dim3(256), lds, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi,
-                    tiles_m, tiles_n, row_scale);
+                    tiles_m, tiles_n, row_scale, ksplit);
 }
 
 }  // namespace fl

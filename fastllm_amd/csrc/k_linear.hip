@@ -92,7 +92,8 @@ static int launch_gemm_generic(Launcher &L, const void *W, const void *x, const 
 }
 
 int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bias, void *y,
-                     int64_t T, int64_t N, int64_t K, int epi, const float *row_scale);   // k_gemm_mfma.hip
+                     int64_t T, int64_t N, int64_t K, int epi, const float *row_scale, int ksplit);   // k_gemm_mfma.hip
+int gemm_mfma_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split);
 
 static GemvArgs plain_args(const void *W, const void *x, const float *bias, void *y, int64_t N, int64_t K, int epi,
                            const float *scale) {
@@ -102,13 +103,18 @@ static GemvArgs plain_args(const void *W, const void *x, const float *bias, void
 }
 
 int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const float *bias, void *y,
-                  int64_t T, int64_t N, int64_t K, int epi, const float *row_scale) {
+                  int64_t T, int64_t N, int64_t K, int epi, const float *row_scale, int max_split, int *n_split_out) {
+    if (n_split_out) *n_split_out = 1;
     if (T <= 0 || N <= 0 || K <= 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "launch_linear: bad shape");
     if (epi == EPI_GATEUP && N % 32) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gate/up matrix rows must be a multiple of 32");
     static const int force_generic = env_int("FL_FORCE_GENERIC_GEMM", 0);
     if (dtype == FL_DTYPE_BF16) {
         if (T == 1 && gemv_supported(dtype, N, K)) return launch_gemv(L, dtype, plain_args(W, x, bias, y, N, K, epi, row_scale));
-        if (!force_generic && gemm_mfma_supported(dtype, T, N, K)) return launch_gemm_mfma(L, W, x, bias, y, T, N, K, epi, row_scale);
+        if (!force_generic && gemm_mfma_supported(dtype, T, N, K)) {
+            const int ks = (n_split_out && !bias) ? gemm_mfma_ksplit(T, N, K, epi, max_split) : 1;
+            if (n_split_out) *n_split_out = ks;
+            return launch_gemm_mfma(L, W, x, bias, y, T, N, K, epi, row_scale, ks);
+        }
         return launch_gemm_generic<bf16_t, bf16_t>(L, W, x, bias, y, T, N, K, epi, row_scale);
     }
     if (dtype == FL_DTYPE_F32) {

@@ -44,7 +44,8 @@ int launch_embed(Launcher &L, int dtype, const void *E, const uint32_t *ids, con
 template <typename OT>
 __global__ __launch_bounds__(256) void rmsnorm_add_kernel(float *__restrict__ x_res, const float *__restrict__ delta,
                                                           const float *__restrict__ w, float eps,
-                                                          OT *__restrict__ xs, float *__restrict__ inv_rms, int h) {
+                                                          OT *__restrict__ xs, float *__restrict__ inv_rms, int h,
+                                                          int n_slab, long long slab_stride) {
     __shared__ float red[4];
     const int t = blockIdx.x, tid = threadIdx.x;
     float *xr = x_res + (size_t)t * h;
@@ -55,10 +56,12 @@ __global__ __launch_bounds__(256) void rmsnorm_add_kernel(float *__restrict__ x_
         load8(xr + c * 8, v);
         load8(w + c * 8, wv);
         if (dr) {
-            float d[8];
-            load8(dr + c * 8, d);
+            for (int sl = 0; sl < n_slab; sl++) {            // split-K slabs, fixed order
+                float d[8];
+                load8(dr + (size_t)sl * slab_stride + c * 8, d);
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[j] += d[j];
+                for (int j = 0; j < 8; j++) v[j] += d[j];
+            }
             store8(xr + c * 8, v);
         }
 #pragma unroll
@@ -72,13 +75,13 @@ __global__ __launch_bounds__(256) void rmsnorm_add_kernel(float *__restrict__ x_
 }
 
 int launch_rmsnorm_add(Launcher &L, int dtype, float *x_res, const float *delta, const float *w, float eps,
-                       void *xs, float *inv_rms, int64_t T, int64_t h) {
-    double bytes = (double)T * h * (4.0 * (delta ? 3 : 1) + (dtype == FL_DTYPE_BF16 ? 2 : 4));
+                       void *xs, float *inv_rms, int64_t T, int64_t h, int n_slab, int64_t slab_stride) {
+    double bytes = (double)T * h * (4.0 * (delta ? 2 + n_slab : 1) + (dtype == FL_DTYPE_BF16 ? 2 : 4));
     if (dtype == FL_DTYPE_BF16)
         return L.launch(KC_RMSNORM, bytes, 0, rmsnorm_add_kernel<bf16_t>, dim3((unsigned)T), dim3(256), 0,
-                        x_res, delta, w, eps, (bf16_t *)xs, inv_rms, (int)h);
+                        x_res, delta, w, eps, (bf16_t *)xs, inv_rms, (int)h, n_slab, (long long)slab_stride);
     return L.launch(KC_RMSNORM, bytes, 0, rmsnorm_add_kernel<float>, dim3((unsigned)T), dim3(256), 0,
-                    x_res, delta, w, eps, (float *)xs, inv_rms, (int)h);
+                    x_res, delta, w, eps, (float *)xs, inv_rms, (int)h, n_slab, (long long)slab_stride);
 }
 
 // ------------------------------------------------------------------------------- RoPE + KV append

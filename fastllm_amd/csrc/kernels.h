@@ -76,8 +76,11 @@ __host__ __device__ inline int64_t gateup_row(int64_t q, int is_up) { return (q 
 // dtype FL_DTYPE_BF16: W and x (and gate-up y) bf16; FL_DTYPE_F32: all fp32.
 // row_scale (optional, fp32 [T]): y[t,:] = row_scale[t] * (x[t,:] . W^T) (+bias) -- the 1/rms factor of
 // a preceding RMSNorm, applied after the dot product (see launch_rmsnorm_add).
+// max_split > 1 allows split-K: y then holds *n_split_out fp32 slabs of [T,N] that the consumer sums
+// (launch_rmsnorm_add does); *n_split_out is always written when the pointer is given.
 int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const float *bias, void *y,
-                  int64_t T, int64_t N, int64_t K, int epi, const float *row_scale = nullptr);
+                  int64_t T, int64_t N, int64_t K, int epi, const float *row_scale = nullptr,
+                  int max_split = 1, int *n_split_out = nullptr);
 // cheap capability probes used by tests / DESIGN numbers
 bool gemv_supported(int dtype, int64_t N, int64_t K);
 bool gemm_mfma_supported(int dtype, int64_t T, int64_t N, int64_t K);
@@ -89,8 +92,10 @@ int launch_embed(Launcher &L, int dtype, const void *E, const uint32_t *ids, con
 // x_res += delta (if delta); xs = x_res * w (compute dtype); inv_rms[t] = 1/sqrt(mean(x_res^2)+eps).
 // RMSNorm(x) * w == inv_rms * xs: the scalar is applied by the consuming projection's epilogue, so
 // the bf16 rounding point (xs) is the same in the prefill and the fused decode path.
+// delta may be n_slab split-K slabs, slab s at delta + s * slab_stride floats.
 int launch_rmsnorm_add(Launcher &L, int dtype, float *x_res, const float *delta, const float *w,
-                       float eps, void *xs, float *inv_rms, int64_t T, int64_t h);
+                       float eps, void *xs, float *inv_rms, int64_t T, int64_t h, int n_slab = 1,
+                       int64_t slab_stride = 0);
 // RoPE(q,k) + KV append.  qkv fp32 [T, (H+2Hkv)*d]; q_out XT [T,H*d]; caches XT [Hkv][max_seq][d]
 // v_transposed: value cache laid out [Hkv][d][max_seq] instead of [Hkv][max_seq][d]
 int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st, const float *cos_tab,

@@ -293,6 +293,8 @@ static int build_rope(Model *m) {
     return FL_OK;
 }
 
+constexpr int kMaxKSplit = 4;
+
 static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T) {
     const Dims &D = m->D;
     const size_t es = m->esize();
@@ -301,7 +303,7 @@ static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T) {
     sc.cap_T = T;
     FL_TRY(dev_alloc(sh.allocs, (void **)&sc.x_res, (size_t)T * D.h * 4, &m->hbm_bytes));
     if (T == 1) FL_TRY(dev_alloc(sh.allocs, (void **)&sc.x_res2, (size_t)D.h * 4, &m->hbm_bytes));
-    FL_TRY(dev_alloc(sh.allocs, (void **)&sc.delta, (size_t)T * D.h * 4, &m->hbm_bytes));
+    FL_TRY(dev_alloc(sh.allocs, (void **)&sc.delta, (size_t)T * D.h * 4 * (T > 1 ? kMaxKSplit : 1), &m->hbm_bytes));   // split-K slabs
     FL_TRY(dev_alloc(sh.allocs, &sc.xn, (size_t)T * D.h * es, &m->hbm_bytes));
     FL_TRY(dev_alloc(sh.allocs, (void **)&sc.inv_rms, (size_t)T * 4, &m->hbm_bytes));
     FL_TRY(dev_alloc(sh.allocs, (void **)&sc.qkv, (size_t)T * nq * 4, &m->hbm_bytes));
@@ -587,6 +589,11 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
         Launcher L = make_launcher(m, sh);
         FL_TRY(launch_embed(L, dt, sh.embed, ids_in_scratch ? sc.ids : nullptr, c->shards[i].st, sc.x_res, T, D.h));
     }
+    // split-K of the row-parallel GEMMs (o_proj, down_proj) only without tensor parallelism: the
+    // all-reduce wants one summed buffer
+    const int max_split = (m->tp == 1 && T > 1) ? kMaxKSplit : 1;
+    const int64_t slab = T * D.h;
+    int nslab = 1;                        // slabs the current delta consists of (same on every shard)
     for (int64_t l = 0; l < D.L; l++) {
         for (size_t i = 0; i < ns; i++) {
             Shard &sh = m->shards[i]; Scratch &sc = SC(sh); CacheShard &cs = c->shards[i]; LayerW &ly = sh.layers[l];
@@ -595,7 +602,7 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             const int64_t nq = (sh.Hs + 2 * sh.Hkvs) * D.d;
             const size_t kv_layer = (size_t)l * sh.Hkvs * c->seq_alloc * D.d * m->esize();
             void *kc = (char *)cs.k + kv_layer, *vc = (char *)cs.v + kv_layer;
-            FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, l == 0 ? nullptr : sc.delta, ly.ln1, D.eps, sc.xn, sc.inv_rms, T, D.h));
+            FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, l == 0 ? nullptr : sc.delta, ly.ln1, D.eps, sc.xn, sc.inv_rms, T, D.h, nslab, slab));
             FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, ly.bqkv, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms));
             const int64_t sa = (int64_t)c->seq_alloc;
             FL_TRY(launch_rope_kv(L, dt, sc.qkv, cs.st, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, kc, vc, T, sh.Hs, sh.Hkvs, D.d, sa, c->v_transposed));
@@ -608,16 +615,16 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             } else {
                 FL_TRY(launch_attn_prefill(L, dt, sc.q, kc, vc, cs.st, sc.ao, T, sh.Hs, sh.Hkvs, D.d, sa, D.scale, D.window));
             }
-            FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, T, D.h, sh.Hs * D.d, EPI_F32));
+            FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, T, D.h, sh.Hs * D.d, EPI_F32, nullptr, max_split, &nslab));
         }
         FL_TRY(all_reduce_delta(m, pre, T * D.h));
         for (size_t i = 0; i < ns; i++) {
             Shard &sh = m->shards[i]; Scratch &sc = SC(sh); LayerW &ly = sh.layers[l];
             FL_HIP(hipSetDevice(sh.device));
             Launcher L = make_launcher(m, sh);
-            FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, sc.delta, ly.ln2, D.eps, sc.xn, sc.inv_rms, T, D.h));
+            FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, sc.delta, ly.ln2, D.eps, sc.xn, sc.inv_rms, T, D.h, nslab, slab));
             FL_TRY(launch_linear(L, dt, ly.wgu, sc.xn, nullptr, sc.act, T, 2 * sh.Ip, D.h, EPI_GATEUP, sc.inv_rms));
-            FL_TRY(launch_linear(L, dt, ly.wd, sc.act, nullptr, sc.delta, T, D.h, sh.Ip, EPI_F32));
+            FL_TRY(launch_linear(L, dt, ly.wd, sc.act, nullptr, sc.delta, T, D.h, sh.Ip, EPI_F32, nullptr, max_split, &nslab));
         }
         FL_TRY(all_reduce_delta(m, pre, T * D.h));
     }
@@ -628,7 +635,7 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
         Launcher L = make_launcher(m, sh);
         float *xl = sc.x_res + (size_t)(T - 1) * D.h, *dl = sc.delta + (size_t)(T - 1) * D.h;
         void *xnl = (char *)sc.xn + (size_t)(T - 1) * D.h * m->esize();
-        FL_TRY(launch_rmsnorm_add(L, dt, xl, dl, sh.norm, D.eps, xnl, sc.inv_rms + (T - 1), 1, D.h));
+        FL_TRY(launch_rmsnorm_add(L, dt, xl, dl, sh.norm, D.eps, xnl, sc.inv_rms + (T - 1), 1, D.h, nslab, slab));
         FL_TRY(launch_linear(L, dt, sh.lm_head, xnl, nullptr, sh.logits_local, 1, sh.Vs, D.h, EPI_F32, sc.inv_rms + (T - 1)));
     }
     FL_TRY(gather_logits(m));

@@ -31,7 +31,7 @@ def _ref(x, w, bias, epi):
 
 # (T, N, K): GEMV (T=1), MFMA (T>1, K%64==0), generic (K%64!=0), ragged M/N tails, big K
 SHAPES = [(1, 512, 256), (1, 6144, 4096), (1, 300, 384), (1, 4096, 14336), (1, 2, 8), (1, 33, 1032),
-          (5, 512, 256), (128, 256, 512), (130, 384, 448), (257, 1000, 1024), (7, 96, 40), (512, 512, 4096),
+          (5, 512, 256), (128, 256, 512), (130, 384, 448), (257, 1000, 1024), (7, 96, 40), (512, 512, 4096), (300, 1024, 2048), (512, 4096, 4096), (129, 2048, 5632),
           (64, 136, 72)]
 
 
