@@ -107,6 +107,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: native libraries (RCCL prints a banner at communicator
+    # creation) are pointed at stderr for the duration of the run
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -246,7 +251,8 @@ def main():
                          "share": round(s["total_ms"] / total_prof_ms, 4) if total_prof_ms else None} for s in stats],
             "hbm_allocated_gb": round(info.hbm_bytes_allocated / 1e9, 2),
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

@@ -673,7 +673,11 @@ static int sync_all(Model *m) {
 // TinyLlama scale); captured lazily on the second step of a cache so that all lazy module /
 // attribute initialisation has already happened eagerly.
 static int decode_step(Model *m, Cache *c, int64_t len_hint) {
-    const bool graphable = m->use_graph && !m->profiling && m->shards.size() == 1 && m->tp == 1 && !c->graph_failed;
+    // one shard per process: plain single-GPU, or one rank of a multi-process TP group (RCCL collectives
+    // are stream-ordered and capturable; every rank captures the same sequence)
+    static const int tp_graph = env_int("FL_TP_GRAPH", 1);
+    const bool one_shard = m->shards.size() == 1 && (m->tp == 1 || (m->tp_mode == FL_TP_MULTI_PROCESS && tp_graph));
+    const bool graphable = m->use_graph && !m->profiling && one_shard && !c->graph_failed;
     if (graphable && c->shards[0].graph) {
         FL_HIP(hipSetDevice(m->shards[0].device));
         FL_HIP(hipGraphLaunch(c->shards[0].graph, m->shards[0].stream));
