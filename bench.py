@@ -223,9 +223,16 @@ def main():
         if gemv and gemv["launches"]:
             avg_ms = gemv["total_ms"] / gemv["launches"]
             ach = gemv["bytes"] / gemv["launches"] / (avg_ms * 1e-3) / 1e9
+            # HBM bytes per launch from the PMC passes committed with the profiles (tools/pmc_traffic.py);
+            # only comparable when the workload is the one they were collected on
+            traffic, tsrc = None, None
+            tf = os.path.join(ROOT, "profiles", "r01", "traffic_gemv.json")
+            if os.path.exists(tf) and args.model == "mistral-7b" and world == 1:
+                tj = json.load(open(tf))
+                traffic, tsrc = round(tj["hbm_bytes_per_launch"]), "profiles/r01/traffic_gemv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
             roof = {"bound": "hbm", "kernel": "gemv_kernel<bf16> (QKV/O/gate-up/down/lm_head weight stream)",
                     "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                    "traffic": None, "launches_per_step": gemv["launches"] // n_prof,
+                    "traffic": traffic, "traffic_source": tsrc, "launches_per_step": gemv["launches"] // n_prof,
                     "bytes_per_launch": round(gemv["bytes"] / gemv["launches"]), "avg_launch_us": round(avg_ms * 1e3, 2)}
         total_prof_ms = sum(s["total_ms"] for s in stats)
         out = {
