@@ -8,9 +8,17 @@ import pytest
 
 import synth
 from oracle import oracle
-from test_gpu_parity import check_logits
 
 pytestmark = pytest.mark.gpu
+
+
+def close_bf16(a, b, what):
+    """Two bf16 evaluations of a 22-layer model along different code paths (GEMM vs GEMV order, P rounded
+    for the MFMA product, split sums): each carries ~1 % relative L2 rounding noise against the fp32
+    result (measured in test_fullsize_vs_oracle), so they differ from each other by up to ~2 %."""
+    n = np.linalg.norm(b)
+    assert np.linalg.norm(a - b) <= 3e-2 * n, "%s: rel L2 %.4f" % (what, np.linalg.norm(a - b) / n)
+    assert np.abs(a - b).max() <= 6e-2 * max(1.0, np.abs(b).max()), "%s: max diff %g" % (what, np.abs(a - b).max())
 
 
 def pooled_weights(cfg, seed=7):
@@ -42,14 +50,26 @@ def tiny():
 
 
 def test_fullsize_vs_oracle(tiny):
+    """fp32 HIP path within 1e-3 of the fp32 oracle at full depth; the bf16 HIP path is as close to the
+    fp32 oracle as a bf16 evaluation with the same rounding points (the oracle's emulation) is."""
     fa, cfg, w = tiny
-    gm = fa.Model(cfg, w, dtype="bf16")
-    om = oracle.OracleModel(cfg, w, round_bf16=True)          # bf16 weights kept as bf16 (exact)
+    g32, g16 = fa.Model(cfg, w, dtype="f32"), fa.Model(cfg, w, dtype="bf16")
+    o32, oemu = oracle.OracleModel(cfg, w), oracle.OracleModel(cfg, w, round_bf16=True)   # bf16 weights kept exact
     ids = synth.prompt_ids(cfg, 20, seed=2)
-    gc, oc = gm.new_cache(64), om.new_cache(64)
-    check_logits(gm.forward(gc, ids[:16], 0), om.forward(oc, ids[:16], 0), "bf16", "full-size prefill")
+    caches = [m.new_cache(64) for m in (g32, g16, o32, oemu)]
+
+    def step(chunk, pos, what):
+        a32, a16, r32, remu = [m.forward(c, chunk, pos) for m, c in zip((g32, g16, o32, oemu), caches)]
+        np.testing.assert_allclose(a32, r32, atol=1e-3, rtol=0, err_msg="fp32 " + what)
+        n = np.linalg.norm(r32)
+        e_gpu, e_emu = np.linalg.norm(a16 - r32) / n, np.linalg.norm(remu - r32) / n
+        assert e_gpu <= 1.5 * e_emu + 2e-3, "%s: bf16 HIP error %.4f vs bf16-emulation error %.4f" % (what, e_gpu, e_emu)
+        assert oracle.argmax(a32) == oracle.argmax(r32)
+        return e_gpu, e_emu
+
+    step(ids[:16], 0, "full-size prefill")
     for i in range(16, 20):
-        check_logits(gm.forward(gc, ids[i:i + 1], i), om.forward(oc, ids[i:i + 1], i), "bf16", "full-size decode %d" % i)
+        step(ids[i:i + 1], i, "full-size decode %d" % i)
 
 
 def test_fullsize_kv_cache_equivalence_and_determinism(tiny):
@@ -62,7 +82,16 @@ def test_fullsize_kv_cache_equivalence_and_determinism(tiny):
     first = None
     for i in range(96, 128):
         part = gm.forward(c2, ids[i:i + 1], i)
-    check_logits(part, full, "bf16", "prefill(128) vs prefill(96)+32 decodes")
+    close_bf16(part, full, "prefill(128) vs prefill(96)+32 decodes")
+    # the same property in fp32 holds to 1e-3
+    g32 = fa.Model(cfg, w, dtype="f32")
+    d1, d2 = g32.new_cache(160), g32.new_cache(160)
+    f_full = g32.forward(d1, ids, 0)
+    g32.forward(d2, ids[:120], 0)
+    for i in range(120, 128):
+        f_part = g32.forward(d2, ids[i:i + 1], i)
+    np.testing.assert_allclose(f_part, f_full, atol=1e-3, rtol=0)
+    g32.close()
     # greedy continuation twice from the same state: bit-identical ids (no atomics, fixed summation order)
     tok = int(np.argmax(full))
     a = gm.decode_greedy(c1, tok, 128, 48)
@@ -86,9 +115,9 @@ def test_fullsize_variant_paths_agree(tiny, env, monkeypatch):
         monkeypatch.setenv(k, v)
     alt = fa.Model(cfg, w, dtype="bf16")
     ac = alt.new_cache(128)
-    check_logits(alt.forward(ac, ids[:32], 0), r0, "bf16", "prefill %s" % env)
+    close_bf16(alt.forward(ac, ids[:32], 0), r0, "prefill %s" % env)
     for i, want in zip(range(32, 40), r1):
-        check_logits(alt.forward(ac, ids[i:i + 1], i), want, "bf16", "decode %d %s" % (i, env))
+        close_bf16(alt.forward(ac, ids[i:i + 1], i), want, "decode %d %s" % (i, env))
 
 
 def test_fullsize_tp_emulated(tiny):
@@ -102,7 +131,7 @@ def test_fullsize_tp_emulated(tiny):
     for tp in (2, 4):                               # Hkv = 4: TP <= 4 for TinyLlama
         gN = fa.Model(cfg, w, dtype="bf16", tp_mode=binding.TP_EMULATED, tp_size=tp)
         cN = gN.new_cache(64)
-        check_logits(gN.forward(cN, ids[:32], 0), a0, "bf16", "tp%d prefill" % tp)
+        close_bf16(gN.forward(cN, ids[:32], 0), a0, "tp%d prefill" % tp)
         for i, want in zip(range(32, 36), a1):
-            check_logits(gN.forward(cN, ids[i:i + 1], i), want, "bf16", "tp%d decode" % tp)
+            close_bf16(gN.forward(cN, ids[i:i + 1], i), want, "tp%d decode" % tp)
         gN.close()
