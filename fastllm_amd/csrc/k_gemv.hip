@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -51,7 +52,10 @@ __device__ inline void unpack_raw(const RawChunk<float> &r, float (&o)[8]) {
 }
 
 // MAXT = 768: up to 12 waves per workgroup (170 VGPRs per lane).
-template <typename WT, typename XT, int R, int U, int PRO, int MAXT>
+// SMALL: every wave owns at most ONE row group and K <= 2 blocks of U chunks (host-checked): the whole
+// weight share of the wave (2*U*R KiB) is requested before x is staged -- one HBM round trip instead of
+// two for the short QKV / o_proj launches, where ramp-up is most of the kernel.
+template <typename WT, typename XT, int R, int U, int PRO, int MAXT, bool SMALL>
 __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float red[kGemvMaxThreads / 64];
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
     typedef RawChunk<WT> Buf[R][U];
     // first K block of this wave's first row group: requested before x is staged, so HBM is busy
     // during the prologue
-    constexpr int NPRE = 1;                          // K blocks requested ahead of the prologue (2 spills: measured slower)
+    constexpr int NPRE = SMALL ? 2 : 1;              // K blocks requested ahead of the prologue
     Buf pre[NPRE];
     bool have_pre[NPRE];
 #pragma unroll
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
     };
     float inv_m = 1.0f;
     if constexpr (PRO == PRO_NORM) {
-        constexpr int NCH = 3;                       // nthr * NCH * 8 >= K (host-checked)
+        constexpr int NCH = SMALL ? 1 : 3;           // nthr * NCH * 8 >= K (host-checked)
         float v[NCH][8], wn[NCH][8];
         const WT *erow = nullptr;
         if (a.embed) erow = reinterpret_cast<const WT *>(a.embed) + (size_t)a.st->token * K;
@@ -236,6 +240,15 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
         }
     };
 
+    if constexpr (SMALL) {
+        if (gw < ngroups) {
+#pragma unroll
+            for (int i = 0; i < NPRE; i++)
+                if (have_pre[i]) fma_block(pre[i], lane + 64 * U * i);
+            finish_group(gw);
+        }
+        return;
+    }
 #pragma nounroll
     for (int g = gw; g < ngroups; g += nw) {
         const WT *wp[R];
@@ -258,6 +271,39 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
                 for (int r = 0; r < R; r++) load_raw_nt(wp[r] + (size_t)(c0 + 64 * u) * 8, w[r][u]);
             fma_block(w, c0);
+        }
+        // K tail: the remaining 1..U-1 whole 64-lane chunks as ONE straight-line block (K = 3584, 5632,
+        // 18944 ... all leave such a remainder), then a generic loop for a ragged last chunk
+        {
+            const int remaining = nchunk - (c0 - lane);          // wave-uniform
+            const int full = remaining >> 6;
+            if (remaining > 0 && (remaining & 63) == 0 && full < U) {
+                auto tail_block = [&](auto TU) {
+                    constexpr int NT = decltype(TU)::value;
+                    RawChunk<WT> w[R][NT];
+#pragma unroll
+                    for (int u = 0; u < NT; u++)
+#pragma unroll
+                        for (int r = 0; r < R; r++) load_raw_nt(wp[r] + (size_t)(c0 + 64 * u) * 8, w[r][u]);
+#pragma unroll
+                    for (int u = 0; u < NT; u++) {
+                        float xv[8];
+                        load8(xs + (c0 + 64 * u) * 8, xv);
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            float wv[8];
+                            unpack_raw(w[r][u], wv);
+#pragma unroll
+                            for (int j = 0; j < 8; j++) acc[r] = fmaf(wv[j], xv[j], acc[r]);
+                        }
+                    }
+                    c0 += 64 * NT;
+                };
+                if (full == 1) tail_block(std::integral_constant<int, 1>{});
+                else if (full == 2) tail_block(std::integral_constant<int, 2>{});
+                else if (full == 3) tail_block(std::integral_constant<int, 3>{});
+                else if (U > 4 && full == 4) tail_block(std::integral_constant<int, 4>{});
+            }
         }
 #pragma nounroll
         for (; c0 < nchunk; c0 += 64) {                          // ragged tail of K
@@ -332,9 +378,9 @@ static void pick_geometry(int64_t ngroups, size_t lds_bytes, int *blocks_out, in
     *blocks_out = bb; *waves_out = bw;
 }
 
-template <typename WT, typename XT, int R, int U, int PRO, int MAXT>
+template <typename WT, typename XT, int R, int U, int PRO, int MAXT, bool SMALL>
 static int launch_gemv_k(Launcher &L, const GemvArgs &a, int blocks, int waves, size_t lds) {
-    auto kern = gemv_kernel<WT, XT, R, U, PRO, MAXT>;
+    auto kern = gemv_kernel<WT, XT, R, U, PRO, MAXT, SMALL>;
     if (lds > 64 * 1024) {
         static std::atomic<size_t> raised{0};      // per instantiation, process-wide
         if (raised.load() < lds) {
@@ -358,7 +404,11 @@ static int launch_gemv_t(Launcher &L, const GemvArgs &a) {
     pick_geometry(ngroups, lds, &blocks, &waves);
     if (PRO == PRO_NORM && (int64_t)waves * 64 * 3 * 8 < K) waves = (int)((K + 64 * 3 * 8 - 1) / (64 * 3 * 8));   // staging capacity
     if (waves < 4) waves = 4;
-    return launch_gemv_k<WT, XT, R, U, PRO, 768>(L, a, blocks, waves, lds);
+    static const int allow_small = env_int("FL_GEMV_SMALL", 1);
+    const bool small = allow_small && sizeof(WT) == 2 && ngroups <= (int64_t)blocks * waves && (K >> 3) % (64 * U) == 0 &&
+                       (K >> 3) <= 2 * 64 * U && (PRO != PRO_NORM || (int64_t)waves * 64 * 8 >= K);
+    if (small) return launch_gemv_k<WT, XT, R, U, PRO, 768, true>(L, a, blocks, waves, lds);
+    return launch_gemv_k<WT, XT, R, U, PRO, 768, false>(L, a, blocks, waves, lds);
 }
 
 template <typename WT, typename XT, int PRO>
