@@ -38,25 +38,50 @@ struct MfmaAttnState {
     }
 };
 
-// One 32-key step.  Column q sees key k iff  k < pre_hi  ||  (lo_q <= k && k < hi_q).
+// Operand sources of one 32-key step.  Global: straight from the caches (decode: every byte is used once).
 template <int D>
-__device__ inline void attn_tile(MfmaAttnState<D> &s, const bf16x8 (&qf)[D / 32], const bf16_t *__restrict__ kb,
-                                 const bf16_t *__restrict__ vT, int ldv, int kbase, int pre_hi, int lo_q, int hi_q,
-                                 float scale, int lane) {
-    const int i = lane & 15, g4 = lane >> 4;
-    const int key0 = kbase + 8 * (i >> 2) + (i & 3);
+struct GlobalKV {
+    const bf16_t *kb, *vT; int ldv, kbase, i, g4;
+    __device__ bf16x8 k_frag(int tile, int dk) const {
+        const int key = kbase + 8 * (i >> 2) + (i & 3) + 4 * tile;
+        return ld_bf16x8(kb + (size_t)key * D + dk * 32 + g4 * 8);
+    }
+    __device__ bf16x8 v_frag(int db) const { return ld_bf16x8(vT + (size_t)(db * 16 + i) * ldv + kbase + 8 * g4); }
+};
+// LDS: a K tile [32 keys][D] and a V^T tile [D][32 keys] staged by LDS-DMA and shared by the waves of a
+// workgroup (prefill).  16-B chunks are XOR-swizzled (K: chunk ^ (row & (CPR-1)); V^T: chunk ^ ((row>>2)&3))
+// on the DMA source address and on the read address, so the 16-lane ds_read_b128 groups spread over banks.
+template <int D>
+struct LdsKV {
+    const unsigned char *kt, *vt; int i, g4;
+    static constexpr int CPR = D / 8;
+    __device__ bf16x8 k_frag(int tile, int dk) const {
+        const int row = 8 * (i >> 2) + (i & 3) + 4 * tile, c = dk * 4 + g4;
+        return *reinterpret_cast<const bf16x8 *>(kt + row * (D * 2) + ((c ^ (row & (CPR - 1))) << 4));
+    }
+    __device__ bf16x8 v_frag(int db) const {
+        const int row = db * 16 + i;
+        return *reinterpret_cast<const bf16x8 *>(vt + row * 64 + ((g4 ^ ((row >> 2) & 3)) << 4));
+    }
+};
+
+// One 32-key step.  Column q sees key k iff  k < pre_hi  ||  (lo_q <= k && k < hi_q).
+template <int D, typename KV>
+__device__ inline void attn_tile(MfmaAttnState<D> &s, const bf16x8 (&qf)[D / 32], const KV &kv, int kbase, int pre_hi,
+                                 int lo_q, int hi_q, float scale, int lane) {
+    const int g4 = lane >> 4;
     float4v s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dk = 0; dk < D / 32; dk++) {
-        const bf16x8 a0 = ld_bf16x8(kb + (size_t)key0 * D + dk * 32 + g4 * 8);
-        const bf16x8 a1 = ld_bf16x8(kb + (size_t)(key0 + 4) * D + dk * 32 + g4 * 8);
+        const bf16x8 a0 = kv.k_frag(0, dk);
+        const bf16x8 a1 = kv.k_frag(1, dk);
         s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[dk], s0, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[dk], s1, 0, 0, 0);
     }
     // value fragments for this step: issued now, consumed after the softmax
     bf16x8 vb[D / 16];
 #pragma unroll
-    for (int db = 0; db < D / 16; db++) vb[db] = ld_bf16x8(vT + (size_t)(db * 16 + i) * ldv + kbase + 8 * g4);
+    for (int db = 0; db < D / 16; db++) vb[db] = kv.v_frag(db);
 
     float p[8];
     float mt = -INFINITY;
@@ -123,8 +148,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const bf16_t 
     MfmaAttnState<D> s; s.init();
     const bf16_t *kb = kc + (size_t)hk * seq_alloc * D;
     const bf16_t *vb = vT + (size_t)hk * D * seq_alloc;
-    for (int kbase = lo + 32 * wave; kbase < hi; kbase += 32 * NW)
-        attn_tile<D>(s, qf, kb, vb, seq_alloc, kbase, 0, lo, hi, scale, lane);
+    for (int kbase = lo + 32 * wave; kbase < hi; kbase += 32 * NW) {
+        const GlobalKV<D> kv{kb, vb, seq_alloc, kbase, i, g4};
+        attn_tile<D>(s, qf, kv, kbase, 0, lo, hi, scale, lane);
+    }
 
     // wave slab -> LDS in the shared format [wave][head][o[D], m, l]
     float lt = s.l;
@@ -159,7 +186,8 @@ static int launch_decode_mfma_t(Launcher &L, const void *q, const void *kc, cons
 }
 
 bool attn_mfma_supported(int dtype, int64_t H, int64_t Hkv, int64_t d) {
-    return dtype == FL_DTYPE_BF16 && (d == 64 || d == 128) && Hkv > 0 && H % Hkv == 0 && H / Hkv <= 16;
+    // decode packs the G = H/Hkv heads into the 16 MFMA columns; prefill runs one wave per head of the group
+    return dtype == FL_DTYPE_BF16 && (d == 64 || d == 128) && Hkv > 0 && H % Hkv == 0 && H / Hkv <= 8;
 }
 
 int launch_attn_decode_mfma(Launcher &L, const void *q, const void *k_cache, const void *v_cache_T, const StepState *st,
@@ -183,19 +211,46 @@ int launch_attn_decode_mfma(Launcher &L, const void *q, const void *k_cache, con
 }
 
 // ------------------------------------------------------------------------------- prefill
-// grid (ceil(T/16/4), H), 4 waves; wave w owns query tokens [t0, t0+16) of head blockIdx.y.
+// grid (ceil(T / (16*TT)), Hkv); workgroup = G*TT waves: wave w serves query head g = w % G of kv head
+// blockIdx.y for the 16 tokens of sub-tile w / G.  All waves walk the same key tiles, which are staged
+// ONCE per workgroup in LDS (K tile + V^T tile, 16 KB per 32 keys at d = 128, double-buffered LDS-DMA),
+// so every K/V byte fetched from L2 feeds G*TT x 16 query rows instead of 16.
 // Mask (App. A.5): cached prefix [0,len) visible; in-call key j visible to token t iff j <= t and
 // (window < 0 or j + window >= t).
+__device__ inline void glds16(const void *g, unsigned char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
 template <int D>
-__global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
+__device__ inline void stage_kv(const bf16_t *__restrict__ kb, const bf16_t *__restrict__ vT, int ldv, int kbase,
+                                unsigned char *buf, int wave, int nwv, int lane) {
+    constexpr int CPR = D / 8, NK = CPR / 2, NV = D / 16;          // wave-instructions (1 KiB each) per tile
+    unsigned char *kt = buf, *vt = buf + 32 * D * 2;
+    for (int e = wave; e < NK + NV; e += nwv) {
+        if (e < NK) {
+            const int p = e * 64 + lane, row = p / CPR, pc = p % CPR, c = pc ^ (row & (CPR - 1));
+            glds16(kb + (size_t)(kbase + row) * D + c * 8, kt + e * 1024);
+        } else {
+            const int ev = e - NK, p = ev * 64 + lane, row = p >> 2, pc = p & 3, c = pc ^ ((row >> 2) & 3);
+            glds16(vT + (size_t)row * ldv + kbase + c * 8, vt + ev * 1024);
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(512) void attn_prefill_mfma_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
                                                                 const bf16_t *__restrict__ vT, const StepState *__restrict__ st,
                                                                 bf16_t *__restrict__ out, int T, int H, int Hkv, int seq_alloc,
-                                                                float scale, int window) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                                float scale, int window, int TT) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // 2 x (K tile | V^T tile)
+    constexpr int TILE = 2 * 32 * D * 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     const int i = lane & 15, g4 = lane >> 4;
-    const int t0 = (blockIdx.x * 4 + wave) * 16;
-    if (t0 >= T) return;                                         // wave-uniform
-    const int hq = blockIdx.y, hk = hq / (H / Hkv);
+    const int G = H / Hkv, hk = blockIdx.y;
+    const int hq = hk * G + wave % G;
+    const int tb0 = blockIdx.x * TT * 16;                        // first token of the workgroup
+    const int t0 = tb0 + (wave / G) * 16;                        // first token of this wave
     const int len = (int)st->len;
     const int t = t0 + i;                                        // this lane's column
     const bool col_ok = t < T;
@@ -213,16 +268,30 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const bf16_t *__
     if (window >= 0 && t - window > 0) jlo = t - window;
     const int lo_q = col_ok ? len + jlo : 0, hi_q = col_ok ? len + t + 1 : 0;
     const int pre_hi = col_ok ? len : 0;
+    // this wave's useful key range (uniform per wave): tiles outside are skipped, staging is not
+    int wstart = 0;
+    if (len == 0 && window >= 0 && t0 - window > 0) wstart = ((t0 - window) / 32) * 32;
+    const int wend = t0 < T ? len + min(T, t0 + 16) : 0;
 
     MfmaAttnState<D> s; s.init();
     const bf16_t *kb = kc + (size_t)hk * seq_alloc * D;
     const bf16_t *vb = vT + (size_t)hk * D * seq_alloc;
-    // the tile range of the whole wave: from the first key any column can see to the last token's key
     int kstart = 0;
-    if (len == 0 && window >= 0 && t0 - window > 0) kstart = ((t0 - window) / 32) * 32;
-    const int kend = len + min(T, t0 + 16);
-    for (int kbase = kstart; kbase < kend; kbase += 32)
-        attn_tile<D>(s, qf, kb, vb, seq_alloc, kbase, pre_hi, lo_q, hi_q, scale, lane);
+    if (len == 0 && window >= 0 && tb0 - window > 0) kstart = ((tb0 - window) / 32) * 32;
+    const int kend = len + min(T, tb0 + 16 * TT);
+    const int nsteps = (kend - kstart + 31) / 32;
+    stage_kv<D>(kb, vb, seq_alloc, kstart, lds, wave, nwv, lane);
+    for (int sidx = 0; sidx < nsteps; sidx++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int kbase = kstart + 32 * sidx;
+        if (sidx + 1 < nsteps) stage_kv<D>(kb, vb, seq_alloc, kbase + 32, lds + ((sidx + 1) & 1) * TILE, wave, nwv, lane);
+        if (kbase + 32 > wstart && kbase < wend) {               // wave-uniform
+            const unsigned char *cur = lds + (sidx & 1) * TILE;
+            const LdsKV<D> kv{cur, cur + 32 * D * 2, i, g4};
+            attn_tile<D>(s, qf, kv, kbase, pre_hi, lo_q, hi_q, scale, lane);
+        }
+    }
 
     float lt = s.l;
     lt += __shfl_xor(lt, 16, 64);
@@ -244,16 +313,21 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const bf16_t *__
 int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, const void *v_cache_T, const StepState *st,
                              void *out, int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t seq_alloc, float scale,
                              int64_t window) {
-    dim3 grid((unsigned)((T + 63) / 64), (unsigned)H);
+    const int G = (int)(H / Hkv);
+    if (G > 8) FL_FAIL(FL_ERR_UNSUPPORTED, "mfma prefill attention: at most 8 query heads per kv head");
+    const int TT = G >= 4 ? 1 : 4 / G;                       // token sub-tiles per workgroup: at least 4 waves
+    dim3 grid((unsigned)((T + 16 * TT - 1) / (16 * TT)), (unsigned)Hkv);
+    dim3 block((unsigned)(G * TT * 64));
+    const size_t lds = 2 * (size_t)(2 * 32 * d * 2);
     double flops = 2.0 * (double)T * T * H * d;
     if (d == 128)
-        return L.launch(KC_ATTN_PREFILL, 0, flops, attn_prefill_mfma_kernel<128>, grid, dim3(256), 0, (const bf16_t *)q,
+        return L.launch(KC_ATTN_PREFILL, 0, flops, attn_prefill_mfma_kernel<128>, grid, block, lds, (const bf16_t *)q,
                         (const bf16_t *)k_cache, (const bf16_t *)v_cache_T, st, (bf16_t *)out, (int)T, (int)H, (int)Hkv,
-                        (int)seq_alloc, scale, (int)window);
+                        (int)seq_alloc, scale, (int)window, TT);
     if (d == 64)
-        return L.launch(KC_ATTN_PREFILL, 0, flops, attn_prefill_mfma_kernel<64>, grid, dim3(256), 0, (const bf16_t *)q,
+        return L.launch(KC_ATTN_PREFILL, 0, flops, attn_prefill_mfma_kernel<64>, grid, block, lds, (const bf16_t *)q,
                         (const bf16_t *)k_cache, (const bf16_t *)v_cache_T, st, (bf16_t *)out, (int)T, (int)H, (int)Hkv,
-                        (int)seq_alloc, scale, (int)window);
+                        (int)seq_alloc, scale, (int)window, TT);
     FL_FAIL(FL_ERR_UNSUPPORTED, "mfma attention: head_dim %lld", (long long)d);
 }
 
