@@ -4,6 +4,7 @@
 #include <string>
 
 #include "fastllm_host.hpp"
+#include "safetensors.hpp"
 
 using namespace fastllm;
 
@@ -80,6 +81,50 @@ int flh_model_create(int family, const char *config_json, const fl_tensor *tenso
         else if (family == 2) { auto r = QwenWithConfig::initialize_model(cfg, map, (DType)dtype, dev); h->qwen = std::make_unique<Model<QwenWithConfig>>(r.first, dev, r.second); }
         else throw Error(FL_ERR_BAD_ARGUMENT, "unknown family");
         *out = h.release();
+        return 0;
+    });
+}
+
+// load_model::<M>(dir) (huggingface.rs:18-139 minus Hub download and tokenizer): the family is chosen from
+// config.json's architectures[0] the way the registry does (model_registry.rs:169-182)
+int flh_load_dir(const char *dir, int dtype, int device_ordinal, void **out, int *family_out) {
+    return guard([&] {
+        const std::string d(dir);
+        const std::string arch = architecture_of(read_text(d + "/config.json"));
+        const char *fam = get_family_from_architecture(arch);
+        if (!fam) throw Error(FL_ERR_BAD_CONFIG, "Unsupported architecture " + arch);
+        Device dev = device_ordinal < 0 ? Device::cpu() : Device::mi355x(device_ordinal);
+        auto h = std::make_unique<Handle>();
+        const std::string f(fam);
+        if (f == "Llama") { h->family = 0; h->llama = std::make_unique<Model<LlamaWithConfig>>(load_model<LlamaWithConfig>(d, (DType)dtype, dev)); }
+        else if (f == "Mistral") { h->family = 1; h->mistral = std::make_unique<Model<MistralWithConfig>>(load_model<MistralWithConfig>(d, (DType)dtype, dev)); }
+        else { h->family = 2; h->qwen = std::make_unique<Model<QwenWithConfig>>(load_model<QwenWithConfig>(d, (DType)dtype, dev)); }
+        if (family_out) *family_out = h->family;
+        *out = h.release();
+        return 0;
+    });
+}
+
+// parse a checkpoint directory on the host only: number of tensors, and for `name` its dtype / shape /
+// a byte checksum (sum of bytes mod 2^64) so tests can compare with an independent reader
+int flh_checkpoint_probe(const char *dir, const char *name, size_t *n_tensors, int *dtype, int *ndim, int64_t shape[4],
+                         uint64_t *byte_sum) {
+    return guard([&] {
+        Checkpoint ck(dir);
+        if (n_tensors) *n_tensors = ck.tensors.size();
+        if (name) {
+            auto it = ck.tensors.find(name);
+            if (it == ck.tensors.end()) throw Error(FL_ERR_MISSING_TENSOR, std::string("cannot find tensor ") + name);
+            const Tensor &t = it->second;
+            *dtype = (int)t.dtype; *ndim = (int)t.shape.size();
+            size_t cnt = 1;
+            for (size_t i = 0; i < t.shape.size() && i < 4; i++) { shape[i] = t.shape[i]; cnt *= (size_t)t.shape[i]; }
+            const size_t bytes = cnt * (t.dtype == DType::F32 ? 4 : 2);
+            uint64_t sum = 0;
+            const unsigned char *p = static_cast<const unsigned char *>(t.data);
+            for (size_t i = 0; i < bytes; i++) sum += p[i];
+            *byte_sum = sum;
+        }
         return 0;
     });
 }
