@@ -32,8 +32,9 @@ __device__ inline void combine_lds(const float *lds, int g, int j4, float &M, fl
 //   last arriver: agent-scope acquire -> barrier -> plain loads
 // (cdna guide Guideline 16, counter form; placement-independent).  The ticket word is reset by the last
 // arriver, so a captured graph replays without a memset node.
+// Returns true in the workgroup that wrote the final output of its heads.
 template <typename CT, int D, int GMAX, int NW>
-__device__ inline void decode_tail(float *lds, int *is_last, int G, int hq0, int ticket_idx, int split, int nsplit,
+__device__ inline bool decode_tail(float *lds, int *is_last, int G, int hq0, int ticket_idx, int split, int nsplit,
                                    float *__restrict__ part_m, float *__restrict__ part_l, float *__restrict__ part_o,
                                    unsigned *__restrict__ counters, CT *__restrict__ out) {
     if (nsplit == 1) {
@@ -45,7 +46,7 @@ __device__ inline void decode_tail(float *lds, int *is_last, int G, int hq0, int
 #pragma unroll
             for (int j = 0; j < 4; j++) elem<CT>::st(out + (size_t)(hq0 + g) * D + j4 + j, O[j] * inv);
         }
-        return;
+        return true;
     }
     for (int e = threadIdx.x; e < G * (D / 4); e += NW * 64) {
         const int g = e / (D / 4), j4 = (e % (D / 4)) * 4;
@@ -71,7 +72,7 @@ __device__ inline void decode_tail(float *lds, int *is_last, int G, int hq0, int
         *is_last = last;
     }
     __syncthreads();
-    if (!*is_last) return;
+    if (!*is_last) return false;
     // last arriver: stage the (m, l) of all splits in LDS, then combine the o slabs in parallel
     float *lm = lds, *ll = lds + GMAX * nsplit;                       // 2 * GMAX * nsplit floats (nsplit <= 64)
     for (int e = threadIdx.x; e < G * nsplit; e += NW * 64) {
@@ -99,6 +100,7 @@ __device__ inline void decode_tail(float *lds, int *is_last, int G, int hq0, int
 #pragma unroll
         for (int j = 0; j < 4; j++) elem<CT>::st(out + (size_t)(hq0 + g) * D + j4 + j, O[j] * inv);
     }
+    return true;
 }
 
 }  // namespace fl

@@ -116,7 +116,8 @@ struct StepState {
     uint32_t step;       // decode steps done in the current fl_decode_greedy call
     int32_t  eos;        // -1: none
     uint32_t done;       // set once eos was sampled
-    uint32_t _pad[2];
+    uint32_t error;      // device-side failure code (bounded spin gave up): the host turns it into FL_ERR_HIP
+    uint32_t _pad[1];
 };
 
 }  // namespace fl

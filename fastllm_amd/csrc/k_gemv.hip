@@ -174,6 +174,27 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.f;
 
+    // RoPE epilogue operands are requested up front (position from the step state, then this wave's cos/sin
+    // pairs) so that their two dependent round trips overlap the weight stream instead of trailing it
+    uint32_t rope_p = 0, rope_slot = 0;
+    float rope_c[R / 2], rope_s[R / 2];
+    auto rope_prefetch = [&](int g) {
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+            const int q = g * (R / 2) + (r >> 1);
+            const int hd = q / half, j = q - hd * half;
+            const bool rot = hd < a.H + a.Hkv;
+            rope_c[r >> 1] = rot ? a.cos_tab[(size_t)rope_p * half + j] : 1.f;
+            rope_s[r >> 1] = rot ? a.sin_tab[(size_t)rope_p * half + j] : 0.f;
+        }
+    };
+    if (epi == EPI_QKV_ROPE) {
+        const uint32_t pos = a.st->pos;
+        rope_slot = a.st->len;
+        rope_p = pos < (uint32_t)a.max_pos ? pos : (uint32_t)a.max_pos - 1;
+        if (gw < ngroups) rope_prefetch(gw);
+    }
+
     auto finish_group = [&](int g) {
         float sum[R];
 #pragma unroll
@@ -190,8 +211,7 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
                 }
             }
         } else if (epi == EPI_QKV_ROPE) {
-            const uint32_t pos = a.st->pos, slot = a.st->len;
-            const uint32_t p = pos < (uint32_t)a.max_pos ? pos : (uint32_t)a.max_pos - 1;
+            const uint32_t slot = rope_slot;
 #pragma unroll
             for (int r = 0; r < R; r += 2) {
                 const int r0w = row_of(g, r), r1w = row_of(g, r + 1);
@@ -203,7 +223,7 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
                 XT *dst;
                 size_t stride = 1;                                        // element stride between j and j+1
                 if (hd < a.H + a.Hkv) {                                   // rotate-half RoPE (App. A.4)
-                    const float c = a.cos_tab[(size_t)p * half + j], s = a.sin_tab[(size_t)p * half + j];
+                    const float c = rope_c[r >> 1], s = rope_s[r >> 1];
                     const float t0 = x0 * c - x1 * s, t1 = x0 * s + x1 * c;
                     x0 = t0; x1 = t1;
                     dst = hd < a.H ? reinterpret_cast<XT *>(a.q_out) + (size_t)hd * a.d
@@ -251,6 +271,7 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
     }
 #pragma nounroll
     for (int g = gw; g < ngroups; g += nw) {
+        if (epi == EPI_QKV_ROPE && g != gw) rope_prefetch(g);
         const WT *wp[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {

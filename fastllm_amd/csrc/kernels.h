@@ -9,7 +9,7 @@ namespace fl {
 // Kernel classes for the measurement hooks (fl_profile_*): one class per kernel symbol family.
 enum KernelClass {
     KC_EMBED = 0, KC_RMSNORM, KC_GEMV, KC_GEMM_MFMA, KC_GEMM_GENERIC, KC_ROPE_KV, KC_ATTN_DECODE,
-    KC_ATTN_COMBINE, KC_ATTN_PREFILL, KC_ARGMAX, KC_REDUCE, KC_CONVERT, KC_COUNT
+    KC_ATTN_COMBINE, KC_ATTN_PREFILL, KC_ARGMAX, KC_REDUCE, KC_CONVERT, KC_ATTN_OPROJ, KC_COUNT
 };
 const char *kernel_class_name(int kc);
 
@@ -126,6 +126,13 @@ int launch_attn_decode_mfma(Launcher &L, const void *q, const void *k_cache, con
 int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, const void *v_cache_T, const StepState *st,
                              void *out, int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t seq_alloc, float scale,
                              int64_t window);
+
+// decode attention + o_proj in one launch (k_attn_oproj.hip): W_o is pulled into LDS while attention runs
+bool attn_oproj_plan(int64_t H, int64_t Hkv, int64_t d, int64_t h, int nsplit, int cus, int *n_blocks, int *rows_attn,
+                     int *rows_other, size_t *lds_bytes);
+int launch_attn_oproj(Launcher &L, const void *q, const void *k_cache, const void *v_cache_T, const StepState *st,
+                      StepState *st_rw, const AttnScratch &sc, void *ao, unsigned *heads_done, const void *Wo,
+                      float *delta, int64_t H, int64_t Hkv, int64_t d, int64_t h, int64_t seq_alloc, float scale);
 
 // ---- weight conversion at model build ---------------------------------------------------------
 // dst[row_map(r)][c] = cvt(src[r0+r][c0+c]); row_mode 0: dst_row0+r, 1: gate rows, 2: up rows

@@ -76,6 +76,8 @@ struct Model {
     uint32_t *host_tokens = nullptr;
     bool use_graph = true;
     bool fused_decode = true;    // norm / RoPE / KV-append fused into the GEMV kernels
+    bool fuse_oproj = true;      // decode attention + o_proj in one launch (k_attn_oproj.hip)
+    StepState *host_state = nullptr;   // pinned: device step state read back for the error word
     std::vector<ProfRecord> prof;
     bool profiling = false;
     int64_t hbm_bytes = 0;
@@ -89,6 +91,7 @@ struct CacheShard {
     uint32_t *out_tokens = nullptr;
     float *part_m = nullptr, *part_l = nullptr, *part_o = nullptr;
     unsigned *counters = nullptr;        // split-S arrival tickets, [Hkvs * q-groups]
+    unsigned *heads_done = nullptr;      // [L] fused attention+o_proj: kv heads published since set_state
     hipGraphExec_t graph = nullptr;
     std::vector<void *> allocs;
 };
@@ -100,6 +103,7 @@ struct Cache {
     size_t max_seq = 0, len = 0;
     size_t seq_alloc = 0;        // max_seq rounded up to 32: row stride of K / column stride of V^T
     bool v_transposed = false;   // bf16 MFMA attention: value cache stored [Hkvs][d][seq_alloc]
+    bool fuse_oproj = false;     // this cache's decode steps use the fused attention+o_proj launch
     int nsplit = 1;
     int warm_steps = 0;          // eager decode steps done (graph is captured after the first)
     bool graph_failed = false;

@@ -119,6 +119,7 @@ Model::~Model() {
     if (emu_ptrs) (void)hipFree(emu_ptrs);
     if (host_logits) (void)hipHostFree(host_logits);
     if (host_tokens) (void)hipHostFree(host_tokens);
+    if (host_state) (void)hipHostFree(host_state);
     for (auto &r : prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
 }
 
@@ -392,6 +393,8 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
     FL_HIP(hipSetDevice(m->shards[0].device));
     FL_HIP(hipHostMalloc((void **)&m->host_logits, (size_t)D.V * 4, hipHostMallocDefault));
     FL_HIP(hipHostMalloc((void **)&m->host_tokens, kOutTokensCap * 4, hipHostMallocDefault));
+    FL_HIP(hipHostMalloc((void **)&m->host_state, sizeof(StepState), hipHostMallocDefault));
+    m->fuse_oproj = env_int("FL_FUSE_OPROJ", 0) != 0;    // measured slower than two launches (profiles/r01/README.md)
 
     // communicators
     if (tp > 1 && P.mode == FL_TP_SINGLE_PROCESS) {
@@ -439,6 +442,17 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
     if (c->v_transposed && max_seq * (size_t)D.d * 4 <= 96 * 1024) ns = 1;
     c->nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(ns, 64));
     c->nsplit = env_int("FL_ATTN_NSPLIT", c->nsplit);
+    {   // decode attention + o_proj in one launch when W_o's per-CU slice fits in LDS next to the attention state
+        hipDeviceProp_t prop;
+        FL_HIP(hipGetDeviceProperties(&prop, m->shards[0].device));
+        // the fused launch runs 8-wave attention workgroups: 256 keys per workgroup step
+        int ns8 = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)((max_seq + 255) / 256), 64));
+        if (max_seq * (size_t)D.d * 4 <= 96 * 1024) ns8 = 1;
+        int nb, ra, ro; size_t lds;
+        c->fuse_oproj = m->fuse_oproj && m->fused_decode && c->v_transposed &&
+                        attn_oproj_plan(m->shards[0].Hs, m->shards[0].Hkvs, D.d, D.h, ns8, prop.multiProcessorCount, &nb, &ra, &ro, &lds);
+        if (c->fuse_oproj) c->nsplit = env_int("FL_ATTN_NSPLIT", ns8);
+    }
     c->shards.resize(m->shards.size());
     for (size_t i = 0; i < m->shards.size(); i++) {
         Shard &sh = m->shards[i]; CacheShard &cs = c->shards[i];
@@ -456,6 +470,8 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.part_o, (size_t)sh.Hs * c->nsplit * D.d * 4, nullptr));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.counters, (size_t)sh.Hs * 4, nullptr));
         FL_HIP(hipMemset(cs.counters, 0, (size_t)sh.Hs * 4));
+        FL_TRY(dev_alloc(cs.allocs, (void **)&cs.heads_done, (size_t)D.L * 4, nullptr));
+        FL_HIP(hipMemset(cs.heads_done, 0, (size_t)D.L * 4));
         FL_HIP(hipMemset(cs.st, 0, sizeof(StepState)));
     }
     m->refs.fetch_add(1);
@@ -464,8 +480,10 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
 }
 
 // ------------------------------------------------------------------------------- forward
-__global__ void set_state_kernel(StepState *st, uint32_t token, uint32_t pos, uint32_t len, uint32_t step, int32_t eos) {
-    st->token = token; st->pos = pos; st->len = len; st->step = step; st->eos = eos; st->done = 0;
+__global__ void set_state_kernel(StepState *st, uint32_t token, uint32_t pos, uint32_t len, uint32_t step, int32_t eos,
+                                 unsigned *heads_done, int n_layers) {
+    if (threadIdx.x == 0) { st->token = token; st->pos = pos; st->len = len; st->step = step; st->eos = eos; st->done = 0; st->error = 0; }
+    for (int l = threadIdx.x; l < n_layers; l += blockDim.x) heads_done[l] = 0;       // targets restart with step
 }
 
 static Launcher make_launcher(Model *m, Shard &sh) {
@@ -546,9 +564,14 @@ static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
             a.v_ld = c->v_transposed ? (int)c->seq_alloc : 0;
             FL_TRY(launch_gemv(L, dt, a));
             AttnScratch as{cs.part_m, cs.part_l, cs.part_o, cs.counters, c->nsplit, len_hint + 1};
-            if (c->v_transposed) FL_TRY(launch_attn_decode_mfma(L, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->seq_alloc, D.scale));
-            else FL_TRY(launch_attn_decode(L, dt, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->seq_alloc, D.scale));
-            FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, 1, D.h, sh.Hs * D.d, EPI_F32));
+            if (c->fuse_oproj) {
+                FL_TRY(launch_attn_oproj(L, sc.q, kc, vc, cs.st, cs.st, as, sc.ao, cs.heads_done + l, ly.wo, sc.delta, sh.Hs,
+                                         sh.Hkvs, D.d, D.h, (int64_t)c->seq_alloc, D.scale));
+            } else {
+                if (c->v_transposed) FL_TRY(launch_attn_decode_mfma(L, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->seq_alloc, D.scale));
+                else FL_TRY(launch_attn_decode(L, dt, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->seq_alloc, D.scale));
+                FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, 1, D.h, sh.Hs * D.d, EPI_F32));
+            }
         }
         FL_TRY(all_reduce_delta(m, false, D.h));
         for (size_t i = 0; i < ns; i++) {
@@ -646,8 +669,8 @@ static int set_state(Model *m, Cache *c, uint32_t token, size_t pos, size_t len,
     for (size_t i = 0; i < m->shards.size(); i++) {
         Shard &sh = m->shards[i];
         FL_HIP(hipSetDevice(sh.device));
-        hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, sh.stream, c->shards[i].st, token, (uint32_t)pos,
-                           (uint32_t)len, step, (int32_t)eos);
+        hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(64), 0, sh.stream, c->shards[i].st, token, (uint32_t)pos,
+                           (uint32_t)len, step, (int32_t)eos, c->shards[i].heads_done, (int)m->D.L);
         FL_HIP(hipGetLastError());
     }
     return FL_OK;
@@ -756,7 +779,9 @@ int forward(Model *m, Cache *c, const uint32_t *ids, size_t T, size_t pos, float
     FL_HIP(hipSetDevice(s0.device));
     if (logits_out) FL_HIP(hipMemcpyAsync(m->host_logits, s0.logits_full, (size_t)D.V * 4, hipMemcpyDeviceToHost, s0.stream));
     if (token_out) FL_HIP(hipMemcpyAsync(m->host_tokens, c->shards[0].out_tokens, 4, hipMemcpyDeviceToHost, s0.stream));
+    FL_HIP(hipMemcpyAsync(m->host_state, c->shards[0].st, sizeof(StepState), hipMemcpyDeviceToHost, s0.stream));
     FL_TRY(sync_all(m));
+    if (m->host_state->error) FL_FAIL(FL_ERR_HIP, "device-side wait gave up (code 0x%x): decode kernels did not make progress", m->host_state->error);
     if (logits_out) memcpy(logits_out, m->host_logits, (size_t)D.V * 4);
     if (token_out) *token_out = m->host_tokens[0];
     return FL_OK;
@@ -779,7 +804,9 @@ int decode_greedy(Model *m, Cache *c, uint32_t first, size_t pos, size_t n_steps
         for (size_t i = 0; i < nb; i++) FL_TRY(decode_step(m, c, (int64_t)(c->len + i)));
         FL_HIP(hipSetDevice(s0.device));
         FL_HIP(hipMemcpyAsync(m->host_tokens, c->shards[0].out_tokens, nb * 4, hipMemcpyDeviceToHost, s0.stream));
+        FL_HIP(hipMemcpyAsync(m->host_state, c->shards[0].st, sizeof(StepState), hipMemcpyDeviceToHost, s0.stream));
         FL_TRY(sync_all(m));
+        if (m->host_state->error) FL_FAIL(FL_ERR_HIP, "device-side wait gave up (code 0x%x): decode kernels did not make progress", m->host_state->error);
         for (size_t i = 0; i < nb; i++) {
             const uint32_t t = m->host_tokens[i];
             if (eos >= 0 && (int64_t)t == eos) {

@@ -102,7 +102,8 @@ def test_fullsize_kv_cache_equivalence_and_determinism(tiny):
     assert len(a) == 48 and len(c1) == 128 + 48
 
 
-@pytest.mark.parametrize("env", [{"FL_FUSED": "0", "FL_GRAPH": "0"}, {"FL_ATTN_MFMA": "0"}, {"FL_GRAPH": "0"}])
+@pytest.mark.parametrize("env", [{"FL_FUSED": "0", "FL_GRAPH": "0"}, {"FL_ATTN_MFMA": "0"}, {"FL_GRAPH": "0"},
+                                 {"FL_FUSE_OPROJ": "1"}, {"FL_GEMV_SMALL": "0"}])
 def test_fullsize_variant_paths_agree(tiny, env, monkeypatch):
     """fused + hipGraph + MFMA attention (default) vs the unfused / eager / VALU-attention variants."""
     fa, cfg, w = tiny

@@ -252,3 +252,28 @@ def test_decode_split_s_path(fa, name, dtype):
         o = om.forward(oc, ids[i:i + 1], i)
         check_logits(a, o, dtype, "split-S decode step %d" % i)
         np.testing.assert_allclose(a, b, atol=1e-4 if dtype == "f32" else 5e-2, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["llama_a", "mistral_a", "qwen2_a"])
+def test_fused_attention_oproj_launch(fa, name, monkeypatch):
+    """FL_FUSE_OPROJ=1: decode attention + o_proj in one launch (W_o slice in LDS, heads-done word, bounded
+    poll) must give the two-launch result, also across many steps of one decode call and with split S."""
+    cfg = synth.CONFIGS[name]
+    w = synth.synth_weights(cfg)
+    ids = synth.prompt_ids(cfg, 12, seed=9)
+    ref = fa.Model(cfg, w, dtype="bf16")
+    rc = ref.new_cache(600)
+    ref.forward(rc, ids[:10], 0)
+    want = [ref.forward(rc, ids[i:i + 1], i) for i in (10, 11)]
+    tok = oracle.argmax(want[-1])
+    want_toks = ref.decode_greedy(rc, tok, 12, 20)
+    monkeypatch.setenv("FL_FUSE_OPROJ", "1")
+    m = fa.Model(cfg, w, dtype="bf16")
+    c = m.new_cache(600)                       # 600 positions -> 3 attention splits of 256
+    m.forward(c, ids[:10], 0)
+    for i, wnt in zip((10, 11), want):
+        check_logits(m.forward(c, ids[i:i + 1], i), wnt, "bf16", "fused attn+oproj step %d" % i)
+    got_toks = m.decode_greedy(c, tok, 12, 20)
+    assert len(got_toks) == 20
+    same = int(np.argmin(np.concatenate([got_toks == want_toks, [False]])))
+    assert same >= 10, (got_toks, want_toks)   # bf16 split-order noise may fork the two greedy runs late
