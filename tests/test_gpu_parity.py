@@ -277,3 +277,80 @@ def test_fused_attention_oproj_launch(fa, name, monkeypatch):
     assert len(got_toks) == 20
     same = int(np.argmin(np.concatenate([got_toks == want_toks, [False]])))
     assert same >= 10, (got_toks, want_toks)   # bf16 split-order noise may fork the two greedy runs late
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_chunked_prefill_and_prefix(fa, case, dtype, monkeypatch):
+    """Two T>1 calls (the second sees a cached prefix: keys < len are visible, App. A.5) and a prefill that
+    the library itself cuts into chunks (FL_PREFILL_CHUNK) must match one oracle prefill per call."""
+    name, cfg, w = case
+    if name == "mistral_win":
+        pytest.skip("a window over a cached prefix differs from one long prefill by construction (prefix is unmasked)")
+    gm, om = _models(fa, cfg, w, dtype)
+    ids = synth.prompt_ids(cfg, 30, seed=12)
+    gc, oc = gm.new_cache(64), om.new_cache(64)
+    check_logits(gm.forward(gc, ids[:11], 0), om.forward(oc, ids[:11], 0), dtype, "first chunk")
+    check_logits(gm.forward(gc, ids[11:30], 11), om.forward(oc, ids[11:30], 11), dtype, "second chunk over a prefix")
+    assert len(gc) == 30
+    monkeypatch.setenv("FL_PREFILL_CHUNK", "7")            # 30 tokens -> 7+7+7+7+2; also a 1-token tail for 29
+    g2 = fa.Model(cfg, w, dtype=dtype)
+    o2 = om.new_cache(64)
+    c2 = g2.new_cache(64)
+    check_logits(g2.forward(c2, ids[:29], 0), om.forward(o2, ids[:29], 0), dtype, "library-chunked prefill")
+
+
+def test_f16_and_f32_source_tensors(fa):
+    """initialize_model casts whatever dtype the checkpoint holds (VarBuilder::from_tensors): f16 / f32 / bf16
+    sources of the same values give the same model."""
+    cfg = synth.CONFIGS["llama_a"]
+    wb = synth.synth_weights(cfg)
+    wf = synth.as_f32(wb)
+    # values exactly representable in f16 as well: quantise the bf16 values to f16 and back first
+    w16 = {k: v.astype(np.float16) for k, v in wf.items()}
+    wf16 = {k: v.astype(np.float32) for k, v in w16.items()}
+    ids = synth.prompt_ids(cfg, 9)
+    a = fa.Model(cfg, w16, dtype="f32")
+    b = fa.Model(cfg, wf16, dtype="f32")
+    ca, cb = a.new_cache(16), b.new_cache(16)
+    np.testing.assert_array_equal(a.forward(ca, ids, 0), b.forward(cb, ids, 0))
+    c = fa.Model(cfg, wb, dtype="f32")
+    d = fa.Model(cfg, wf, dtype="f32")
+    cc, cd = c.new_cache(16), d.new_cache(16)
+    np.testing.assert_array_equal(c.forward(cc, ids, 0), d.forward(cd, ids, 0))
+
+
+def test_concurrent_streams_on_one_model(fa):
+    """The reference's streaming path runs several generations on clones of one model concurrently
+    (mod.rs:137-238).  Distinct caches on one fl_model from several threads must not interfere."""
+    import threading
+    cfg = synth.CONFIGS["mistral_a"]
+    w = synth.synth_weights(cfg)
+    gm = fa.Model(cfg, w, dtype="bf16")
+    prompts = [synth.prompt_ids(cfg, 6 + k, seed=100 + k) for k in range(6)]
+
+    def run(p):
+        c = gm.new_cache(64)
+        first = gm.forward_argmax(c, p, 0)
+        return np.concatenate([[first], gm.decode_greedy(c, first, len(p), 12)])
+    want = [run(p) for p in prompts]
+    got = [None] * len(prompts)
+
+    def worker(k):
+        got[k] = run(prompts[k])
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(len(prompts))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_long_decode_keeps_matching_the_oracle(fa):
+    """64 teacher-forced decode steps through the captured graph: no drift, no state leak between replays."""
+    cfg = synth.CONFIGS["qwen2_a"]
+    w = synth.synth_weights(cfg)
+    gm, om = _models(fa, cfg, w, "f32")
+    ids = synth.prompt_ids(cfg, 80, seed=31)
+    gc, oc = gm.new_cache(96), om.new_cache(96)
+    gm.forward(gc, ids[:16], 0); om.forward(oc, ids[:16], 0)
+    for i in range(16, 80):
+        np.testing.assert_allclose(gm.forward(gc, ids[i:i + 1], i), om.forward(oc, ids[i:i + 1], i), atol=FP32_TOL, rtol=0)
