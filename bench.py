@@ -172,7 +172,7 @@ def main():
     rs = np.random.RandomState(1234)
     prompt = rs.randint(0, cfg["vocab_size"], size=T).astype(np.uint32)
     prompt[0] = 1
-    cache = model.new_cache(T + max(K, W) + 16)
+    cache = model.new_cache(T + max(K, W) + 64)
 
     # ---- warm-up: prefill + W decode steps (also captures the decode graph) ----
     first = model.forward_argmax(cache, prompt, 0)
@@ -205,10 +205,22 @@ def main():
         elapsed, t_prefill = float(tt[0]), float(tt[1])
     assert len(toks) == K
 
+    # ---- the reference's loop shape for comparison: one fl_forward per token, V fp32 logits copied to the host
+    #      and argmax there (mod.rs:421-452): PCIe-inclusive, never the headline value ----
+    n_host = 32
+    tok = int(toks[-1])
+    barrier(); model.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_host):
+        lg = model.forward(cache, [tok], T + K + i)
+        tok = int(np.flatnonzero(lg == lg.max())[-1])
+    model.synchronize(); barrier()
+    t_host_loop = (time.perf_counter() - t0) / n_host
+
     # ---- per-kernel HIP-event timing of the same decode steps (eager, event pair per launch) ----
     n_prof = 8
     model.profile_begin()
-    model.decode_greedy(cache, int(toks[-1]), T + K, n_prof)
+    model.decode_greedy(cache, tok, T + K + n_host, n_prof)
     stats = model.profile_end()
     barrier()
 
@@ -246,6 +258,8 @@ def main():
             "cpu_baseline": cpu,
             "e2e_hbm": {"bytes_per_token": b_tok, "achieved_GBps": round(tok_s * b_tok / world / 1e9, 1),
                         "frac_of_8TBps_per_gpu": round(tok_s * b_tok / world / 8e12, 4)},
+            "host_loop": {"tokens_per_sec": round(1.0 / t_host_loop, 2),
+                          "note": "fl_forward per token: logits (V fp32) to the host + host argmax, PCIe-inclusive"},
             "prefill": {"tokens": T, "tokens_per_sec": round(T / t_prefill, 1), "ms": round(t_prefill * 1e3, 2),
                         "mfma_frac_of_2.5PF": round(prefill_flops(cfg, T) / t_prefill / world / 2.5e15, 4),
                         "kernels": [{"name": s["name"], "launches": s["launches"], "ms": round(s["total_ms"], 3),

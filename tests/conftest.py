@@ -9,7 +9,16 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def _ensure_built():
+    libs = [os.path.join(ROOT, "fastllm_amd", "lib", "libfastllm_mi355x.so"), os.path.join(ROOT, "fastllm_amd", "lib", "libfastllm_host.so"),
+            os.path.join(ROOT, "oracle", "liboracle.so")]
+    if not all(os.path.exists(p) for p in libs):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 def pytest_configure(config):
+    _ensure_built()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
