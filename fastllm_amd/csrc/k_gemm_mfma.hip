@@ -12,6 +12,8 @@
 //
 // Epilogues: fp32 store (+bias) or SiLU-gate on the 16-interleaved gate/up layout (tile column
 // blocks alternate gate/up, so one lane holds gate[j] and up[j]).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "kernels.h"
@@ -132,6 +134,111 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const bf16_t *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256x128 tile, 8 waves (4 along M x 2 along N, 64x64 per wave: the same fragment code), BK = 64,
+// THREE LDS stages (3 x 48 KiB).  The LDS-DMA of tile s+2 is issued while tile s is computed and is
+// still in flight across the next workgroup barrier: the per-step wait is a COUNTED s_waitcnt vmcnt(6)
+// (the six DMA instructions of the younger tile stay outstanding) followed by a raw s_barrier -- a
+// __syncthreads() here would drain the DMA (its fence waits vmcnt(0)).  One workgroup per CU; each X
+// row block is shared by two N-waves and each W tile by four M-waves, which also cuts the L2->LDS
+// bytes per MAC by 25 % against the 128x128 kernel.  Used when T and the grid are large enough.
+constexpr int BM2 = 256, STAGE2 = (BM2 + BN) * BK * 2;       // 48 KiB per stage
+
+// stage `rows` x 64 of a [nrows][K] matrix; 8 waves, rows/64 LDS-DMA instructions per wave
+template <int ROWS>
+__device__ inline void stage_rows8(const bf16_t *__restrict__ M, int nrows, int K, int row0, int k0,
+                                   unsigned char *lds_tile, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; i++) {
+        const int rb = (i * 8 + wave) * 8;                       // 8 rows (1 KiB) per instruction
+        const int r = rb + (lane >> 3), pc = lane & 7, c = pc ^ ((r >> 1) & 7);
+        int gr = row0 + r; if (gr > nrows - 1) gr = nrows - 1;
+        glds16(M + (size_t)gr * K + k0 + c * 8, lds_tile + rb * 128);
+    }
+}
+
+__global__ __launch_bounds__(512) void gemm_mfma256_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
+                                                           const float *__restrict__ bias, void *__restrict__ out,
+                                                           int T, int N, int K, int epi, int tiles_m, int tiles_n,
+                                                           const float *__restrict__ row_scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [3 stages][X 256x64 | W 128x64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = tiles_m * tiles_n, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int li = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tn = li / tiles_m, tm = li % tiles_m;
+    const int m0 = tm * BM2, n0 = tn * BN;
+
+    float4v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    auto stage = [&](int kt, int slot) {                          // 4 + 2 = 6 LDS-DMA instructions per wave
+        unsigned char *base = lds + slot * STAGE2;
+        stage_rows8<BM2>(X, T, K, m0, kt * BK, base, wave, lane);
+        stage_rows8<BN>(W, N, K, n0, kt * BK, base + BM2 * BK * 2, wave, lane);
+    };
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    for (int kt = 0; kt < nk; kt++) {
+        // tile kt has landed for this wave: its loads are older than the (at most) 6 of tile kt+1
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                             // everyone's tile kt landed; slot (kt+2)%3 is free
+        if (kt + 2 < nk) stage(kt + 2, (kt + 2) % 3);
+        const unsigned char *xt = lds + (kt % 3) * STAGE2, *wt = xt + BM2 * BK * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int chunk = ks * 4 + (lane >> 4);
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = read_frag(xt, wm * 64 + i * 16 + (lane & 15), chunk);
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[j] = read_frag(wt, wn * 64 + j * 16 + (lane & 15), chunk);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    const int cn = lane & 15, rm = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int m = m0 + wm * 64 + i * 16 + rm + rg;
+            if (m >= T) continue;
+            const float rs = row_scale ? row_scale[m] : 1.0f;
+            if (epi == EPI_GATEUP) {
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const int n = n0 + wn * 64 + j * 16 + cn;
+                    if (n + 16 < N) {
+                        const int qq = (n >> 5) * 16 + (n & 15);
+                        float gt = acc[i][j][rg] * rs, up = acc[i][j + 1][rg] * rs;
+                        float av = gt / (1.0f + expf(-gt)) * up;
+                        reinterpret_cast<bf16_t *>(out)[(size_t)m * (N / 2) + qq] = float_to_bf16_bits(av);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int n = n0 + wn * 64 + j * 16 + cn;
+                    if (n < N) reinterpret_cast<float *>(out)[(size_t)m * N + n] = acc[i][j][rg] * rs + (bias ? bias[n] : 0.f);
+                }
+            }
+        }
+    }
+}
+
 bool gemm_mfma_supported(int dtype, int64_t T, int64_t N, int64_t K) {
     return dtype == FL_DTYPE_BF16 && T > 1 && K % BK == 0 && K >= BK && N >= 1;
 }
@@ -147,6 +254,24 @@ int gemm_mfma_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
 
 int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bias, void *y,
                      int64_t T, int64_t N, int64_t K, int epi, const float *row_scale, int ksplit) {
+    static const int use256 = getenv("FL_GEMM_256") ? atoi(getenv("FL_GEMM_256")) : 1;
+    if (use256 && ksplit == 1 && T >= 192 && K / BK >= 3) {
+        const int tm2 = (int)((T + BM2 - 1) / BM2), tn2 = (int)((N + BN - 1) / BN);
+        // measured (profiles/r01/gemm_probe.txt): +13 % over the 128x128 kernel at thousands of tiles, -5 % at
+        // ~450 tiles (1.75 rounds of one workgroup per CU): use it only when the tail round does not matter
+        if ((int64_t)tm2 * tn2 >= 1024) {
+            const size_t lds2 = 3 * (size_t)STAGE2;                     // 144 KiB
+            static bool attr2 = false;
+            if (!attr2) {
+                FL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_mfma256_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                attr2 = true;
+            }
+            double bytes2 = ((double)N * K + (double)T * K) * 2.0;
+            return L.launch(KC_GEMM_MFMA, bytes2, 2.0 * T * N * K, gemm_mfma256_kernel, dim3((unsigned)(tm2 * tn2)), dim3(512),
+                            lds2, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tm2, tn2, row_scale);
+        }
+    }
     const int tiles_m = (int)((T + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
     if (ksplit > 1 && bias) FL_FAIL(FL_ERR_BAD_ARGUMENT, "split-K GEMM cannot add a bias");
     const size_t lds = 4 * TILE_BYTES;     // 64 KiB

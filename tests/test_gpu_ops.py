@@ -32,6 +32,7 @@ def _ref(x, w, bias, epi):
 # (T, N, K): GEMV (T=1), MFMA (T>1, K%64==0), generic (K%64!=0), ragged M/N tails, big K
 SHAPES = [(1, 512, 256), (1, 6144, 4096), (1, 300, 384), (1, 4096, 14336), (1, 2, 8), (1, 33, 1032),
           (5, 512, 256), (128, 256, 512), (130, 384, 448), (257, 1000, 1024), (7, 96, 40), (512, 512, 4096), (300, 1024, 2048), (512, 4096, 4096), (129, 2048, 5632),
+          (1030, 26000, 256), (520, 44000, 192), (2050, 16400, 128),   # 256x128 three-stage kernel (>= 1024 tiles)
           (64, 136, 72)]
 
 
@@ -51,7 +52,7 @@ def test_linear_plain(fa, T, N, K, dtype):
 
 
 @pytest.mark.parametrize("T,I,K", [(1, 352, 256), (1, 14336, 4096), (1, 40, 64), (9, 352, 256), (200, 704, 512),
-                                   (128, 1792, 1024), (3, 24, 48)])
+                                   (128, 1792, 1024), (3, 24, 48), (1025, 13000, 192)])
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
 def test_linear_silu_gate(fa, T, I, K, dtype):
     """gate/up rows in HF order in, silu(gate)*up out (the library interleaves them 16x16 itself)."""
