@@ -181,8 +181,11 @@ bool attn_oproj_plan(int64_t H, int64_t Hkv, int64_t d, int64_t h, int nsplit, i
 int launch_attn_oproj(Launcher &L, const void *q, const void *k_cache, const void *v_cache_T, const StepState *st,
                       StepState *st_rw, const AttnScratch &sc, void *ao, unsigned *heads_done, const void *Wo,
                       float *delta, int64_t H, int64_t Hkv, int64_t d, int64_t h, int64_t seq_alloc, float scale) {
-    int cus = 256;
-    { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount; }
+    static int cus = 0;                                   // queried once (all shards run on the same kind of GPU)
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t p;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+    }
     int nb = 0, ra = 0, ro = 0; size_t lds = 0;
     if (!attn_oproj_plan(H, Hkv, d, h, sc.nsplit, cus, &nb, &ra, &ro, &lds))
         FL_FAIL(FL_ERR_UNSUPPORTED, "fused attention+o_proj launch does not fit this shape");
