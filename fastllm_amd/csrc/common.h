@@ -117,7 +117,7 @@ struct StepState {
     int32_t  eos;        // -1: none
     uint32_t done;       // set once eos was sampled
     uint32_t error;      // device-side failure code (bounded spin gave up): the host turns it into FL_ERR_HIP
-    uint32_t _pad[1];
+    uint32_t call0;      // KV entries cached when the API call began (== len unless the library chunks a prefill)
 };
 
 }  // namespace fl

@@ -237,13 +237,15 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const CT *__restrict_
     float qv[GMAX][8];
     load_q<CT, D, GMAX>(qv, q + (size_t)t * H * D, hq0, G, lane, scale);
     AttnState<GMAX> s; s.init();
-    int jlo = 0;
-    if (window >= 0 && t - window > 0) jlo = t - window;
-    if (jlo == 0) {
+    // prefix cached before the API call: unmasked; window runs over the call's own tokens (call0 <= len)
+    const int c0 = (int)st->call0;
+    int lo = c0;
+    if (window >= 0 && len + t - window > c0) lo = len + t - window;
+    if (lo == c0) {
         attend_range<CT, D, GMAX, 4, 2>(s, qv, G, kb, vb, 0, len + t + 1, wave, lane);
     } else {
-        if (len > 0) attend_range<CT, D, GMAX, 4, 2>(s, qv, G, kb, vb, 0, len, wave, lane);
-        attend_range<CT, D, GMAX, 4, 2>(s, qv, G, kb, vb, len + jlo, len + t + 1, wave, lane);
+        if (c0 > 0) attend_range<CT, D, GMAX, 4, 2>(s, qv, G, kb, vb, 0, c0, wave, lane);
+        attend_range<CT, D, GMAX, 4, 2>(s, qv, G, kb, vb, lo, len + t + 1, wave, lane);
     }
     merge_to_lds<D, GMAX, 4>(s, G, lds, wave, lane);
     for (int e = threadIdx.x; e < G * (D / 4); e += 256) {

@@ -153,20 +153,23 @@ __global__ __launch_bounds__(512) void attn_prefill_mfma_kernel(const bf16_t *__
             for (int j = 0; j < 8; j++) qf[dk][j] = (__bf16)0.f;
         }
     }
-    int jlo = 0;
-    if (window >= 0 && t - window > 0) jlo = t - window;
-    const int lo_q = col_ok ? len + jlo : 0, hi_q = col_ok ? len + t + 1 : 0;
-    const int pre_hi = col_ok ? len : 0;
+    // keys cached before the API call are an unmasked prefix; the causal + sliding-window mask runs over
+    // the call's own tokens even when the library cut the call into chunks (call0 <= len)
+    const int c0 = (int)st->call0;
+    int lo = c0;
+    if (window >= 0 && len + t - window > c0) lo = len + t - window;
+    const int lo_q = col_ok ? lo : 0, hi_q = col_ok ? len + t + 1 : 0;
+    const int pre_hi = col_ok ? c0 : 0;
     // this wave's useful key range (uniform per wave): tiles outside are skipped, staging is not
     int wstart = 0;
-    if (len == 0 && window >= 0 && t0 - window > 0) wstart = ((t0 - window) / 32) * 32;
+    if (c0 == 0 && window >= 0 && len + t0 - window > 0) wstart = ((len + t0 - window) / 32) * 32;
     const int wend = t0 < T ? len + min(T, t0 + 16) : 0;
 
     MfmaAttnState<D> s; s.init();
     const bf16_t *kb = kc + (size_t)hk * seq_alloc * D;
     const bf16_t *vb = vT + (size_t)hk * D * seq_alloc;
     int kstart = 0;
-    if (len == 0 && window >= 0 && tb0 - window > 0) kstart = ((tb0 - window) / 32) * 32;
+    if (c0 == 0 && window >= 0 && len + tb0 - window > 0) kstart = ((len + tb0 - window) / 32) * 32;
     const int kend = len + min(T, tb0 + 16 * TT);
     const int nsteps = (kend - kstart + 31) / 32;
     stage_kv<D>(kb, vb, seq_alloc, kstart, lds, wave, nwv, lane);

@@ -480,9 +480,9 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
 }
 
 // ------------------------------------------------------------------------------- forward
-__global__ void set_state_kernel(StepState *st, uint32_t token, uint32_t pos, uint32_t len, uint32_t step, int32_t eos,
+__global__ void set_state_kernel(StepState *st, uint32_t token, uint32_t pos, uint32_t len, uint32_t call0, uint32_t step, int32_t eos,
                                  unsigned *heads_done, int n_layers) {
-    if (threadIdx.x == 0) { st->token = token; st->pos = pos; st->len = len; st->step = step; st->eos = eos; st->done = 0; st->error = 0; }
+    if (threadIdx.x == 0) { st->token = token; st->pos = pos; st->len = len; st->call0 = call0; st->step = step; st->eos = eos; st->done = 0; st->error = 0; }
     for (int l = threadIdx.x; l < n_layers; l += blockDim.x) heads_done[l] = 0;       // targets restart with step
 }
 
@@ -665,12 +665,13 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
     return FL_OK;
 }
 
-static int set_state(Model *m, Cache *c, uint32_t token, size_t pos, size_t len, uint32_t step, int64_t eos) {
+static int set_state(Model *m, Cache *c, uint32_t token, size_t pos, size_t len, uint32_t step, int64_t eos, size_t call0 = (size_t)-1) {
+    if (call0 == (size_t)-1) call0 = len;
     for (size_t i = 0; i < m->shards.size(); i++) {
         Shard &sh = m->shards[i];
         FL_HIP(hipSetDevice(sh.device));
         hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(64), 0, sh.stream, c->shards[i].st, token, (uint32_t)pos,
-                           (uint32_t)len, step, (int32_t)eos, c->shards[i].heads_done, (int)m->D.L);
+                           (uint32_t)len, (uint32_t)call0, step, (int32_t)eos, c->shards[i].heads_done, (int)m->D.L);
         FL_HIP(hipGetLastError());
     }
     return FL_OK;
@@ -756,14 +757,16 @@ int forward(Model *m, Cache *c, const uint32_t *ids, size_t T, size_t pos, float
     } else {
         const int64_t chunk_max = env_int("FL_PREFILL_CHUNK", 8192);
         size_t done = 0;
+        const size_t call0 = c->len;                 // the mask of every chunk is that of the single call
         while (done < T) {
-            const int64_t Tc = (int64_t)std::min<size_t>(T - done, (size_t)chunk_max);
+            int64_t Tc = (int64_t)std::min<size_t>(T - done, (size_t)chunk_max);
+            if (T - done - (size_t)Tc == 1 && Tc > 2) Tc -= 1;      // never leave a 1-token tail (it would take the decode mask)
             for (auto &sh : m->shards) {
                 FL_HIP(hipSetDevice(sh.device));
                 if (sh.pre.cap_T < Tc) FL_TRY(alloc_scratch(m, sh, sh.pre, Tc));
                 FL_HIP(hipMemcpyAsync(sh.pre.ids, ids + done, (size_t)Tc * 4, hipMemcpyHostToDevice, sh.stream));
             }
-            FL_TRY(set_state(m, c, ids[done], pos + done, c->len, 0, -1));
+            FL_TRY(set_state(m, c, ids[done], pos + done, c->len, 0, -1, call0));
             if (Tc == 1) {
                 // a 1-token tail chunk goes through the decode kernels but is still one `forward`
                 FL_TRY(enqueue_forward(m, c, false, 1, false, (int64_t)c->len));

@@ -281,11 +281,10 @@ def test_fused_attention_oproj_launch(fa, name, monkeypatch):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_chunked_prefill_and_prefix(fa, case, dtype, monkeypatch):
-    """Two T>1 calls (the second sees a cached prefix: keys < len are visible, App. A.5) and a prefill that
-    the library itself cuts into chunks (FL_PREFILL_CHUNK) must match one oracle prefill per call."""
+    """Two T>1 calls (the second sees a cached prefix: keys < len are visible whatever the window, App. A.5)
+    and a prefill that the library itself cuts into chunks (FL_PREFILL_CHUNK) must match one oracle prefill
+    per API call: library chunking keeps the single call's causal + sliding-window mask."""
     name, cfg, w = case
-    if name == "mistral_win":
-        pytest.skip("a window over a cached prefix differs from one long prefill by construction (prefix is unmasked)")
     gm, om = _models(fa, cfg, w, dtype)
     ids = synth.prompt_ids(cfg, 30, seed=12)
     gc, oc = gm.new_cache(64), om.new_cache(64)
@@ -297,6 +296,10 @@ def test_chunked_prefill_and_prefix(fa, case, dtype, monkeypatch):
     o2 = om.new_cache(64)
     c2 = g2.new_cache(64)
     check_logits(g2.forward(c2, ids[:29], 0), om.forward(o2, ids[:29], 0), dtype, "library-chunked prefill")
+    # ... and over a cached prefix: 8 cached, then 22 = 7+7+6+2 (no 1-token tail chunk is ever cut)
+    c3, o3 = g2.new_cache(64), om.new_cache(64)
+    g2.forward(c3, ids[:8], 0); om.forward(o3, ids[:8], 0)
+    check_logits(g2.forward(c3, ids[8:30], 8), om.forward(o3, ids[8:30], 8), dtype, "library-chunked prefill over a prefix")
 
 
 def test_f16_and_f32_source_tensors(fa):
