@@ -128,6 +128,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU path in the product)")
+    # FL_BENCH_SAME_DEVICE=1: rehearsal of the N-rank path on a one-GPU box -- every rank drives cuda:0 with
+    # 1/N of the weights.  RCCL refuses two ranks on one device, so the group is wired with the IPC
+    # inboxes alone.  Ranks share one HBM: the tokens/s of such a run is NOT a scaling figure.
+    same_device = world > 1 and os.environ.get("FL_BENCH_SAME_DEVICE", "0") == "1"
+    if same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -149,7 +155,7 @@ def main():
     log("synthetic weights in HBM: %.1f GB in %.1fs" % (sum(v.numel() for v in wts.values()) * 2 / 1e9, time.perf_counter() - t0))
 
     uid = None
-    if world > 1:
+    if world > 1 and not same_device:
         box = [fa.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
@@ -157,8 +163,16 @@ def main():
     model = fa.Model(cfg, as_fl_tensors(wts, local_rank), dtype="bf16",
                      tp_mode=binding.TP_MULTI_PROCESS if world > 1 else binding.TP_NONE, tp_size=world, tp_rank=rank,
                      device_ids=[local_rank], unique_id=uid)
+    if same_device:
+        hs = [None] * world
+        dist.all_gather_object(hs, model.ipc_export())
+        model.ipc_connect(hs)
     log("model built in %.1fs" % (time.perf_counter() - t0))
     info = model.info()
+    collectives = {0: None, 1: "rccl", 2: "one-shot peer inboxes (k_comm.hip) + rccl for prefill", 3: "local"}[info.small_collectives]
+    if same_device:
+        collectives = "one-shot peer inboxes (k_comm.hip); all ranks on ONE GPU (rehearsal)"
+    log("decode collectives:", collectives)
 
     do_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     cpu = None
@@ -253,7 +267,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "%s bf16 greedy decode, %d-token prompt, %d generated tokens, batch 1, TP=%d"
                                    % (args.model, T, K, world), "kv_len": "%d..%d" % (T, T + K),
-                       "parallelism": "tp%d" % world},
+                       "parallelism": "tp%d" % world, "collectives": collectives},
             "roofline": roof,
             "cpu_baseline": cpu,
             "e2e_hbm": {"bytes_per_token": b_tok, "achieved_GBps": round(tok_s * b_tok / world / 1e9, 1),

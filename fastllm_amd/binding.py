@@ -14,6 +14,7 @@ FAMILY = {"llama": 0, "mistral": 1, "qwen2": 2}
 F32, BF16, F16 = 0, 1, 2
 TP_NONE, TP_SINGLE_PROCESS, TP_MULTI_PROCESS, TP_EMULATED = 0, 1, 2, 3
 UNIQUE_ID_BYTES = 128
+IPC_HANDLE_BYTES = 64
 
 
 class FastLLMError(RuntimeError):
@@ -43,7 +44,7 @@ class FlParallel(C.Structure):
 class FlModelInfo(C.Structure):
     _fields_ = [("cfg", FlConfig), ("head_dim", C.c_int64), ("compute_dtype", C.c_int32), ("tp_size", C.c_int32),
                 ("weight_bytes_per_token", C.c_int64), ("kv_bytes_per_position", C.c_int64),
-                ("hbm_bytes_allocated", C.c_int64)]
+                ("hbm_bytes_allocated", C.c_int64), ("small_collectives", C.c_int32), ("_pad", C.c_int32)]
 
 
 class FlKernelStat(C.Structure):
@@ -66,6 +67,8 @@ def lib():
         L.fl_last_error.restype = C.c_char_p
         L.fl_device_count.argtypes = [C.POINTER(C.c_int)]
         L.fl_comm_unique_id.argtypes = [vp]
+        L.fl_comm_ipc_export.argtypes = [vp, vp]
+        L.fl_comm_ipc_connect.argtypes = [vp, vp]
         L.fl_model_create.argtypes = [C.POINTER(FlConfig), C.POINTER(FlTensor), sz, C.c_int32, C.POINTER(FlParallel), C.POINTER(vp)]
         L.fl_model_retain.argtypes = [vp]
         L.fl_model_retain.restype = None
@@ -216,6 +219,18 @@ class Model:
 
     def synchronize(self):
         _check(lib().fl_synchronize(self._h))
+
+    def ipc_export(self):
+        """This rank's inbox handle (FL_TP_MULTI_PROCESS): ship it to every peer."""
+        buf = C.create_string_buffer(IPC_HANDLE_BYTES)
+        _check(lib().fl_comm_ipc_export(self._h, buf))
+        return buf.raw
+
+    def ipc_connect(self, handles):
+        """handles: the tp handles in rank order (own one included)."""
+        blob = b"".join(bytes(h) for h in handles)
+        buf = C.create_string_buffer(blob, len(blob))
+        _check(lib().fl_comm_ipc_connect(self._h, buf))
 
     def profile_begin(self):
         _check(lib().fl_profile_begin(self._h))

@@ -36,6 +36,9 @@ int fl_comm_unique_id(void *out) {
     return FL_OK;
 }
 
+int fl_comm_ipc_export(fl_model *m, void *handle_out) { return comm_ipc_export(M(m), handle_out); }
+int fl_comm_ipc_connect(fl_model *m, const void *handles) { return comm_ipc_connect(M(m), handles); }
+
 int fl_model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n_tensors, int32_t compute_dtype,
                     const fl_parallel *par, fl_model **out) {
     Model *m = nullptr;
@@ -66,6 +69,7 @@ int fl_model_get_info(const fl_model *m, fl_model_info *out) {
     out->weight_bytes_per_token = es * (D.L * (per_layer + small) + D.h + D.V * D.h);
     out->kv_bytes_per_position = es * D.L * D.Hkv * D.d * 2;
     out->hbm_bytes_allocated = mm->hbm_bytes;
+    out->small_collectives = mm->tp == 1 ? 0 : mm->tp_mode == FL_TP_EMULATED ? 3 : mm->shards[0].pc.connected ? 2 : 1;
     return FL_OK;
 }
 

@@ -1,0 +1,106 @@
+// k_comm.hip -- one-shot all-reduce / all-gather over peer-mapped HBM (xGMI), for the small
+// messages of tensor-parallel decode.
+//
+// a decode step all-reduces one [h] fp32 vector (16 KB for Mistral-7B) twice per
+// layer.  A ring collective pays several xGMI hops of latency for a message that fits in one packet
+// burst, so every rank instead PUSHES its vector straight into an inbox slot in every peer's HBM
+// (xGMI is point-to-point: seven independent links, one 16 KB store burst on each), raises a flag
+// there, waits for the tp flags in its own inbox and sums the tp slots in rank order -- the same
+// order on every rank, so all ranks hold bit-identical sums and stay in lock step on the argmax.
+//
+// Memory: the inbox and the flags live in one hipDeviceMallocUncached allocation per rank (peer
+// stores must not be hidden by the owner's L2), exported with hipIpcGetMemHandle and mapped by the
+// peers (comm.hip).  Two inbox halves alternate by epoch parity: a rank can run at most one
+// collective ahead of the slowest peer (it needs that peer's flag to finish), so the half it
+// overwrites is never still being read.  Epochs count collectives and live on the device, so a
+// captured decode graph replays with no argument update.
+#include "kernels.h"
+
+namespace fl {
+
+template <bool GATHER>
+__global__ __launch_bounds__(1024) void oneshot_kernel(const float *__restrict__ in, float *__restrict__ out, CommTable tab,
+                                                       int rank, int tp, int n, int nmax, long long out_stride, uint32_t *__restrict__ epoch_ctr,
+                                                       uint32_t *__restrict__ err, long long timeout_ticks) {
+    __shared__ uint32_t s_bad;
+    const int tid = threadIdx.x;
+    const uint32_t e = *epoch_ctr + 1;
+    const size_t half = (size_t)(e & 1) * tp * nmax;
+    if (tid == 0) s_bad = 0;
+
+    // push: my vector into slot [rank] of every rank's inbox (own inbox included: one code path)
+    const size_t my_slot = half + (size_t)rank * nmax;
+    if ((n & 3) == 0) {
+        for (int i = tid * 4; i < n; i += 4096) {
+            const float4v v = *reinterpret_cast<const float4v *>(in + i);
+            for (int p = 0; p < tp; p++) *reinterpret_cast<float4v *>(tab.inbox[p] + my_slot + i) = v;
+        }
+    } else {
+        for (int i = tid; i < n; i += 1024) {
+            const float v = in[i];
+            for (int p = 0; p < tp; p++) tab.inbox[p][my_slot + i] = v;
+        }
+    }
+    __threadfence_system();                       // every store has been acknowledged by its peer before a flag is raised
+    __syncthreads();
+    if (tid < tp) {
+        __hip_atomic_store(tab.flags[tid] + rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // wait for rank `tid`'s flag in my own inbox; bounded so a dead peer cannot hang the GPU
+        const uint32_t *f = tab.flags[rank] + tid;
+        const long long t0 = wall_clock64();
+        while ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > timeout_ticks) { s_bad = 1; break; }
+        }
+    }
+    __syncthreads();
+    __threadfence_system();                       // acquire: the slots are read only after all tp flags were seen
+    if (s_bad) {                                  // give up: report, do not touch `out`
+        if (tid == 0) { *err = 0xA11D0000u | (uint32_t)rank; *epoch_ctr = e; }
+        return;
+    }
+    const float *mine = tab.inbox[rank] + half;
+    if ((n & 3) == 0) {
+        for (int i = tid * 4; i < n; i += 4096) {
+            if (GATHER) {
+                for (int s = 0; s < tp; s++)
+                    *reinterpret_cast<float4v *>(out + (size_t)s * out_stride + i) = *reinterpret_cast<const float4v *>(mine + (size_t)s * nmax + i);
+            } else {
+                float4v acc = *reinterpret_cast<const float4v *>(mine + i);
+                for (int s = 1; s < tp; s++) acc += *reinterpret_cast<const float4v *>(mine + (size_t)s * nmax + i);
+                *reinterpret_cast<float4v *>(out + i) = acc;
+            }
+        }
+    } else {
+        for (int i = tid; i < n; i += 1024) {
+            if (GATHER) {
+                for (int s = 0; s < tp; s++) out[(size_t)s * out_stride + i] = mine[(size_t)s * nmax + i];
+            } else {
+                float acc = mine[i];
+                for (int s = 1; s < tp; s++) acc += mine[(size_t)s * nmax + i];
+                out[i] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) *epoch_ctr = e;
+}
+
+// One collective over n <= nmax floats.  all-reduce: out[n] = sum_r in_r[n] (in == out allowed: every
+// thread reads its elements of `in` before any write of `out`, and writes only its own elements).
+// all-gather: out[r*out_stride + i] = in_r[i].
+int launch_oneshot(Launcher &L, bool gather, const float *in, float *out, const CommTable &tab, int rank, int tp,
+                   int64_t n, int64_t nmax, int64_t out_stride, uint32_t *epoch_ctr, uint32_t *err, long long timeout_ticks) {
+    if (n <= 0 || n > nmax || tp < 1 || tp > FL_MAX_TP) FL_FAIL(FL_ERR_BAD_ARGUMENT, "one-shot collective: bad size %lld (max %lld), tp %d", (long long)n, (long long)nmax, tp);
+    const double bytes = (double)n * 4 * (2.0 * tp + 1);
+    L.tag = gather ? "allgather" : "allreduce";
+    int rc;
+    if (gather)
+        rc = L.launch(KC_COMM, bytes, 0, oneshot_kernel<true>, dim3(1), dim3(1024), 0, in, out, tab, rank, tp, (int)n, (int)nmax, (long long)out_stride, epoch_ctr, err, timeout_ticks);
+    else
+        rc = L.launch(KC_COMM, bytes, 0, oneshot_kernel<false>, dim3(1), dim3(1024), 0, in, out, tab, rank, tp, (int)n, (int)nmax, (long long)out_stride, epoch_ctr, err, timeout_ticks);
+    L.tag = "";
+    return rc;
+}
+
+}  // namespace fl

@@ -7,7 +7,7 @@ namespace fl {
 
 static const char *kNames[KC_COUNT] = {
     "embed", "rmsnorm_add", "gemv", "gemm_mfma", "gemm_generic", "rope_kv_append", "attn_decode",
-    "attn_combine", "attn_prefill", "argmax_advance", "reduce_shards", "convert", "attn_oproj"};
+    "attn_combine", "attn_prefill", "argmax_advance", "reduce_shards", "convert", "attn_oproj", "comm_oneshot"};
 const char *kernel_class_name(int kc) { return (kc >= 0 && kc < KC_COUNT) ? kNames[kc] : "?"; }
 
 // ------------------------------------------------------------------------------- embedding

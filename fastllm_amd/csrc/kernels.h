@@ -9,7 +9,7 @@ namespace fl {
 // Kernel classes for the measurement hooks (fl_profile_*): one class per kernel symbol family.
 enum KernelClass {
     KC_EMBED = 0, KC_RMSNORM, KC_GEMV, KC_GEMM_MFMA, KC_GEMM_GENERIC, KC_ROPE_KV, KC_ATTN_DECODE,
-    KC_ATTN_COMBINE, KC_ATTN_PREFILL, KC_ARGMAX, KC_REDUCE, KC_CONVERT, KC_ATTN_OPROJ, KC_COUNT
+    KC_ATTN_COMBINE, KC_ATTN_PREFILL, KC_ARGMAX, KC_REDUCE, KC_CONVERT, KC_ATTN_OPROJ, KC_COMM, KC_COUNT
 };
 const char *kernel_class_name(int kc);
 
@@ -106,6 +106,14 @@ int launch_argmax_advance(Launcher &L, const float *logits, int64_t V, StepState
                           int advance);
 // dst[i] = sum_s src[s][i] for n floats, written to every src (emulated all-reduce)
 int launch_reduce_shards(Launcher &L, float *const *bufs_dev, int nshards, int64_t n);
+
+// ---- one-shot collectives over peer-mapped HBM (k_comm.hip) -----------------------------------
+constexpr int FL_MAX_TP = 8;
+// Per-rank view of the tp inboxes: entry r is rank r's inbox / flag array as mapped in THIS process
+// (own allocation for r == rank, hipIpcOpenMemHandle / peer pointer otherwise).
+struct CommTable { float *inbox[FL_MAX_TP]; uint32_t *flags[FL_MAX_TP]; };
+int launch_oneshot(Launcher &L, bool gather, const float *in, float *out, const CommTable &tab, int rank, int tp,
+                   int64_t n, int64_t nmax, int64_t out_stride, uint32_t *epoch_ctr, uint32_t *err, long long timeout_ticks);
 
 // ---- attention -----------------------------------------------------------------------------
 struct AttnScratch { float *part_m, *part_l, *part_o; unsigned *counters; int nsplit; int64_t kv_len_hint; };

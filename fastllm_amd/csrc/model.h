@@ -45,6 +45,19 @@ struct Scratch {                 // activations of one forward chunk on one shar
     uint32_t *ids = nullptr;     // [T]
 };
 
+// One-shot collectives over peer-mapped HBM (k_comm.hip): this rank's inbox and its view of the peers'.
+struct PeerComm {
+    void *local = nullptr;       // hipDeviceMallocUncached: [flags, 4 KB | inbox: 2 halves x tp slots x nmax floats]
+    size_t bytes = 0;
+    int64_t nmax = 0;            // floats per slot
+    CommTable tab{};
+    void *mapped[FL_MAX_TP] = {};     // hipIpcOpenMemHandle mappings of the peers (closed on destroy)
+    uint32_t *epoch = nullptr;   // device: collectives done so far (same on every rank)
+    uint32_t *err = nullptr;     // pinned host word a kernel writes when a peer never showed up
+    long long timeout_ticks = 0; // wall_clock64 ticks (100 MHz)
+    bool connected = false;
+};
+
 struct Shard {
     int device = 0;
     int rank = 0;                // TP rank this shard plays
@@ -60,6 +73,7 @@ struct Shard {
     float *logits_full = nullptr;    // [V]
     std::vector<void *> allocs;
     ncclComm_t comm = nullptr;
+    PeerComm pc;
 };
 
 struct Model {
@@ -114,6 +128,9 @@ struct Cache {
 int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int compute_dtype,
                  const fl_parallel *par, Model **out);
 int cache_create(Model *m, size_t max_seq, Cache **out);
+// FL_TP_MULTI_PROCESS: export this rank's inbox / map the peers' (handles: tp x FL_IPC_HANDLE_BYTES in rank order)
+int comm_ipc_export(Model *m, void *handle_out);
+int comm_ipc_connect(Model *m, const void *handles);
 // mode: 0 = logits to host, 1 = argmax token to host
 int forward(Model *m, Cache *c, const uint32_t *ids, size_t T, size_t pos, float *logits_out, uint32_t *token_out);
 int decode_greedy(Model *m, Cache *c, uint32_t first, size_t pos, size_t n_steps, int64_t eos,

@@ -35,6 +35,9 @@ const char *last_error() { return g_err; }
     return FL_ERR_RCCL; } } while (0)
 
 static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
+static int comm_alloc(Model *m, Shard &sh);
+static int comm_bootstrap_over_rccl(Model *m);
+static int comm_check(Model *m);
 
 // ------------------------------------------------------------------------------- config
 int resolve_config(const fl_config *cfg, Dims *o) {
@@ -110,6 +113,10 @@ Model::~Model() {
         (void)hipSetDevice(s.device);
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         if (s.comm) ncclCommDestroy(s.comm);
+        for (void *mp : s.pc.mapped) if (mp) (void)hipIpcCloseMemHandle(mp);
+        if (s.pc.local) (void)hipFree(s.pc.local);
+        if (s.pc.epoch) (void)hipFree(s.pc.epoch);
+        if (s.pc.err) (void)hipHostFree(s.pc.err);
         for (void *p : s.allocs) (void)hipFree(p);
         if (s.stream && std::find(closed.begin(), closed.end(), s.stream) == closed.end()) {
             closed.push_back(s.stream);
@@ -403,10 +410,17 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
         FL_NCCL(ncclCommInitAll(comms.data(), tp, devs.data()));
         for (int i = 0; i < tp; i++) m->shards[i].comm = comms[i];
     } else if (tp > 1 && P.mode == FL_TP_MULTI_PROCESS) {
-        if (!P.unique_id) FL_FAIL(FL_ERR_BAD_ARGUMENT, "FL_TP_MULTI_PROCESS needs a unique_id");
-        ncclUniqueId id; memcpy(&id, P.unique_id, sizeof id);
-        FL_HIP(hipSetDevice(m->shards[0].device));
-        FL_NCCL(ncclCommInitRank(&m->shards[0].comm, tp, id, P.tp_rank));
+        // Small collectives (decode) go over peer-mapped inboxes; RCCL carries the large prefill ones.
+        // Without a unique_id there is no RCCL communicator: the host must connect the inboxes itself
+        // (fl_comm_ipc_export / fl_comm_ipc_connect) and every collective takes the one-shot path.
+        if (tp > FL_MAX_TP) FL_FAIL(FL_ERR_UNSUPPORTED, "tp_size %d > %d", tp, FL_MAX_TP);
+        FL_TRY(comm_alloc(m.get(), m->shards[0]));
+        if (P.unique_id) {
+            ncclUniqueId id; memcpy(&id, P.unique_id, sizeof id);
+            FL_HIP(hipSetDevice(m->shards[0].device));
+            FL_NCCL(ncclCommInitRank(&m->shards[0].comm, tp, id, P.tp_rank));
+            if (env_int("FL_ONESHOT", 1)) FL_TRY(comm_bootstrap_over_rccl(m.get()));
+        }
     } else if (tp > 1 && P.mode == FL_TP_EMULATED) {
         FL_HIP(hipMalloc((void **)&m->emu_ptrs, sizeof(float *) * tp * 2));
     } else if (tp > 1) {
@@ -421,6 +435,157 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
         m->use_graph = env_int("FL_GRAPH", 0) != 0;     // eager unless graph capture of RCCL is asked for
     }
     *out = m.release();
+    return FL_OK;
+}
+
+
+// ------------------------------------------------------------------------------- one-shot collectives
+constexpr size_t kCommFlagBytes = 4096;
+static Launcher make_launcher(Model *m, Shard &sh);
+static int comm_connect_impl(Model *m, const void *handles);
+
+static int comm_alloc(Model *m, Shard &sh) {
+    PeerComm &pc = sh.pc;
+    FL_HIP(hipSetDevice(sh.device));
+    pc.nmax = std::max<int64_t>(env_int("FL_AR_INBOX_FLOATS", 65536), 4) / 4 * 4;
+    pc.bytes = kCommFlagBytes + (size_t)2 * m->tp * pc.nmax * 4;
+    FL_HIP(hipExtMallocWithFlags(&pc.local, pc.bytes, hipDeviceMallocUncached));
+    FL_HIP(hipMemset(pc.local, 0, pc.bytes));
+    FL_HIP(hipMalloc((void **)&pc.epoch, 64));
+    FL_HIP(hipMemset(pc.epoch, 0, 64));
+    FL_HIP(hipHostMalloc((void **)&pc.err, 64, hipHostMallocDefault));
+    *pc.err = 0;
+    pc.timeout_ticks = (long long)env_int("FL_AR_TIMEOUT_MS", 20000) * 100000LL;       // 100 MHz wall clock
+    FL_HIP(hipDeviceSynchronize());
+    m->hbm_bytes += (int64_t)pc.bytes;
+    return FL_OK;
+}
+
+static void comm_set_entry(PeerComm &pc, int r, void *base) {
+    pc.tab.flags[r] = (uint32_t *)base;
+    pc.tab.inbox[r] = (float *)((char *)base + kCommFlagBytes);
+}
+
+int comm_ipc_export(Model *m, void *handle_out) {
+    if (!m || !handle_out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+    if (m->tp_mode != FL_TP_MULTI_PROCESS || m->tp < 2) FL_FAIL(FL_ERR_BAD_ARGUMENT, "peer inboxes exist in FL_TP_MULTI_PROCESS mode only");
+    Shard &sh = m->shards[0];
+    FL_HIP(hipSetDevice(sh.device));
+    static_assert(sizeof(hipIpcMemHandle_t) <= FL_IPC_HANDLE_BYTES, "handle size");
+    hipIpcMemHandle_t h;
+    FL_HIP(hipIpcGetMemHandle(&h, sh.pc.local));
+    memset(handle_out, 0, FL_IPC_HANDLE_BYTES);
+    memcpy(handle_out, &h, sizeof h);
+    return FL_OK;
+}
+
+int comm_ipc_connect(Model *m, const void *handles) {
+    if (!m || !handles) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+    if (m->tp_mode != FL_TP_MULTI_PROCESS || m->tp < 2) FL_FAIL(FL_ERR_BAD_ARGUMENT, "peer inboxes exist in FL_TP_MULTI_PROCESS mode only");
+    std::lock_guard<std::mutex> lock(m->mu);
+    return comm_connect_impl(m, handles);
+}
+
+static int comm_connect_impl(Model *m, const void *handles) {
+    Shard &sh = m->shards[0];
+    PeerComm &pc = sh.pc;
+    if (pc.connected) FL_FAIL(FL_ERR_BAD_ARGUMENT, "peer inboxes are already connected");
+    FL_HIP(hipSetDevice(sh.device));
+    for (int r = 0; r < m->tp; r++) {
+        if (r == sh.rank) { comm_set_entry(pc, r, pc.local); continue; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char *)handles + (size_t)r * FL_IPC_HANDLE_BYTES, sizeof h);
+        void *p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            for (void *&mp : pc.mapped) if (mp) { (void)hipIpcCloseMemHandle(mp); mp = nullptr; }
+            FL_FAIL(FL_ERR_HIP, "hipIpcOpenMemHandle of rank %d's inbox failed: %s", r, hipGetErrorString(e));
+        }
+        pc.mapped[r] = p;
+        comm_set_entry(pc, r, p);
+    }
+    pc.connected = true;
+    return FL_OK;
+}
+
+// n floats in chunks of at most nmax; reduce: out = sum over ranks (in == out allowed);
+// gather: out[r * out_stride + i] = in_r[i]
+static int oneshot(Model *m, Shard &sh, bool gather, const float *in, float *out, int64_t n, int64_t out_stride) {
+    PeerComm &pc = sh.pc;
+    Launcher L = make_launcher(m, sh);
+    for (int64_t off = 0; off < n; off += pc.nmax) {
+        const int64_t c = std::min(pc.nmax, n - off);
+        FL_TRY(launch_oneshot(L, gather, in + off, out + off, pc.tab, sh.rank, m->tp, c, pc.nmax, out_stride, pc.epoch, pc.err, pc.timeout_ticks));
+    }
+    return FL_OK;
+}
+
+// Self-contained bootstrap when an RCCL communicator exists: all-gather the IPC handles through it,
+// map the peers, then prove the path on integer-valued data against ncclAllReduce.  Every decision
+// is agreed by all ranks (min over ranks), so either all use the one-shot path or none does.
+static int comm_bootstrap_over_rccl(Model *m) {
+    Shard &sh = m->shards[0];
+    PeerComm &pc = sh.pc;
+    const int tp = m->tp;
+    const bool verbose = env_int("FL_VERBOSE", 0) != 0;
+    FL_HIP(hipSetDevice(sh.device));
+    char *dbuf = nullptr;
+    const size_t test_n = 4096;
+    FL_HIP(hipMalloc((void **)&dbuf, (size_t)tp * FL_IPC_HANDLE_BYTES + 64 + 2 * test_n * 4));
+    std::vector<char> hbuf((size_t)tp * FL_IPC_HANDLE_BYTES);
+    int ok = comm_ipc_export(m, hbuf.data() + (size_t)sh.rank * FL_IPC_HANDLE_BYTES) == FL_OK;
+    auto agree = [&](int mine, int *all) -> int {
+        int *d = (int *)(dbuf + (size_t)tp * FL_IPC_HANDLE_BYTES);
+        FL_HIP(hipMemcpyAsync(d, &mine, 4, hipMemcpyHostToDevice, sh.stream));
+        FL_NCCL(ncclAllReduce(d, d, 1, ncclInt, ncclMin, sh.comm, sh.stream));
+        FL_HIP(hipMemcpyAsync(all, d, 4, hipMemcpyDeviceToHost, sh.stream));
+        FL_HIP(hipStreamSynchronize(sh.stream));
+        return FL_OK;
+    };
+    auto finish = [&](int rc) { (void)hipFree(dbuf); return rc; };
+    int all = 0;
+    if (agree(ok, &all) != FL_OK) return finish(FL_ERR_RCCL);
+    if (!all) return finish(FL_OK);
+    FL_HIP(hipMemcpyAsync(dbuf + (size_t)sh.rank * FL_IPC_HANDLE_BYTES, hbuf.data() + (size_t)sh.rank * FL_IPC_HANDLE_BYTES,
+                          FL_IPC_HANDLE_BYTES, hipMemcpyHostToDevice, sh.stream));
+    FL_NCCL(ncclAllGather(dbuf + (size_t)sh.rank * FL_IPC_HANDLE_BYTES, dbuf, FL_IPC_HANDLE_BYTES, ncclChar, sh.comm, sh.stream));
+    FL_HIP(hipMemcpyAsync(hbuf.data(), dbuf, hbuf.size(), hipMemcpyDeviceToHost, sh.stream));
+    FL_HIP(hipStreamSynchronize(sh.stream));
+    ok = comm_connect_impl(m, hbuf.data()) == FL_OK;
+    if (!ok && verbose) fprintf(stderr, "[fastllm_mi355x] rank %d: %s\n", sh.rank, last_error());
+    if (agree(ok, &all) != FL_OK) return finish(FL_ERR_RCCL);
+    if (all) {
+        // proof run: x_r[i] = (i % 251) + 1000 r  (exact in fp32 whatever the summation order)
+        float *a = (float *)(dbuf + (size_t)tp * FL_IPC_HANDLE_BYTES + 64), *b = a + test_n;
+        std::vector<float> x(test_n), ya(test_n), yb(test_n);
+        for (size_t i = 0; i < test_n; i++) x[i] = (float)(i % 251) + 1000.f * sh.rank;
+        FL_HIP(hipMemcpyAsync(a, x.data(), test_n * 4, hipMemcpyHostToDevice, sh.stream));
+        FL_HIP(hipMemcpyAsync(b, x.data(), test_n * 4, hipMemcpyHostToDevice, sh.stream));
+        const long long keep = pc.timeout_ticks;
+        pc.timeout_ticks = 200000000LL;              // 2 s: a path that does not work must fail fast here
+        int rc = oneshot(m, sh, false, a, a, (int64_t)test_n, 0);
+        pc.timeout_ticks = keep;
+        if (rc != FL_OK) return finish(rc);
+        FL_NCCL(ncclAllReduce(b, b, test_n, ncclFloat, ncclSum, sh.comm, sh.stream));
+        FL_HIP(hipMemcpyAsync(ya.data(), a, test_n * 4, hipMemcpyDeviceToHost, sh.stream));
+        FL_HIP(hipMemcpyAsync(yb.data(), b, test_n * 4, hipMemcpyDeviceToHost, sh.stream));
+        FL_HIP(hipStreamSynchronize(sh.stream));
+        ok = *pc.err == 0 && memcmp(ya.data(), yb.data(), test_n * 4) == 0;
+        if (!ok && verbose) fprintf(stderr, "[fastllm_mi355x] rank %d: one-shot all-reduce self-test failed (err 0x%x)\n", sh.rank, *pc.err);
+        if (agree(ok, &all) != FL_OK) return finish(FL_ERR_RCCL);
+    }
+    if (!all) {                                      // stay on RCCL; the epoch counters may differ now, so the path is closed for good
+        pc.connected = false;
+        *pc.err = 0;
+    }
+    if (verbose && sh.rank == 0) fprintf(stderr, "[fastllm_mi355x] small collectives: %s\n", all ? "one-shot over peer-mapped HBM" : "RCCL");
+    return finish(FL_OK);
+}
+
+static int comm_check(Model *m) {
+    for (auto &sh : m->shards)
+        if (sh.pc.err && *sh.pc.err) FL_FAIL(FL_ERR_RCCL, "one-shot collective gave up waiting for a peer (code 0x%x): the tensor-parallel group is broken", *sh.pc.err);
     return FL_OK;
 }
 
@@ -504,6 +669,12 @@ static int all_reduce_delta(Model *m, bool pre, int64_t count) {
         Launcher L = make_launcher(m, s0);
         return launch_reduce_shards(L, tab, m->tp, count);
     }
+    if (m->tp_mode == FL_TP_MULTI_PROCESS) {
+        Shard &sh = m->shards[0];
+        float *buf = pre ? sh.pre.delta : sh.dec.delta;
+        if (sh.pc.connected && (count <= sh.pc.nmax || !sh.comm)) return oneshot(m, sh, false, buf, buf, count, 0);
+        if (!sh.comm) FL_FAIL(FL_ERR_RCCL, "tensor-parallel group is not connected: call fl_comm_ipc_connect first");
+    }
     FL_NCCL(ncclGroupStart());
     for (auto &sh : m->shards) {
         float *buf = pre ? sh.pre.delta : sh.dec.delta;
@@ -529,6 +700,11 @@ static int gather_logits(Model *m) {
             for (auto &src : m->shards)
                 FL_HIP(hipMemcpyAsync(dst.logits_full + src.v0, src.logits_local, (size_t)src.Vs * 4, hipMemcpyDeviceToDevice, s0.stream));
         return FL_OK;
+    }
+    if (m->tp_mode == FL_TP_MULTI_PROCESS) {
+        Shard &sh = m->shards[0];
+        if (sh.pc.connected && (sh.Vs <= sh.pc.nmax || !sh.comm)) return oneshot(m, sh, true, sh.logits_local, sh.logits_full, sh.Vs, sh.Vs);
+        if (!sh.comm) FL_FAIL(FL_ERR_RCCL, "tensor-parallel group is not connected: call fl_comm_ipc_connect first");
     }
     FL_NCCL(ncclGroupStart());
     for (auto &sh : m->shards)
@@ -785,6 +961,7 @@ int forward(Model *m, Cache *c, const uint32_t *ids, size_t T, size_t pos, float
     FL_HIP(hipMemcpyAsync(m->host_state, c->shards[0].st, sizeof(StepState), hipMemcpyDeviceToHost, s0.stream));
     FL_TRY(sync_all(m));
     if (m->host_state->error) FL_FAIL(FL_ERR_HIP, "device-side wait gave up (code 0x%x): decode kernels did not make progress", m->host_state->error);
+    FL_TRY(comm_check(m));
     if (logits_out) memcpy(logits_out, m->host_logits, (size_t)D.V * 4);
     if (token_out) *token_out = m->host_tokens[0];
     return FL_OK;
@@ -810,6 +987,7 @@ int decode_greedy(Model *m, Cache *c, uint32_t first, size_t pos, size_t n_steps
         FL_HIP(hipMemcpyAsync(m->host_state, c->shards[0].st, sizeof(StepState), hipMemcpyDeviceToHost, s0.stream));
         FL_TRY(sync_all(m));
         if (m->host_state->error) FL_FAIL(FL_ERR_HIP, "device-side wait gave up (code 0x%x): decode kernels did not make progress", m->host_state->error);
+        FL_TRY(comm_check(m));
         for (size_t i = 0; i < nb; i++) {
             const uint32_t t = m->host_tokens[i];
             if (eos >= 0 && (int64_t)t == eos) {

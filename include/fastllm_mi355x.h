@@ -98,8 +98,11 @@ typedef enum fl_tp_mode {
     FL_TP_NONE = 0,                 /* one GPU: device_ids[0] (or device 0 if NULL) */
     FL_TP_SINGLE_PROCESS = 1,       /* this process drives tp_size GPUs (device_ids[tp_size]); the
                                        shape of the reference's one-process server (main.rs:128) */
-    FL_TP_MULTI_PROCESS = 2,        /* one process per GPU: this process is tp_rank of tp_size and
-                                       joins the RCCL communicator named by unique_id */
+    FL_TP_MULTI_PROCESS = 2,        /* one process per GPU: this process is tp_rank of tp_size.  With a
+                                       unique_id it joins that RCCL communicator (large prefill
+                                       collectives) and connects the peer inboxes for the small decode
+                                       collectives by itself; with unique_id == NULL there is no RCCL and
+                                       the host connects the inboxes: fl_comm_ipc_export / _connect */
     FL_TP_EMULATED = 3              /* tp_size shards on ONE GPU, collectives done locally: lets a
                                        single-GPU box verify the sharded kernels (tests only) */
 } fl_tp_mode;
@@ -128,6 +131,15 @@ int         fl_comm_unique_id(void *out /* FL_UNIQUE_ID_BYTES */);
  * the reference's hard-wired dtype (main.rs:120); FL_DTYPE_F32 is the fp32 parity mode. */
 int fl_model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n_tensors,
                     int32_t compute_dtype, const fl_parallel *par, fl_model **out);
+
+/* FL_TP_MULTI_PROCESS: the decode step's two [h] fp32 all-reduces per layer and the logits all-gather
+ * are one-shot pushes into inboxes that every rank maps from every peer's HBM over xGMI (new
+ * capability; the reference is single-device, README.md:149).  A model created with a unique_id
+ * wires them itself over RCCL.  Otherwise: every rank exports its inbox handle, the host all-gathers
+ * the tp handles out of band (rank order) and every rank connects before its first forward. */
+#define FL_IPC_HANDLE_BYTES 64
+int fl_comm_ipc_export(fl_model *m, void *handle_out /* FL_IPC_HANDLE_BYTES */);
+int fl_comm_ipc_connect(fl_model *m, const void *handles /* tp_size * FL_IPC_HANDLE_BYTES */);
 /* Clone for the streaming path (mod.rs:155,181,207) is a refcount bump. */
 void fl_model_retain(fl_model *m);
 void fl_model_release(fl_model *m);
@@ -140,6 +152,8 @@ typedef struct fl_model_info {
     int64_t weight_bytes_per_token; /* algorithmic HBM bytes a decode step reads from weights (whole model) */
     int64_t kv_bytes_per_position;  /* K+V bytes one cached position adds to a decode step */
     int64_t hbm_bytes_allocated;    /* this process, all shards */
+    int32_t small_collectives;      /* decode collectives: 0 none (tp 1), 1 RCCL, 2 one-shot peer inboxes, 3 local (emulated) */
+    int32_t _pad;
 } fl_model_info;
 int fl_model_get_info(const fl_model *m, fl_model_info *out);
 

@@ -48,6 +48,10 @@ CONFIGS = {
     "llama_mha": dict(family="llama", hidden_size=128, intermediate_size=256, vocab_size=200,
                       num_hidden_layers=3, num_attention_heads=2, num_key_value_heads=None,
                       rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=512),
+    # enough kv heads for a 4-way tensor-parallel group (no golden fixture: TP tests only)
+    "llama_tp4": dict(family="llama", hidden_size=512, intermediate_size=1024, vocab_size=512,
+                      num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=4,
+                      rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=512),
 }
 
 

@@ -1,0 +1,92 @@
+"""Multi-process tensor parallelism with the one-shot collectives (fastllm_amd/csrc/k_comm.hip).
+
+tp ranks are separate processes that here share the box's single GPU: the inboxes are real
+hipIpc mappings between processes and the flag / epoch protocol runs exactly as it does across
+xGMI; only the link is missing.  Every rank must produce bit-identical logits (the sum runs in rank
+order everywhere), equal to FL_TP_EMULATED's (same shards, same order) and within tolerance of the
+oracle.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import synth
+from oracle import oracle
+from test_gpu_parity import check_logits
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run_group(tmp_path, name, dtype, tp, T=10, n_tf=4, n_greedy=6, env_extra=None):
+    env = dict(os.environ, FL_AR_TIMEOUT_MS="8000")
+    env.update(env_extra or {})
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "tp_ipc_worker.py"), str(r), str(tp), name, dtype,
+                               str(tmp_path), str(T), str(n_tf), str(n_greedy)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(tp)]
+    outs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=240)
+            outs.append(o.decode(errors="replace"))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
+    return [np.load(os.path.join(str(tmp_path), "out_%d.npz" % r)) for r in range(tp)]
+
+
+@pytest.mark.parametrize("name,tp,dtype", [("llama_a", 2, "bf16"), ("mistral_a", 2, "f32"), ("qwen2_a", 2, "bf16"),
+                                           ("llama_mha", 2, "f32"), ("llama_tp4", 4, "bf16")])
+def test_multiprocess_oneshot_matches_emulated_and_oracle(tmp_path, name, tp, dtype):
+    import fastllm_amd as fa
+    from fastllm_amd import binding
+    cfg = synth.CONFIGS[name]
+    T, n_tf, n_greedy = 10, 4, 6
+    res = run_group(tmp_path, name, dtype, tp, T, n_tf, n_greedy)
+    for r in range(1, tp):                                   # lock step: every rank holds the same bits
+        for k in ("prefill", "decode", "tokens"):
+            np.testing.assert_array_equal(res[r][k], res[0][k], err_msg="rank %d vs 0: %s" % (r, k))
+    w = synth.synth_weights(cfg)
+    ids = synth.prompt_ids(cfg, T + n_tf, seed=11)
+    gN = fa.Model(cfg, w, dtype=dtype, tp_mode=binding.TP_EMULATED, tp_size=tp)
+    om = oracle.OracleModel(cfg, synth.as_f32(w), round_bf16=(dtype == "bf16"))
+    cN, oc = gN.new_cache(64), om.new_cache(64)
+    e, o = gN.forward(cN, ids[:T], 0), om.forward(oc, ids[:T], 0)
+    np.testing.assert_array_equal(res[0]["prefill"], e)
+    check_logits(res[0]["prefill"], o, dtype, "multi-process prefill vs oracle")
+    for i in range(n_tf):
+        e, o = gN.forward(cN, ids[T + i:T + i + 1], T + i), om.forward(oc, ids[T + i:T + i + 1], T + i)
+        np.testing.assert_array_equal(res[0]["decode"][i], e)
+        check_logits(res[0]["decode"][i], o, dtype, "multi-process decode vs oracle")
+    f = gN.forward_argmax(cN, ids[:1], T + n_tf)
+    rest = gN.decode_greedy(cN, f, T + n_tf + 1, n_greedy)
+    np.testing.assert_array_equal(res[0]["tokens"], np.concatenate([[f], rest]).astype(np.uint32))
+
+
+def test_small_inbox_chunks_collectives(tmp_path):
+    """An inbox smaller than the message: prefill all-reduces and the logits all-gather run as several
+    one-shot rounds."""
+    res = run_group(tmp_path, "mistral_a", "bf16", 2, env_extra={"FL_AR_INBOX_FLOATS": "64"})
+    ref_dir = tmp_path / "ref"
+    ref_dir.mkdir()
+    ref = run_group(ref_dir, "mistral_a", "bf16", 2)
+    for k in ("prefill", "decode", "tokens"):
+        np.testing.assert_array_equal(res[0][k], ref[0][k])
+        np.testing.assert_array_equal(res[1][k], ref[0][k])
+
+
+def test_unconnected_group_fails_loudly():
+    import fastllm_amd as fa
+    from fastllm_amd import binding
+    cfg = synth.CONFIGS["llama_a"]
+    m = fa.Model(cfg, synth.synth_weights(cfg), tp_mode=binding.TP_MULTI_PROCESS, tp_size=2, tp_rank=0, device_ids=[0])
+    c = m.new_cache(16)
+    with pytest.raises(fa.FastLLMError) as e:
+        m.forward(c, [1, 2, 3], 0)
+    assert "not connected" in str(e.value)

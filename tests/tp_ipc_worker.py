@@ -1,0 +1,64 @@
+"""One rank of a multi-process tensor-parallel group (tests/test_gpu_tp_ipc.py starts tp of these).
+
+No RCCL: the ranks may share one GPU (the GPU boxes have one), so the group is wired with
+fl_comm_ipc_export / fl_comm_ipc_connect and every collective takes the one-shot path over
+peer-mapped inboxes.  Handles are exchanged through files in `outdir`.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def exchange(outdir, rank, world, blob, tag, timeout=120.0):
+    tmp = os.path.join(outdir, "%s_%d.tmp" % (tag, rank))
+    with open(tmp, "wb") as f:
+        f.write(blob)
+    os.rename(tmp, os.path.join(outdir, "%s_%d" % (tag, rank)))
+    out, t0 = [], time.time()
+    for r in range(world):
+        p = os.path.join(outdir, "%s_%d" % (tag, r))
+        while not os.path.exists(p):
+            if time.time() - t0 > timeout:
+                raise RuntimeError("rank %d never published %s" % (r, tag))
+            time.sleep(0.01)
+        with open(p, "rb") as f:
+            out.append(f.read())
+    return out
+
+
+def main():
+    rank, world, name, dtype, outdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+    T, n_tf, n_greedy = int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8])
+    import fastllm_amd as fa
+    from fastllm_amd import binding
+    import synth
+    cfg = synth.CONFIGS[name] if name in synth.CONFIGS else fa.MODEL_CONFIGS[name]
+    w = synth.synth_weights(cfg)
+    m = fa.Model(cfg, w, dtype=dtype, tp_mode=binding.TP_MULTI_PROCESS, tp_size=world, tp_rank=rank, device_ids=[0])
+    m.ipc_connect(exchange(outdir, rank, world, m.ipc_export(), "handle"))
+    ids = synth.prompt_ids(cfg, T + n_tf, seed=11)
+    c = m.new_cache(T + n_tf + n_greedy + 8)
+    res = {"prefill": m.forward(c, ids[:T], 0)}
+    step = []
+    for i in range(T, T + n_tf):
+        step.append(m.forward(c, ids[i:i + 1], i))
+    res["decode"] = np.stack(step) if step else np.zeros((0, cfg["vocab_size"]), np.float32)
+    first = m.forward_argmax(c, ids[:1], T + n_tf)
+    t0 = time.time()
+    rest = m.decode_greedy(c, first, T + n_tf + 1, n_greedy)
+    res["greedy_s"] = np.array(time.time() - t0)
+    res["tokens"] = np.concatenate([[first], rest]).astype(np.uint32)
+    np.savez(os.path.join(outdir, "out_%d.npz" % rank), **res)
+    exchange(outdir, rank, world, b"done", "done")      # nobody unmaps an inbox a peer may still push to
+    c.close()
+    m.close()
+
+
+if __name__ == "__main__":
+    main()
