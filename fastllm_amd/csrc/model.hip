@@ -433,6 +433,10 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
         FL_HIP(hipSetDevice(m->shards[0].device));
         FL_NCCL(ncclCommInitRank(&m->shards[0].comm, 1, id, 0));
         m->use_graph = env_int("FL_GRAPH", 0) != 0;     // eager unless graph capture of RCCL is asked for
+        if (env_int("FL_ONESHOT", 1)) {                 // ... and of the inbox bootstrap: a group of one
+            FL_TRY(comm_alloc(m.get(), m->shards[0]));
+            FL_TRY(comm_bootstrap_over_rccl(m.get()));
+        }
     }
     *out = m.release();
     return FL_OK;
@@ -443,6 +447,7 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
 constexpr size_t kCommFlagBytes = 4096;
 static Launcher make_launcher(Model *m, Shard &sh);
 static int comm_connect_impl(Model *m, const void *handles);
+static int comm_export_impl(Shard &sh, void *handle_out);
 
 static int comm_alloc(Model *m, Shard &sh) {
     PeerComm &pc = sh.pc;
@@ -469,7 +474,10 @@ static void comm_set_entry(PeerComm &pc, int r, void *base) {
 int comm_ipc_export(Model *m, void *handle_out) {
     if (!m || !handle_out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
     if (m->tp_mode != FL_TP_MULTI_PROCESS || m->tp < 2) FL_FAIL(FL_ERR_BAD_ARGUMENT, "peer inboxes exist in FL_TP_MULTI_PROCESS mode only");
-    Shard &sh = m->shards[0];
+    return comm_export_impl(m->shards[0], handle_out);
+}
+
+static int comm_export_impl(Shard &sh, void *handle_out) {
     FL_HIP(hipSetDevice(sh.device));
     static_assert(sizeof(hipIpcMemHandle_t) <= FL_IPC_HANDLE_BYTES, "handle size");
     hipIpcMemHandle_t h;
@@ -534,7 +542,7 @@ static int comm_bootstrap_over_rccl(Model *m) {
     const size_t test_n = 4096;
     FL_HIP(hipMalloc((void **)&dbuf, (size_t)tp * FL_IPC_HANDLE_BYTES + 64 + 2 * test_n * 4));
     std::vector<char> hbuf((size_t)tp * FL_IPC_HANDLE_BYTES);
-    int ok = comm_ipc_export(m, hbuf.data() + (size_t)sh.rank * FL_IPC_HANDLE_BYTES) == FL_OK;
+    int ok = comm_export_impl(sh, hbuf.data() + (size_t)sh.rank * FL_IPC_HANDLE_BYTES) == FL_OK;
     auto agree = [&](int mine, int *all) -> int {
         int *d = (int *)(dbuf + (size_t)tp * FL_IPC_HANDLE_BYTES);
         FL_HIP(hipMemcpyAsync(d, &mine, 4, hipMemcpyHostToDevice, sh.stream));
@@ -669,7 +677,7 @@ static int all_reduce_delta(Model *m, bool pre, int64_t count) {
         Launcher L = make_launcher(m, s0);
         return launch_reduce_shards(L, tab, m->tp, count);
     }
-    if (m->tp_mode == FL_TP_MULTI_PROCESS) {
+    if (m->tp_mode == FL_TP_MULTI_PROCESS || m->shards[0].pc.connected) {
         Shard &sh = m->shards[0];
         float *buf = pre ? sh.pre.delta : sh.dec.delta;
         if (sh.pc.connected && (count <= sh.pc.nmax || !sh.comm)) return oneshot(m, sh, false, buf, buf, count, 0);

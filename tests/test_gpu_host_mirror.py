@@ -94,9 +94,14 @@ def test_trait_forward_counter_semantics(host, monkeypatch):
     host.flh_model_destroy(h)
 
 
-def test_rccl_plumbing_single_rank(monkeypatch):
-    """A 1-rank RCCL communicator at the real all-reduce call sites (identity) must not change results."""
+@pytest.mark.parametrize("oneshot,graph", [("0", "0"), ("0", "1"), ("1", "0"), ("1", "1")])
+def test_rccl_plumbing_single_rank(monkeypatch, oneshot, graph):
+    """A 1-rank RCCL communicator at the real all-reduce call sites (identity) must not change results.
+    oneshot=1 also runs the inbox bootstrap a multi-process group does over RCCL (handle all-gather, connect,
+    self-test against ncclAllReduce, vote) for a group of one, and then the one-shot kernels at the call sites."""
     import fastllm_amd as fa
+    monkeypatch.setenv("FL_ONESHOT", oneshot)
+    monkeypatch.setenv("FL_GRAPH", graph)
     cfg = synth.CONFIGS["llama_a"]
     w = synth.synth_weights(cfg)
     ids = synth.prompt_ids(cfg, 10)
@@ -106,6 +111,7 @@ def test_rccl_plumbing_single_rank(monkeypatch):
     a2 = plain.forward(c, ids[9:], 9)
     monkeypatch.setenv("FL_DEBUG_RCCL_SELF", "1")
     m = fa.Model(cfg, w, dtype="f32")
+    assert m.info().small_collectives == (2 if oneshot == "1" else 0)
     c = m.new_cache(32)
     np.testing.assert_array_equal(m.forward(c, ids[:9], 0), a1)
     np.testing.assert_array_equal(m.forward(c, ids[9:], 9), a2)
