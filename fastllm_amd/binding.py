@@ -47,6 +47,10 @@ class FlModelInfo(C.Structure):
                 ("hbm_bytes_allocated", C.c_int64), ("small_collectives", C.c_int32), ("_pad", C.c_int32)]
 
 
+class FlSampling(C.Structure):
+    _fields_ = [("temperature", C.c_double), ("seed", C.c_uint64), ("draws_done", C.c_uint64)]
+
+
 class FlKernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double), ("bytes", C.c_double),
                 ("flops", C.c_double)]
@@ -87,6 +91,9 @@ def lib():
         L.fl_forward.argtypes = [vp, vp, vp, sz, sz, vp]
         L.fl_forward_argmax.argtypes = [vp, vp, vp, sz, sz, vp]
         L.fl_decode_greedy.argtypes = [vp, vp, C.c_uint32, sz, sz, C.c_int64, vp, C.POINTER(sz)]
+        L.fl_forward_sample.argtypes = [vp, vp, vp, sz, sz, C.POINTER(FlSampling), vp]
+        L.fl_decode_sample.argtypes = [vp, vp, C.c_uint32, sz, sz, C.c_int64, C.POINTER(FlSampling), vp, C.POINTER(sz)]
+        L.fl_op_sample.argtypes = [vp, C.c_int64, C.POINTER(FlSampling), C.c_int64, vp]
         L.fl_synchronize.argtypes = [vp]
         L.fl_tp_slice.argtypes = [C.POINTER(FlConfig), C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
         L.fl_profile_begin.argtypes = [vp]
@@ -101,6 +108,15 @@ def lib():
 def _check(rc):
     if rc != 0:
         raise FastLLMError(rc, lib().fl_last_error().decode(errors="replace"))
+
+
+def op_sample(logits, n_draws, temperature, seed=0, draws_done=0):
+    """The token-selection kernel alone on a host logits vector: n_draws successive tokens."""
+    a = np.ascontiguousarray(logits, dtype=np.float32)
+    out = np.zeros(n_draws, dtype=np.uint32)
+    sp = FlSampling(temperature, seed, draws_done)
+    _check(lib().fl_op_sample(a.ctypes.data, a.size, C.byref(sp), n_draws, out.ctypes.data))
+    return out
 
 
 def abi_version():
@@ -215,6 +231,21 @@ class Model:
         toks = np.zeros(max(n_steps, 1), dtype=np.uint32)
         n = C.c_size_t(0)
         _check(lib().fl_decode_greedy(self._h, cache._h, int(first_token), pos, n_steps, eos, toks.ctypes.data, C.byref(n)))
+        return toks[: n.value]
+
+    def forward_sample(self, cache, ids, pos, temperature, seed=0, draws_done=0):
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        tok = C.c_uint32(0)
+        sp = FlSampling(temperature, seed, draws_done)
+        _check(lib().fl_forward_sample(self._h, cache._h, ids.ctypes.data, ids.size, pos, C.byref(sp), C.byref(tok)))
+        return tok.value
+
+    def decode_sample(self, cache, first_token, pos, n_steps, temperature, seed=0, draws_done=1, eos=-1):
+        toks = np.zeros(max(n_steps, 1), dtype=np.uint32)
+        n = C.c_size_t(0)
+        sp = FlSampling(temperature, seed, draws_done)
+        _check(lib().fl_decode_sample(self._h, cache._h, int(first_token), pos, n_steps, eos, C.byref(sp), toks.ctypes.data,
+                                      C.byref(n)))
         return toks[: n.value]
 
     def synchronize(self):

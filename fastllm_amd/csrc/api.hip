@@ -104,6 +104,18 @@ int fl_decode_greedy(fl_model *m, fl_cache *c, uint32_t first_token, size_t pos,
     return decode_greedy(M(m), C(c), first_token, pos, n_steps, eos, tokens_out, n_out);
 }
 
+int fl_forward_sample(fl_model *m, fl_cache *c, const uint32_t *ids, size_t T, size_t pos, const fl_sampling *sampling,
+                      uint32_t *token_out) {
+    if (!token_out || !sampling) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+    return forward(M(m), C(c), ids, T, pos, nullptr, token_out, sampling);
+}
+
+int fl_decode_sample(fl_model *m, fl_cache *c, uint32_t first_token, size_t pos, size_t n_steps, int64_t eos,
+                     const fl_sampling *sampling, uint32_t *tokens_out, size_t *n_out) {
+    if (!sampling) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null sampling");
+    return decode_greedy(M(m), C(c), first_token, pos, n_steps, eos, tokens_out, n_out, sampling);
+}
+
 int fl_synchronize(fl_model *m) {
     if (!m) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null model");
     for (auto &sh : M(m)->shards) { FL_HIP(hipSetDevice(sh.device)); FL_HIP(hipStreamSynchronize(sh.stream)); }
@@ -162,6 +174,32 @@ int fl_tune(const char *key, int value) {
     else if (!strcmp(key, "gemv_blocks")) gemv_set_tuning(0, 0, value, -1);        // 0 = automatic
     else if (!strcmp(key, "gemv_waves")) gemv_set_tuning(0, 0, -1, value);          // 0 = automatic
     else FL_FAIL(FL_ERR_BAD_ARGUMENT, "unknown tuning key %s", key);
+    return FL_OK;
+}
+
+int fl_op_sample(const float *logits, int64_t V, const fl_sampling *sampling, int64_t n_draws, uint32_t *tokens_out) {
+    if (!logits || !sampling || !tokens_out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+    if (V <= 0 || V > (1 << 24) || n_draws <= 0 || n_draws > (1 << 20)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "bad size");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FL_FAIL(FL_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU path");
+    FL_HIP(hipSetDevice(0));
+    struct Bufs { float *lg = 0, *sc = 0; StepState *st = 0; SampleState *ss = 0; uint32_t *out = 0; hipStream_t s = 0;
+                  ~Bufs() { (void)hipFree(lg); (void)hipFree(sc); (void)hipFree(st); (void)hipFree(ss); (void)hipFree(out); if (s) (void)hipStreamDestroy(s); } } B;
+    FL_HIP(hipStreamCreate(&B.s));
+    FL_HIP(hipMalloc((void **)&B.lg, (size_t)V * 4));
+    FL_HIP(hipMalloc((void **)&B.sc, (size_t)V * 4));
+    FL_HIP(hipMalloc((void **)&B.st, sizeof(StepState)));
+    FL_HIP(hipMalloc((void **)&B.ss, sizeof(SampleState)));
+    FL_HIP(hipMalloc((void **)&B.out, (size_t)n_draws * 4));
+    StepState st{}; st.eos = -1;
+    const SampleState ss = make_sampler(sampling);
+    FL_HIP(hipMemcpy(B.lg, logits, (size_t)V * 4, hipMemcpyHostToDevice));
+    FL_HIP(hipMemcpy(B.st, &st, sizeof st, hipMemcpyHostToDevice));
+    FL_HIP(hipMemcpy(B.ss, &ss, sizeof ss, hipMemcpyHostToDevice));
+    Launcher L; L.stream = B.s;
+    for (int64_t i = 0; i < n_draws; i++) FL_TRY(launch_select_advance(L, B.lg, V, B.st, B.ss, B.sc, B.out, 1));
+    FL_HIP(hipStreamSynchronize(B.s));
+    FL_HIP(hipMemcpy(tokens_out, B.out, (size_t)n_draws * 4, hipMemcpyDeviceToHost));
     return FL_OK;
 }
 

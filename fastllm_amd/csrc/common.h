@@ -120,4 +120,14 @@ struct StepState {
     uint32_t call0;      // KV entries cached when the API call began (== len unless the library chunks a prefill)
 };
 
+// Token selection state of a cache, next to StepState: LogitsProcessor (mod.rs:373-374) on the device.
+// on == 0: ArgMax.  Otherwise Sampling::All { temperature }: the u32 words of the seeded ChaCha12 stream
+// (rand 0.8 StdRng) consumed so far are counted here, so a captured decode graph draws the next word.
+struct SampleState {
+    uint32_t on;
+    float inv_temp;          // (f32)(1 / temperature): `logits / temperature` is an affine multiply in candle
+    uint32_t draw_lo, draw_hi;
+    uint32_t key[8];
+};
+
 }  // namespace fl

@@ -7,7 +7,7 @@ namespace fl {
 
 static const char *kNames[KC_COUNT] = {
     "embed", "rmsnorm_add", "gemv", "gemm_mfma", "gemm_generic", "rope_kv_append", "attn_decode",
-    "attn_combine", "attn_prefill", "argmax_advance", "reduce_shards", "convert", "attn_oproj", "comm_oneshot"};
+    "attn_combine", "attn_prefill", "select_advance", "reduce_shards", "convert", "attn_oproj", "comm_oneshot"};
 const char *kernel_class_name(int kc) { return (kc >= 0 && kc < KC_COUNT) ? kNames[kc] : "?"; }
 
 // ------------------------------------------------------------------------------- embedding
@@ -140,15 +140,14 @@ int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st
                     (int)Hkv, (int)d, (int)max_seq, (int)v_transposed);
 }
 
-// ------------------------------------------------------------------------------- argmax + advance
-// LogitsProcessor ArgMax (App. A.7): iter().enumerate().max_by(total_cmp) -> on exact ties the
-// LAST maximal index wins.  Also advances the device-resident step state so that a captured
-// decode graph can be replayed back to back with no host round trip (mod.rs:411-453 loop body).
-__global__ __launch_bounds__(1024) void argmax_advance_kernel(const float *__restrict__ logits, int V,
-                                                              StepState *__restrict__ st,
-                                                              uint32_t *__restrict__ out_tokens, int advance) {
-    __shared__ float bv[16];
-    __shared__ int bi[16];
+// ------------------------------------------------------------------------------- token selection + advance
+// LogitsProcessor::sample (mod.rs:308-310,425-428) on the device, then the loop-carried state of
+// mod.rs:411-453 (token, pos, len, step, eos) is advanced so that a captured decode graph can be
+// replayed back to back with no host round trip.
+//
+// ArgMax (temperature None or < 1e-7, App. A.7): iter().enumerate().max_by(total_cmp) -> on exact ties
+// the LAST maximal index wins.
+__device__ inline int argmax_last(const float *__restrict__ logits, int V, float *bv, int *bi) {
     const int tid = threadIdx.x;
     float best = -INFINITY; int idx = -1;
     int i = tid;
@@ -178,7 +177,157 @@ __global__ __launch_bounds__(1024) void argmax_advance_kernel(const float *__res
             float ov = bv[w]; int oi = bi[w];
             if (oi >= 0 && (idx < 0 || ov > best || (ov == best && oi > idx))) { best = ov; idx = oi; }
         }
-        const uint32_t tok = (uint32_t)(idx < 0 ? 0 : idx);
+    }
+    return idx < 0 ? 0 : idx;                           // valid in thread 0
+}
+
+// rand_chacha ChaCha12 block `counter` (64-bit block counter, stream id 0) of the stream keyed by `key`
+__device__ inline uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+__device__ inline uint32_t chacha12_word(const uint32_t *key, uint64_t word_index) {
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[4 + i] = key[i];
+    const uint64_t counter = word_index >> 4;
+    s[12] = (uint32_t)counter; s[13] = (uint32_t)(counter >> 32); s[14] = 0; s[15] = 0;
+    uint32_t x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = s[i];
+#define FL_QR(a, b, c, d) \
+    a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12); \
+    a += b; d ^= a; d = rotl32(d, 8);  c += d; b ^= c; b = rotl32(b, 7);
+#pragma unroll
+    for (int r = 0; r < 12; r += 2) {
+        FL_QR(x[0], x[4], x[8], x[12])  FL_QR(x[1], x[5], x[9], x[13])
+        FL_QR(x[2], x[6], x[10], x[14]) FL_QR(x[3], x[7], x[11], x[15])
+        FL_QR(x[0], x[5], x[10], x[15]) FL_QR(x[1], x[6], x[11], x[12])
+        FL_QR(x[2], x[7], x[8], x[13])  FL_QR(x[3], x[4], x[9], x[14])
+    }
+#undef FL_QR
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) if ((int)(word_index & 15) == i) out = x[i] + s[i];
+    return out;
+}
+
+// Left-to-right fp32 sum of p[0..V) by ONE lane -- the order of the reference's scalar loops -- with the
+// other 1023 threads staging tiles of p through LDS ahead of it.  cumulative: p[i] is replaced by the
+// running sum p[0]+..+p[i] (rand's WeightedIndex::new keeps exactly those).
+constexpr int kSelTile = 4096;
+__device__ inline float sequential_sum(float *__restrict__ p, int V, float *tiles /* 2 x kSelTile */, float *bcast, bool cumulative) {
+    const int tid = threadIdx.x;
+    const int ntiles = (V + kSelTile - 1) / kSelTile;
+    float acc = 0.f;
+    auto load_tile = [&](int t) {
+        float *buf = tiles + (t & 1) * kSelTile;
+        for (int j = tid; j < kSelTile; j += 1024) { const int i = t * kSelTile + j; buf[j] = i < V ? p[i] : 0.f; }
+    };
+    auto store_tile = [&](int t) {
+        const float *buf = tiles + (t & 1) * kSelTile;
+        for (int j = tid; j < kSelTile; j += 1024) { const int i = t * kSelTile + j; if (i < V) p[i] = buf[j]; }
+    };
+    load_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; t++) {
+        if (tid == 0) {
+            float *buf = tiles + (t & 1) * kSelTile;
+            const int n = min(kSelTile, V - t * kSelTile);
+            // one dependent add chain; the LDS reads of the next 16 values are issued before the adds of
+            // the current 16 so that their latency hides behind the chain
+            int j = 0;
+            float4v cur[4], nxt[4];
+            if (n >= 16) for (int u = 0; u < 4; u++) cur[u] = *reinterpret_cast<const float4v *>(buf + 4 * u);
+            for (; j + 16 <= n; j += 16) {
+                const bool more = j + 32 <= n;
+                if (more) for (int u = 0; u < 4; u++) nxt[u] = *reinterpret_cast<const float4v *>(buf + j + 16 + 4 * u);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    float4v c;
+                    c[0] = acc = __fadd_rn(acc, cur[u][0]); c[1] = acc = __fadd_rn(acc, cur[u][1]);
+                    c[2] = acc = __fadd_rn(acc, cur[u][2]); c[3] = acc = __fadd_rn(acc, cur[u][3]);
+                    if (cumulative) *reinterpret_cast<float4v *>(buf + j + 4 * u) = c;
+                }
+                if (more) for (int u = 0; u < 4; u++) cur[u] = nxt[u];
+            }
+            for (; j < n; j++) { acc = __fadd_rn(acc, buf[j]); if (cumulative) buf[j] = acc; }
+        } else if (tid >= 64) {                      // the summing wave does nothing else
+            // buffer (t+1)&1 held tile t-1: write its running sums back, then refill it with tile t+1;
+            // a thread touches the same slots in both steps, so no barrier is needed between them
+            if (cumulative && t >= 1) {
+                const float *buf = tiles + ((t - 1) & 1) * kSelTile;
+                for (int j = tid - 64; j < kSelTile; j += 960) { const int i = (t - 1) * kSelTile + j; if (i < V) p[i] = buf[j]; }
+            }
+            if (t + 1 < ntiles) {
+                float *buf = tiles + ((t + 1) & 1) * kSelTile;
+                for (int j = tid - 64; j < kSelTile; j += 960) { const int i = (t + 1) * kSelTile + j; buf[j] = i < V ? p[i] : 0.f; }
+            }
+        }
+        __syncthreads();
+    }
+    if (cumulative) store_tile(ntiles - 1);
+    if (tid == 0) bcast[0] = acc;
+    __syncthreads();
+    return bcast[0];
+}
+
+// Sampling::All { temperature } (candle-transformers LogitsProcessor over rand 0.8's WeightedIndex<f32>):
+//   prs = softmax(logits * (f32)(1/temperature));  total = sum(prs);  chosen = uniform[0,1) * total with
+//   uniform = f32::from_bits((next_u32() >> 9) | 0x3f800000) - 1;  token = #{ j < V-1 : prs[0]+..+prs[j] <= chosen }.
+// Both sums of the reference (softmax denominator: candle's scalar vec_sum in a default build; cumulative
+// weights: WeightedIndex::new) run left to right in fp32, and at V ~ 1e5 that order is visible in the
+// result (small terms are absorbed: the sequential total is off by ~4e-5, several tokens wide in a flat
+// region), so the two sums are done in that order by one lane; max / exp / divide / count are parallel.
+// exp is evaluated in fp64 and rounded, which reproduces a correctly rounded expf (glibc's, which Rust's
+// f32::exp calls) except in ~1e-9 of the cases.
+__device__ inline int sample_all(const float *__restrict__ logits, int V, SampleState *__restrict__ ss, float *__restrict__ p,
+                                 float *red, float *tiles, float *bcast, int *count) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float mul = ss->inv_temp;
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, __fmul_rn(logits[i], mul));
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+    for (int w = 1; w < 16; w++) mx = fmaxf(mx, red[w]);
+    for (int i = tid; i < V; i += 1024) p[i] = (float)exp((double)__fsub_rn(__fmul_rn(logits[i], mul), mx));
+    __syncthreads();
+    const float S = sequential_sum(p, V, tiles, bcast, false);
+    for (int i = tid; i < V; i += 1024) p[i] = __fdiv_rn(p[i], S);
+    if (tid == 0) *count = 0;
+    __syncthreads();
+    const float total = sequential_sum(p, V, tiles, bcast, true);       // p[] now holds the cumulative weights
+    if (tid == 0) {
+        // UniformFloat::new(0, total): scale = total, lowered by ulps while scale * (1 - 2^-23) >= total
+        float scale = total;
+        while (__fmul_rn(scale, 1.0f - 1.1920929e-07f) >= total) scale = __uint_as_float(__float_as_uint(scale) - 1);
+        const uint64_t w = ((uint64_t)ss->draw_hi << 32) | ss->draw_lo;
+        const uint32_t u = chacha12_word(ss->key, w);
+        ss->draw_lo = (uint32_t)(w + 1); ss->draw_hi = (uint32_t)((w + 1) >> 32);
+        bcast[1] = __fmul_rn(__fsub_rn(__uint_as_float((u >> 9) | 0x3f800000u), 1.0f), scale);
+    }
+    __syncthreads();
+    const float chosen = bcast[1];
+    int n = 0;
+    for (int i = tid; i < V - 1; i += 1024) n += p[i] <= chosen ? 1 : 0;      // partition_point over the first V-1
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if (lane == 0 && n) atomicAdd(count, n);
+    __syncthreads();
+    return *count;
+}
+
+__global__ __launch_bounds__(1024) void select_advance_kernel(const float *__restrict__ logits, int V,
+                                                              StepState *__restrict__ st, SampleState *__restrict__ ss,
+                                                              float *__restrict__ scratch, uint32_t *__restrict__ out_tokens,
+                                                              int advance) {
+    __shared__ float bv[16], bcast[2];
+    __shared__ int bi[16], count;
+    __shared__ float tiles[2 * kSelTile];
+    const int tid = threadIdx.x;
+    int idx;
+    if (ss->on) idx = sample_all(logits, V, ss, scratch, bv, tiles, bcast, &count);
+    else idx = argmax_last(logits, V, bv, bi);
+    if (tid == 0) {
+        const uint32_t tok = (uint32_t)idx;
         if (out_tokens) out_tokens[st->step] = tok;
         st->token = tok;
         if (st->eos >= 0 && tok == (uint32_t)st->eos) st->done = 1;
@@ -186,10 +335,11 @@ __global__ __launch_bounds__(1024) void argmax_advance_kernel(const float *__res
     }
 }
 
-int launch_argmax_advance(Launcher &L, const float *logits, int64_t V, StepState *st, uint32_t *out_tokens,
-                          int advance) {
-    return L.launch(KC_ARGMAX, (double)V * 4, 0, argmax_advance_kernel, dim3(1), dim3(1024), 0, logits, (int)V, st,
-                    out_tokens, advance);
+// scratch: V floats (probabilities / cumulative weights of the sampling path)
+int launch_select_advance(Launcher &L, const float *logits, int64_t V, StepState *st, SampleState *ss, float *scratch,
+                          uint32_t *out_tokens, int advance) {
+    return L.launch(KC_ARGMAX, (double)V * 4, 0, select_advance_kernel, dim3(1), dim3(1024), 0, logits, (int)V, st, ss,
+                    scratch, out_tokens, advance);
 }
 
 // ------------------------------------------------------------------------------- local shard reduce

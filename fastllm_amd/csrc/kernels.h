@@ -101,9 +101,10 @@ int launch_rmsnorm_add(Launcher &L, int dtype, float *x_res, const float *delta,
 int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st, const float *cos_tab,
                    const float *sin_tab, int64_t max_pos, void *q_out, void *k_cache, void *v_cache,
                    int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t max_seq, bool v_transposed);
-// logits[V] -> st->token (ties: last max index), out_tokens[st->step]; advances pos/len/step
-int launch_argmax_advance(Launcher &L, const float *logits, int64_t V, StepState *st, uint32_t *out_tokens,
-                          int advance);
+// logits[V] -> st->token by ArgMax (ties: last max index) or, when ss->on, by temperature sampling with
+// the seeded ChaCha12 stream; out_tokens[st->step] = token; advances pos/len/step
+int launch_select_advance(Launcher &L, const float *logits, int64_t V, StepState *st, SampleState *ss, float *scratch /* [V] */,
+                          uint32_t *out_tokens, int advance);
 // dst[i] = sum_s src[s][i] for n floats, written to every src (emulated all-reduce)
 int launch_reduce_shards(Launcher &L, float *const *bufs_dev, int nshards, int64_t n);
 

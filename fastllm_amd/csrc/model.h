@@ -102,6 +102,8 @@ struct Model {
 struct CacheShard {
     void *k = nullptr, *v = nullptr;     // [L][Hkvs][max_seq][d]
     StepState *st = nullptr;
+    SampleState *ss = nullptr;           // token selection: ArgMax or seeded temperature sampling
+    float *sel_scratch = nullptr;        // [V] probabilities / cumulative weights of the sampling path
     uint32_t *out_tokens = nullptr;
     float *part_m = nullptr, *part_l = nullptr, *part_o = nullptr;
     unsigned *counters = nullptr;        // split-S arrival tickets, [Hkvs * q-groups]
@@ -132,8 +134,12 @@ int cache_create(Model *m, size_t max_seq, Cache **out);
 int comm_ipc_export(Model *m, void *handle_out);
 int comm_ipc_connect(Model *m, const void *handles);
 // mode: 0 = logits to host, 1 = argmax token to host
-int forward(Model *m, Cache *c, const uint32_t *ids, size_t T, size_t pos, float *logits_out, uint32_t *token_out);
+// device token-selection state for a LogitsProcessor::new(seed, Some(temperature), None); null: ArgMax
+SampleState make_sampler(const fl_sampling *sampling);
+// sampling == null: ArgMax
+int forward(Model *m, Cache *c, const uint32_t *ids, size_t T, size_t pos, float *logits_out, uint32_t *token_out,
+            const fl_sampling *sampling = nullptr);
 int decode_greedy(Model *m, Cache *c, uint32_t first, size_t pos, size_t n_steps, int64_t eos,
-                  uint32_t *tokens_out, size_t *n_out);
+                  uint32_t *tokens_out, size_t *n_out, const fl_sampling *sampling = nullptr);
 
 }  // namespace fl

@@ -643,6 +643,9 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.part_o, (size_t)sh.Hs * c->nsplit * D.d * 4, nullptr));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.counters, (size_t)sh.Hs * 4, nullptr));
         FL_HIP(hipMemset(cs.counters, 0, (size_t)sh.Hs * 4));
+        FL_TRY(dev_alloc(cs.allocs, (void **)&cs.ss, sizeof(SampleState), nullptr));
+        FL_HIP(hipMemset(cs.ss, 0, sizeof(SampleState)));
+        FL_TRY(dev_alloc(cs.allocs, (void **)&cs.sel_scratch, (size_t)D.V * 4, nullptr));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.heads_done, (size_t)D.L * 4, nullptr));
         FL_HIP(hipMemset(cs.heads_done, 0, (size_t)D.L * 4));
         FL_HIP(hipMemset(cs.st, 0, sizeof(StepState)));
@@ -654,9 +657,30 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
 
 // ------------------------------------------------------------------------------- forward
 __global__ void set_state_kernel(StepState *st, uint32_t token, uint32_t pos, uint32_t len, uint32_t call0, uint32_t step, int32_t eos,
-                                 unsigned *heads_done, int n_layers) {
-    if (threadIdx.x == 0) { st->token = token; st->pos = pos; st->len = len; st->call0 = call0; st->step = step; st->eos = eos; st->done = 0; st->error = 0; }
+                                 unsigned *heads_done, int n_layers, SampleState *ss, SampleState ss_new, int ss_set) {
+    if (threadIdx.x == 0) {
+        st->token = token; st->pos = pos; st->len = len; st->call0 = call0; st->step = step; st->eos = eos; st->done = 0; st->error = 0;
+        if (ss_set) *ss = ss_new;
+    }
     for (int l = threadIdx.x; l < n_layers; l += blockDim.x) heads_done[l] = 0;       // targets restart with step
+}
+
+// LogitsProcessor::new(seed, Some(temperature), None) (mod.rs:373-374): ArgMax below 1e-7, else the
+// StdRng stream of rand 0.8 -- ChaCha12 keyed by SeedableRng::seed_from_u64 (PCG32 XSH-RR expansion of
+// the u64 into 8 little-endian key words) -- positioned after `draws_done` u32 words.
+SampleState make_sampler(const fl_sampling *sp) {
+    SampleState s{};
+    if (!sp || !(sp->temperature >= 1e-7)) return s;
+    s.on = 1;
+    s.inv_temp = (float)(1.0 / sp->temperature);
+    uint64_t state = sp->seed;
+    for (int i = 0; i < 8; i++) {
+        state = state * 6364136223846793005ull + 11634580027462260723ull;
+        const uint32_t xs = (uint32_t)(((state >> 18) ^ state) >> 27), rot = (uint32_t)(state >> 59);
+        s.key[i] = (xs >> rot) | (xs << ((32 - rot) & 31));
+    }
+    s.draw_lo = (uint32_t)sp->draws_done; s.draw_hi = (uint32_t)(sp->draws_done >> 32);
+    return s;
 }
 
 static Launcher make_launcher(Model *m, Shard &sh) {
@@ -849,13 +873,16 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
     return FL_OK;
 }
 
-static int set_state(Model *m, Cache *c, uint32_t token, size_t pos, size_t len, uint32_t step, int64_t eos, size_t call0 = (size_t)-1) {
+// sampler: non-null (re)sets the cache's token selection; null keeps it (later chunks of one call)
+static int set_state(Model *m, Cache *c, uint32_t token, size_t pos, size_t len, uint32_t step, int64_t eos, size_t call0 = (size_t)-1,
+                     const SampleState *sampler = nullptr) {
     if (call0 == (size_t)-1) call0 = len;
     for (size_t i = 0; i < m->shards.size(); i++) {
         Shard &sh = m->shards[i];
         FL_HIP(hipSetDevice(sh.device));
         hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(64), 0, sh.stream, c->shards[i].st, token, (uint32_t)pos,
-                           (uint32_t)len, (uint32_t)call0, step, (int32_t)eos, c->shards[i].heads_done, (int)m->D.L);
+                           (uint32_t)len, (uint32_t)call0, step, (int32_t)eos, c->shards[i].heads_done, (int)m->D.L,
+                           c->shards[i].ss, sampler ? *sampler : SampleState{}, sampler ? 1 : 0);
         FL_HIP(hipGetLastError());
     }
     return FL_OK;
@@ -866,7 +893,7 @@ static int enqueue_argmax(Model *m, Cache *c, int advance) {
         Shard &sh = m->shards[i];
         FL_HIP(hipSetDevice(sh.device));
         Launcher L = make_launcher(m, sh);
-        FL_TRY(launch_argmax_advance(L, sh.logits_full, m->D.V, c->shards[i].st, c->shards[i].out_tokens, advance));
+        FL_TRY(launch_select_advance(L, sh.logits_full, m->D.V, c->shards[i].st, c->shards[i].ss, c->shards[i].sel_scratch, c->shards[i].out_tokens, advance));
     }
     return FL_OK;
 }
@@ -927,15 +954,17 @@ static int check_call(Model *m, Cache *c, size_t T, size_t pos) {
     return FL_OK;
 }
 
-int forward(Model *m, Cache *c, const uint32_t *ids, size_t T, size_t pos, float *logits_out, uint32_t *token_out) {
+int forward(Model *m, Cache *c, const uint32_t *ids, size_t T, size_t pos, float *logits_out, uint32_t *token_out,
+            const fl_sampling *sampling) {
     FL_TRY(check_call(m, c, T, pos));
+    const SampleState sampler = make_sampler(sampling);
     if (!ids) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null ids");
     for (size_t t = 0; t < T; t++)
         if ((int64_t)ids[t] >= m->D.V) FL_FAIL(FL_ERR_BAD_ARGUMENT, "token id %u out of range (vocab %lld)", ids[t], (long long)m->D.V);
     std::lock_guard<std::mutex> lock(m->mu);
     const Dims &D = m->D;
     if (T == 1) {
-        FL_TRY(set_state(m, c, ids[0], pos, c->len, 0, -1));
+        FL_TRY(set_state(m, c, ids[0], pos, c->len, 0, -1, (size_t)-1, &sampler));
         FL_TRY(decode_step(m, c, (int64_t)c->len));
         c->len += 1;
     } else {
@@ -950,7 +979,7 @@ int forward(Model *m, Cache *c, const uint32_t *ids, size_t T, size_t pos, float
                 if (sh.pre.cap_T < Tc) FL_TRY(alloc_scratch(m, sh, sh.pre, Tc));
                 FL_HIP(hipMemcpyAsync(sh.pre.ids, ids + done, (size_t)Tc * 4, hipMemcpyHostToDevice, sh.stream));
             }
-            FL_TRY(set_state(m, c, ids[done], pos + done, c->len, 0, -1, call0));
+            FL_TRY(set_state(m, c, ids[done], pos + done, c->len, 0, -1, call0, &sampler));
             if (Tc == 1) {
                 // a 1-token tail chunk goes through the decode kernels but is still one `forward`
                 FL_TRY(enqueue_forward(m, c, false, 1, false, (int64_t)c->len));
@@ -976,7 +1005,8 @@ int forward(Model *m, Cache *c, const uint32_t *ids, size_t T, size_t pos, float
 }
 
 int decode_greedy(Model *m, Cache *c, uint32_t first, size_t pos, size_t n_steps, int64_t eos,
-                  uint32_t *tokens_out, size_t *n_out) {
+                  uint32_t *tokens_out, size_t *n_out, const fl_sampling *sampling) {
+    const SampleState sampler = make_sampler(sampling);
     if (n_out) *n_out = 0;
     if (n_steps == 0) return FL_OK;
     FL_TRY(check_call(m, c, n_steps, pos));
@@ -988,7 +1018,7 @@ int decode_greedy(Model *m, Cache *c, uint32_t first, size_t pos, size_t n_steps
     uint32_t tok = first;
     while (done < n_steps) {
         const size_t nb = std::min(n_steps - done, kOutTokensCap);
-        FL_TRY(set_state(m, c, tok, pos + done, c->len, 0, eos));
+        FL_TRY(set_state(m, c, tok, pos + done, c->len, 0, eos, (size_t)-1, done == 0 ? &sampler : nullptr));
         for (size_t i = 0; i < nb; i++) FL_TRY(decode_step(m, c, (int64_t)(c->len + i)));
         FL_HIP(hipSetDevice(s0.device));
         FL_HIP(hipMemcpyAsync(m->host_tokens, c->shards[0].out_tokens, nb * 4, hipMemcpyDeviceToHost, s0.stream));

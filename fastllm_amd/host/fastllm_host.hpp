@@ -410,6 +410,99 @@ inline uint32_t argmax_last(const float *v, size_t n) {      // LogitsProcessor 
     return (uint32_t)best;
 }
 
+// rand 0.8 `StdRng` as LogitsProcessor seeds it: ChaCha12, key = SeedableRng::seed_from_u64 (PCG32 XSH-RR
+// expansion of the u64 into eight little-endian words), 64-bit block counter from 0, stream id 0, consumed
+// one u32 word at a time.
+class StdRng {
+   public:
+    explicit StdRng(uint64_t seed) {
+        uint64_t st = seed;
+        for (auto &k : key_) {
+            st = st * 6364136223846793005ull + 11634580027462260723ull;
+            const uint32_t xs = (uint32_t)(((st >> 18) ^ st) >> 27), rot = (uint32_t)(st >> 59);
+            k = (xs >> rot) | (xs << ((32 - rot) & 31));
+        }
+    }
+    uint32_t next_u32() {
+        if ((word_ & 15) == 0) block(word_ >> 4);
+        return buf_[word_++ & 15];
+    }
+    uint64_t words_consumed() const { return word_; }
+
+   private:
+    static uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+    static void qr(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d) {
+        a += b; d ^= a; d = rotl(d, 16); c += d; b ^= c; b = rotl(b, 12);
+        a += b; d ^= a; d = rotl(d, 8);  c += d; b ^= c; b = rotl(b, 7);
+    }
+    void block(uint64_t counter) {
+        uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+        for (int i = 0; i < 8; i++) s[4 + i] = key_[i];
+        s[12] = (uint32_t)counter; s[13] = (uint32_t)(counter >> 32); s[14] = s[15] = 0;
+        uint32_t x[16];
+        std::memcpy(x, s, sizeof x);
+        for (int r = 0; r < 12; r += 2) {
+            qr(x[0], x[4], x[8], x[12]); qr(x[1], x[5], x[9], x[13]); qr(x[2], x[6], x[10], x[14]); qr(x[3], x[7], x[11], x[15]);
+            qr(x[0], x[5], x[10], x[15]); qr(x[1], x[6], x[11], x[12]); qr(x[2], x[7], x[8], x[13]); qr(x[3], x[4], x[9], x[14]);
+        }
+        for (int i = 0; i < 16; i++) buf_[i] = x[i] + s[i];
+    }
+    uint32_t key_[8], buf_[16];
+    uint64_t word_ = 0;
+};
+
+// candle_transformers::generation::LogitsProcessor as the reference builds it:
+// LogitsProcessor::new(Default::default(), Some(temperature as f64), None) (mod.rs:157-158,373-374).
+// This is the reference's own host-side shape (logits on the host, mod.rs:421-428); the device-side
+// equivalent is fl_forward_sample / fl_decode_sample.
+class LogitsProcessor {
+   public:
+    LogitsProcessor(uint64_t seed, std::optional<double> temperature) : rng_(seed) {
+        if (temperature && !(*temperature < 1e-7)) { sampling_ = true; temperature_ = *temperature; }
+    }
+    bool is_argmax() const { return !sampling_; }
+    double temperature() const { return temperature_; }
+    uint64_t draws() const { return rng_.words_consumed(); }
+    uint32_t sample(const float *logits, size_t n) {
+        if (n == 0) throw Error(FL_ERR_BAD_ARGUMENT, "empty logits");
+        if (!sampling_) return argmax_last(logits, n);
+        // prs = softmax_last_dim(logits / temperature): `Tensor / f64` is affine(1/t, 0) in the tensor's dtype
+        const float mul = (float)(1.0 / temperature_);
+        prs_.resize(n);
+        float mx = -INFINITY;
+        for (size_t i = 0; i < n; i++) { prs_[i] = logits[i] * mul; if (prs_[i] > mx) mx = prs_[i]; }
+        float sum = 0.f;
+        for (size_t i = 0; i < n; i++) { prs_[i] = std::exp(prs_[i] - mx); sum += prs_[i]; }
+        for (size_t i = 0; i < n; i++) prs_[i] /= sum;
+        // WeightedIndex::new: running f32 total, left to right; weights must be >= 0 and not all zero
+        float total = 0.f;
+        for (size_t i = 0; i < n; i++) {
+            if (!(prs_[i] >= 0.f)) throw Error(FL_ERR_BAD_ARGUMENT, "Failed to sample next token: invalid weight");
+            total = i == 0 ? prs_[0] : total + prs_[i];
+        }
+        if (total == 0.f) throw Error(FL_ERR_BAD_ARGUMENT, "Failed to sample next token: all weights zero");
+        // UniformFloat::<f32>::new(0, total) and one sample
+        float scale = total;
+        const float max_rand = 1.0f - 1.1920929e-07f;
+        while (mul_rn(scale, max_rand) >= total) { uint32_t b; std::memcpy(&b, &scale, 4); b -= 1; std::memcpy(&scale, &b, 4); }
+        const uint32_t bits = (rng_.next_u32() >> 9) | 0x3f800000u;
+        float v12; std::memcpy(&v12, &bits, 4);
+        const float chosen = mul_rn(v12 - 1.0f, scale);
+        // partition_point(|w| w <= chosen) over the n-1 cumulative weights
+        float cum = prs_[0];
+        size_t idx = 0;
+        while (idx < n - 1 && cum <= chosen) { idx++; cum += prs_[idx]; }
+        return (uint32_t)idx;
+    }
+
+   private:
+    static float mul_rn(float a, float b) { volatile float r = a * b; return r; }     // a product, never fused with an add
+    StdRng rng_;
+    bool sampling_ = false;
+    double temperature_ = 0;
+    std::vector<float> prs_;
+};
+
 template <class M>
 struct Model {                                // mod.rs:342-361
     M model;
@@ -424,8 +517,7 @@ struct Model {                                // mod.rs:342-361
     std::vector<uint32_t> generate_ids(const std::vector<uint32_t> &prompt, size_t max_tokens, float temperature,
                                        std::optional<uint32_t> eos = std::nullopt) {
         cache = M::initialize_cache(device, dtype);                       // mod.rs:370
-        if (!(temperature < 1e-7f))                                        // LogitsProcessor::new(seed, Some(t), None)
-            throw Error(FL_ERR_UNSUPPORTED, "sampling with temperature >= 1e-7 is outside the accelerated path (greedy only)");
+        LogitsProcessor logits_processor(0, (double)temperature);         // mod.rs:373-374 (Default::default() seed)
         if (prompt.empty()) throw Error(FL_ERR_BAD_ARGUMENT, "Tokenization error: empty prompt");
         Tensor input = Tensor::from_ids(prompt);                           // mod.rs:386-394
         std::vector<uint32_t> output_ids;
@@ -434,7 +526,7 @@ struct Model {                                // mod.rs:342-361
         Tensor logits = model.forward(input, pos, cache); forwards++;      // mod.rs:402-405
         pos += prompt.size();                                              // mod.rs:408
         for (size_t i = 0; i < max_tokens; i++) {                          // mod.rs:411
-            const uint32_t next = argmax_last(logits.f32(), (size_t)logits.elem_count());   // mod.rs:421-428
+            const uint32_t next = logits_processor.sample(logits.f32(), (size_t)logits.elem_count());   // mod.rs:421-428
             if (eos && next == *eos) break;                                // mod.rs:431-436
             output_ids.push_back(next);                                    // mod.rs:438
             Tensor next_input = Tensor::from_ids({next});                  // mod.rs:441-444

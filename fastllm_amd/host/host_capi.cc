@@ -149,6 +149,23 @@ int flh_generate(void *hv, const uint32_t *prompt, size_t T, size_t max_tokens, 
     });
 }
 
+// LogitsProcessor::new(seed, temperature, None) / .sample (mod.rs:373-374,425-428); has_temperature 0 = None
+int flh_logits_processor_new(uint64_t seed, int has_temperature, double temperature, void **out) {
+    return guard([&] {
+        *out = new LogitsProcessor(seed, has_temperature ? std::optional<double>(temperature) : std::nullopt);
+        return 0;
+    });
+}
+int flh_logits_processor_sample(void *lp, const float *logits, size_t n, uint32_t *token_out, uint64_t *draws_out) {
+    return guard([&] {
+        LogitsProcessor *p = static_cast<LogitsProcessor *>(lp);
+        *token_out = p->sample(logits, n);
+        if (draws_out) *draws_out = p->draws();
+        return 0;
+    });
+}
+void flh_logits_processor_free(void *lp) { delete static_cast<LogitsProcessor *>(lp); }
+
 // ModelInitializer::forward through the model's own cache object (trait-level call)
 int flh_forward(void *hv, const uint32_t *ids, size_t T, size_t pos, float *logits_out, size_t *n_logits) {
     return guard([&] {

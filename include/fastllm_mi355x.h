@@ -190,6 +190,23 @@ int fl_forward_argmax(fl_model *m, fl_cache *c, const uint32_t *ids, size_t T, s
 int fl_decode_greedy(fl_model *m, fl_cache *c, uint32_t first_token, size_t pos, size_t n_steps,
                      int64_t eos, uint32_t *tokens_out, size_t *n_out);
 
+/* LogitsProcessor::new(seed, Some(temperature), None) + .sample() (mod.rs:373-374,425-428) on the device.
+ * temperature < 1e-7 is ArgMax, as in candle.  Otherwise Sampling::All: softmax(logits / temperature) in
+ * fp32, then rand 0.8's WeightedIndex<f32> driven by StdRng::seed_from_u64(seed) (ChaCha12); one u32 word of
+ * the stream is consumed per sampled token.  The reference builds a fresh processor with seed 0 per
+ * request, samples the first token from the prefill logits and goes on in the loop: here that is
+ *   fl_forward_sample(.., {t, 0, 0}, &tok);  fl_decode_sample(.., tok, pos, n, eos, {t, 0, 1}, ..)
+ * (draws_done = words already consumed, so one request may span several calls). */
+typedef struct fl_sampling {
+    double   temperature;
+    uint64_t seed;
+    uint64_t draws_done;
+} fl_sampling;
+int fl_forward_sample(fl_model *m, fl_cache *c, const uint32_t *ids, size_t T, size_t pos,
+                      const fl_sampling *sampling, uint32_t *token_out);
+int fl_decode_sample(fl_model *m, fl_cache *c, uint32_t first_token, size_t pos, size_t n_steps, int64_t eos,
+                     const fl_sampling *sampling, uint32_t *tokens_out, size_t *n_out);
+
 int fl_synchronize(fl_model *m);
 
 /* Which slice of a full HF tensor does tp_rank own?  Pure host function (no GPU):
@@ -222,6 +239,10 @@ int fl_tune(const char *key, int value);
  * up = rows [N/2,N); y is [T, N/2]).  iters > 0 with ms_out != NULL times `iters` launches. */
 int fl_op_linear(const void *x, const void *w, const float *bias, int64_t T, int64_t N, int64_t K,
                  int32_t dtype, int32_t epilogue, float *y, int32_t iters, double *ms_out);
+
+/* The token-selection kernel alone, for unit tests: `n_draws` successive selections from one host logits
+ * vector (consuming successive words of the seeded stream; ArgMax when temperature < 1e-7). */
+int fl_op_sample(const float *logits, int64_t V, const fl_sampling *sampling, int64_t n_draws, uint32_t *tokens_out);
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,16 @@ def lib():
         L.orc_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int64, C.c_int,
                                    C.c_void_p, C.c_void_p]
         L.orc_last_error.restype = C.c_char_p
+        L.orc_chacha_block.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+        L.orc_chacha_block.restype = None
+        L.orc_rng_seed_from_u64.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_rng_seed_from_u64.restype = None
+        L.orc_rng_next_u32.argtypes = [C.c_void_p]
+        L.orc_rng_next_u32.restype = C.c_uint32
+        L.orc_sampler_init.argtypes = [C.c_void_p, C.c_uint64, C.c_double]
+        L.orc_sampler_init.restype = None
+        L.orc_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.orc_sample.restype = C.c_uint32
         _LIB = L
     return _LIB
 
@@ -219,3 +229,52 @@ class OracleCache:
 def argmax(logits):
     a = np.ascontiguousarray(logits, dtype=np.float32)
     return int(lib().orc_argmax(a.ctypes.data, a.size))
+
+
+class OrcRng(C.Structure):
+    _fields_ = [("key", C.c_uint32 * 8), ("word", C.c_uint64)]
+
+
+class OrcSamplerS(C.Structure):
+    _fields_ = [("rng", OrcRng), ("temperature", C.c_double), ("argmax", C.c_int)]
+
+
+class OrcSampleInfo(C.Structure):
+    _fields_ = [("u", C.c_uint32), ("chosen", C.c_float), ("total", C.c_float), ("cum_lo", C.c_float),
+                ("cum_hi", C.c_float), ("p", C.c_float)]
+
+
+def chacha_block(key_words, counter, rounds):
+    key = (C.c_uint32 * 8)(*key_words)
+    out = (C.c_uint32 * 16)()
+    lib().orc_chacha_block(key, counter, rounds, out)
+    return list(out)
+
+
+class Sampler:
+    """LogitsProcessor::new(seed, temperature, None) of the reference's generate loop (ref_sampler.c).
+    temperature None -> ArgMax."""
+
+    def __init__(self, seed=0, temperature=None):
+        self._s = OrcSamplerS()
+        lib().orc_sampler_init(C.byref(self._s), seed, -1.0 if temperature is None else float(temperature))
+
+    @property
+    def key(self):
+        return list(self._s.rng.key)
+
+    @property
+    def draws(self):
+        return int(self._s.rng.word)
+
+    def next_u32(self):
+        return int(lib().orc_rng_next_u32(C.byref(self._s.rng)))
+
+    def sample(self, logits, want_info=False):
+        a = np.ascontiguousarray(logits, dtype=np.float32)
+        scratch = np.empty_like(a)
+        info = OrcSampleInfo()
+        tok = int(lib().orc_sample(C.byref(self._s), a.ctypes.data, a.size, scratch.ctypes.data, C.byref(info)))
+        if want_info:
+            return tok, dict(u=info.u, chosen=info.chosen, total=info.total, cum_lo=info.cum_lo, cum_hi=info.cum_hi, p=info.p)
+        return tok
