@@ -269,6 +269,132 @@ __device__ inline float sequential_sum(float *__restrict__ p, int V, float *tile
     return bcast[0];
 }
 
+// The same left-to-right fp32 sum, bit for bit, without walking V dependent adds.
+//
+// While the running sum s stays inside one binade [2^k, 2^(k+1)) it is an integer multiple m*q of
+// q = 2^(k-23), and fl(s + a) = (m + r)*q where r = round-to-nearest-even of a/q -- the tie (a/q = n + 1/2)
+// goes by the parity of m + n, nothing else about m matters.  So a run of elements inside one binade
+// advances m by an integer that depends only on the parity of the incoming m: every thread computes both
+// candidates (inc[0], inc[1]) for its contiguous run in parallel, using a binade guessed from an
+// ordinary block scan, and one lane then chains the 1024 runs with integer adds, checking each guess
+// exactly (incoming exponent == k, outgoing m <= 2^24).  Runs that cross a binade, start at 0 or sit too
+// close to a power of two to be guessed are "slow": their elements are parked in LDS and the lane adds
+// them one by one in fp32.  A distribution crosses ~25 binades on its way to 1, so a few dozen runs
+// are slow and the rest cost one chain step each.  Measured (MI355X, one workgroup): the chain step is ~45
+// scalar instructions at a single wave's issue rate (one per ~5 cycles), so the 1024 steps take ~120 us; the
+// one-lane walk costs ~7 cycles per element, i.e. the two meet at V ~ 32k and ordered_sum is 2.6x faster at
+// Qwen2's V = 152k.  Next step: compose same-binade stretches with a parity-transducer scan (the step map
+// m -> m + inc[m & 1] is associative on (inc[0], inc[1])) so that the serial part is one step per stretch.
+constexpr int kSlowSlots = 56;          // LDS slots for slow runs (more fall back to global reads)
+constexpr int kMaxRun = 152;            // elements per thread: V <= 1024 * 152 = 155648 (Qwen2: 152064)
+struct OrderedSumLds {
+    float s_in[1025];                   // exact running sum entering each run (s_in[1024] = total)
+    int inc0[1024], inc1[1024];         // mantissa increment of a fast run for even / odd incoming mantissa
+    short kexp[1024];                   // guessed biased exponent of a fast run, -1: slow
+    short slot[1024];                   // LDS slot of a slow run, -1: read from global
+    float wtot[16];
+    int nslots;
+    float parked[kSlowSlots * kMaxRun];
+};
+
+// a slow run, one fp32 add at a time (wave-uniform: every lane computes the same chain)
+__device__ inline uint32_t walk_run(uint32_t sbits, const float *__restrict__ p, int c0, int c1, int slot, const float *parked) {
+    float s = __uint_as_float(sbits);
+    if (slot >= 0) {
+        const float *q = parked + slot * kMaxRun;                 // 16-byte aligned: kMaxRun % 4 == 0
+        const int n = c1 - c0;
+        int j = 0;
+        for (; j + 8 <= n; j += 8) {                              // two b128 reads per 8 dependent adds
+            const float4v a = *reinterpret_cast<const float4v *>(q + j), b = *reinterpret_cast<const float4v *>(q + j + 4);
+            s = __fadd_rn(s, a[0]); s = __fadd_rn(s, a[1]); s = __fadd_rn(s, a[2]); s = __fadd_rn(s, a[3]);
+            s = __fadd_rn(s, b[0]); s = __fadd_rn(s, b[1]); s = __fadd_rn(s, b[2]); s = __fadd_rn(s, b[3]);
+        }
+        for (; j < n; j++) s = __fadd_rn(s, q[j]);
+    }
+    else for (int i = c0; i < c1; i++) s = __fadd_rn(s, p[i]);
+    return __float_as_uint(s);
+}
+
+__device__ inline float ordered_sum(const float *__restrict__ p, int V, OrderedSumLds &L) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int run = ((V + 1023) / 1024 + 3) & ~3;
+    const int i0 = min(V, tid * run), i1 = min(V, i0 + run), n = i1 - i0;
+    const bool vec = (V & 3) == 0;
+    // phase A: estimated prefix (any order will do: it only picks the binade to try)
+    float cs = 0.f;
+    if (vec) for (int i = i0; i < i1; i += 4) { const float4v v = *reinterpret_cast<const float4v *>(p + i); cs += (v[0] + v[1]) + (v[2] + v[3]); }
+    else for (int i = i0; i < i1; i++) cs += p[i];
+    float inc = cs;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float up = __shfl_up(inc, o, 64); if (lane >= o) inc += up; }
+    if (tid == 0) L.nslots = 0;
+    __syncthreads();
+    if (lane == 63) L.wtot[wave] = inc;
+    __syncthreads();
+    float wbase = 0.f;
+    for (int w = 0; w < wave; w++) wbase += L.wtot[w];
+    const float est_out = wbase + inc, est_in = est_out - cs;
+    // phase B: classify the run and, if it looks like it stays in one binade, take both increments
+    const uint32_t eb = __float_as_uint(est_in) >> 23;              // biased exponent (est_in >= 0)
+    const float lo = __uint_as_float(eb << 23), hi = __uint_as_float((eb + 1) << 23);
+    const bool fast = n > 0 && eb > 24 && eb < 250 && est_in >= lo * 1.001f && est_out <= hi * 0.999f;
+    short myslot = -1;
+    if (fast) {
+        const float inv_q = __uint_as_float((uint32_t)(127 + 150 - (int)eb) << 23);      // 2^(23 - k), k = eb - 127
+        int a0 = 0, a1 = 1;
+        auto step = [&](float a) {
+            const float t = a * inv_q;                              // exact (power of two), < 2^24 in a one-binade run
+            const float fl = floorf(t);
+            const float fr = t - fl;                                // exact
+            const int nn = (int)fl + (fr > 0.5f ? 1 : 0);
+            const int tie = fr == 0.5f ? 1 : 0;
+            a0 += nn + (tie & (a0 + (int)fl));
+            a1 += nn + (tie & (a1 + (int)fl));
+        };
+        if (vec) for (int i = i0; i < i1; i += 4) { const float4v v = *reinterpret_cast<const float4v *>(p + i); step(v[0]); step(v[1]); step(v[2]); step(v[3]); }
+        else for (int i = i0; i < i1; i++) step(p[i]);
+        L.inc0[tid] = a0; L.inc1[tid] = a1 - 1;
+        L.kexp[tid] = (short)eb;
+    } else {
+        L.kexp[tid] = -1;
+        if (n > 0 && n <= kMaxRun) {
+            const int sl = atomicAdd(&L.nslots, 1);
+            if (sl < kSlowSlots) { myslot = (short)sl; for (int i = i0; i < i1; i++) L.parked[sl * kMaxRun + (i - i0)] = p[i]; }
+        }
+    }
+    L.slot[tid] = myslot;
+    __syncthreads();
+    // phase C: wave 0 chains the runs.  The per-run data sits in vector registers (lane j = run 64g + j)
+    // and is read back with v_readlane, so the chain itself is wave-uniform integer arithmetic; a slow
+    // run is walked in fp32 by a separate function.
+    if (wave == 0) {
+        uint32_t sb = 0;                                             // bits of the running sum (>= 0)
+        for (int g = 0; g < 16; g++) {
+            const int c = g * 64 + lane;
+            const int ke_v = L.kexp[c], a0_v = L.inc0[c], a1_v = L.inc1[c], sl_v = L.slot[c];
+            uint32_t sin_v = 0;
+#pragma unroll 1
+            for (int j = 0; j < 64; j++) {
+                if (lane == j) sin_v = sb;
+                const int c0 = min(V, (g * 64 + j) * run), c1 = min(V, c0 + run);
+                const int ke = __builtin_amdgcn_readlane(ke_v, j);
+                const int a0 = __builtin_amdgcn_readlane(a0_v, j), a1 = __builtin_amdgcn_readlane(a1_v, j);
+                // branch-free fast step: the new bits are (ke << 23) + (m2 - 2^23), also right when m2 == 2^24
+                const uint32_t m = (sb & 0x7fffffu) | 0x800000u;
+                const uint32_t m2 = m + (uint32_t)(a0 + (int)(m & 1) * (a1 - a0));
+                const bool ok = (ke >= 0) & ((int)(sb >> 23) == ke) & (m2 <= 0x1000000u);
+                const uint32_t fast_sb = ((uint32_t)ke << 23) + (m2 - 0x800000u);
+                if (!ok && c0 < c1) sb = __builtin_amdgcn_readfirstlane(walk_run(sb, p, c0, c1, __builtin_amdgcn_readlane(sl_v, j), L.parked));
+                else sb = (ok & (c0 < c1)) ? fast_sb : sb;
+            }
+            L.s_in[c] = __uint_as_float(sin_v);
+        }
+        if (lane == 0) L.s_in[1024] = __uint_as_float(sb);
+    }
+    __syncthreads();
+    return L.s_in[1024];
+}
+
 // Sampling::All { temperature } (candle-transformers LogitsProcessor over rand 0.8's WeightedIndex<f32>):
 //   prs = softmax(logits * (f32)(1/temperature));  total = sum(prs);  chosen = uniform[0,1) * total with
 //   uniform = f32::from_bits((next_u32() >> 9) | 0x3f800000) - 1;  token = #{ j < V-1 : prs[0]+..+prs[j] <= chosen }.
@@ -279,9 +405,14 @@ __device__ inline float sequential_sum(float *__restrict__ p, int V, float *tile
 // exp is evaluated in fp64 and rounded, which reproduces a correctly rounded expf (glibc's, which Rust's
 // f32::exp calls) except in ~1e-9 of the cases.
 __device__ inline int sample_all(const float *__restrict__ logits, int V, SampleState *__restrict__ ss, float *__restrict__ p,
-                                 float *red, float *tiles, float *bcast, int *count) {
+                                 float *red, unsigned char *lds, float *bcast, int *count) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float mul = ss->inv_temp;
+    // on == 1: ordered_sum (parallel, bit-identical to the walk); on == 2 or a vocabulary beyond its run
+    // size: sequential_sum (the plain walk, kept as the cross-check)
+    const bool walk = ss->on == 2 || V > 1024 * kMaxRun;
+    OrderedSumLds &L = *reinterpret_cast<OrderedSumLds *>(lds);
+    float *tiles = reinterpret_cast<float *>(lds);
     float mx = -INFINITY;
     for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, __fmul_rn(logits[i], mul));
     mx = wave_max(mx);
@@ -291,11 +422,12 @@ __device__ inline int sample_all(const float *__restrict__ logits, int V, Sample
     for (int w = 1; w < 16; w++) mx = fmaxf(mx, red[w]);
     for (int i = tid; i < V; i += 1024) p[i] = (float)exp((double)__fsub_rn(__fmul_rn(logits[i], mul), mx));
     __syncthreads();
-    const float S = sequential_sum(p, V, tiles, bcast, false);
+    const float S = walk ? sequential_sum(p, V, tiles, bcast, false) : ordered_sum(p, V, L);
     for (int i = tid; i < V; i += 1024) p[i] = __fdiv_rn(p[i], S);
     if (tid == 0) *count = 0;
     __syncthreads();
-    const float total = sequential_sum(p, V, tiles, bcast, true);       // p[] now holds the cumulative weights
+    // walk: p[] is replaced by the cumulative weights; ordered: L.s_in[] holds the sum entering every run
+    const float total = walk ? sequential_sum(p, V, tiles, bcast, true) : ordered_sum(p, V, L);
     if (tid == 0) {
         // UniformFloat::new(0, total): scale = total, lowered by ulps while scale * (1 - 2^-23) >= total
         float scale = total;
@@ -307,12 +439,25 @@ __device__ inline int sample_all(const float *__restrict__ logits, int V, Sample
     }
     __syncthreads();
     const float chosen = bcast[1];
+    // partition_point: how many cumulative weights are <= chosen (chosen < total, so the last one never is)
     int n = 0;
-    for (int i = tid; i < V - 1; i += 1024) n += p[i] <= chosen ? 1 : 0;      // partition_point over the first V-1
+    if (walk) {
+        for (int i = tid; i < V - 1; i += 1024) n += p[i] <= chosen ? 1 : 0;
+    } else {
+        const int run = ((V + 1023) / 1024 + 3) & ~3;
+        const int i0 = min(V, tid * run), i1 = min(V, i0 + run);
+        if (i0 < i1) {
+            if (L.s_in[tid + 1] <= chosen) n = i1 - i0;            // the whole run is below (sums only grow)
+            else if (L.s_in[tid] <= chosen) {                       // the boundary run: walk it from its exact start
+                float cum = L.s_in[tid];
+                for (int i = i0; i < i1; i++) { cum = __fadd_rn(cum, p[i]); if (cum <= chosen) n++; else break; }
+            }
+        }
+    }
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
     if (lane == 0 && n) atomicAdd(count, n);
     __syncthreads();
-    return *count;
+    return min(*count, V - 1);
 }
 
 __global__ __launch_bounds__(1024) void select_advance_kernel(const float *__restrict__ logits, int V,
@@ -321,10 +466,11 @@ __global__ __launch_bounds__(1024) void select_advance_kernel(const float *__res
                                                               int advance) {
     __shared__ float bv[16], bcast[2];
     __shared__ int bi[16], count;
-    __shared__ float tiles[2 * kSelTile];
+    constexpr size_t kLds = sizeof(OrderedSumLds) > 2 * kSelTile * 4 ? sizeof(OrderedSumLds) : 2 * kSelTile * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
     const int tid = threadIdx.x;
     int idx;
-    if (ss->on) idx = sample_all(logits, V, ss, scratch, bv, tiles, bcast, &count);
+    if (ss->on) idx = sample_all(logits, V, ss, scratch, bv, lds, bcast, &count);
     else idx = argmax_last(logits, V, bv, bi);
     if (tid == 0) {
         const uint32_t tok = (uint32_t)idx;

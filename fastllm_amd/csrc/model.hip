@@ -132,6 +132,7 @@ Model::~Model() {
 
 Cache::~Cache() {
     if (!m) return;
+    std::lock_guard<std::mutex> lock(m->mu);       // not while another thread captures on the model's stream
     for (size_t i = 0; i < shards.size(); i++) {
         (void)hipSetDevice(m->shards[i].device);
         (void)hipStreamSynchronize(m->shards[i].stream);
@@ -604,6 +605,9 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
     const Dims &D = m->D;
     std::unique_ptr<Cache> c(new Cache());
     c->m = m; c->max_seq = max_seq; c->len = 0;
+    // Under the model mutex and on the model's stream: another thread may be capturing its decode graph
+    // on that stream, and a legacy-stream memset would try to join the capture.
+    std::lock_guard<std::mutex> lock(m->mu);
     c->seq_alloc = (max_seq + 31) / 32 * 32;
     c->v_transposed = env_int("FL_ATTN_MFMA", 1) != 0 && attn_mfma_supported(m->dtype, m->shards[0].Hs, m->shards[0].Hkvs, D.d);
     // decode attention splits S so that the K/V stream of one kv head is spread over many CUs
@@ -634,21 +638,22 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
         FL_TRY(dev_alloc(cs.allocs, &cs.k, kvb, nullptr));
         FL_TRY(dev_alloc(cs.allocs, &cs.v, kvb, nullptr));
         // finite contents everywhere: the MFMA kernel multiplies masked keys' values by p = 0
-        FL_HIP(hipMemset(cs.k, 0, kvb));
-        FL_HIP(hipMemset(cs.v, 0, kvb));
+        FL_HIP(hipMemsetAsync(cs.k, 0, kvb, sh.stream));
+        FL_HIP(hipMemsetAsync(cs.v, 0, kvb, sh.stream));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.st, sizeof(StepState), nullptr));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.out_tokens, kOutTokensCap * 4, nullptr));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.part_m, (size_t)sh.Hs * c->nsplit * 4, nullptr));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.part_l, (size_t)sh.Hs * c->nsplit * 4, nullptr));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.part_o, (size_t)sh.Hs * c->nsplit * D.d * 4, nullptr));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.counters, (size_t)sh.Hs * 4, nullptr));
-        FL_HIP(hipMemset(cs.counters, 0, (size_t)sh.Hs * 4));
+        FL_HIP(hipMemsetAsync(cs.counters, 0, (size_t)sh.Hs * 4, sh.stream));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.ss, sizeof(SampleState), nullptr));
-        FL_HIP(hipMemset(cs.ss, 0, sizeof(SampleState)));
+        FL_HIP(hipMemsetAsync(cs.ss, 0, sizeof(SampleState), sh.stream));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.sel_scratch, (size_t)D.V * 4, nullptr));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.heads_done, (size_t)D.L * 4, nullptr));
-        FL_HIP(hipMemset(cs.heads_done, 0, (size_t)D.L * 4));
-        FL_HIP(hipMemset(cs.st, 0, sizeof(StepState)));
+        FL_HIP(hipMemsetAsync(cs.heads_done, 0, (size_t)D.L * 4, sh.stream));
+        FL_HIP(hipMemsetAsync(cs.st, 0, sizeof(StepState), sh.stream));
+        FL_HIP(hipStreamSynchronize(sh.stream));
     }
     m->refs.fetch_add(1);
     *out = c.release();
@@ -671,7 +676,7 @@ __global__ void set_state_kernel(StepState *st, uint32_t token, uint32_t pos, ui
 SampleState make_sampler(const fl_sampling *sp) {
     SampleState s{};
     if (!sp || !(sp->temperature >= 1e-7)) return s;
-    s.on = 1;
+    s.on = env_int("FL_SAMPLE_WALK", 0) ? 2 : 1;       // 2: plain one-lane walk instead of ordered_sum (cross-check)
     s.inv_temp = (float)(1.0 / sp->temperature);
     uint64_t state = sp->seed;
     for (int i = 0; i < 8; i++) {

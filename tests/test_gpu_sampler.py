@@ -41,7 +41,7 @@ def compare_draws(got, lg, seed, temperature, draws_done=0):
 
 @pytest.mark.parametrize("V,temperature,seed", [(320, 0.8, 0), (32000, 1.0, 0), (32000, 0.3, 11), (152064, 0.7, 0),
                                                 (151, 1.5, 3), (50257, 2.0, 123456789)])
-def test_kernel_draws_match_oracle(fa, V, temperature, seed):
+def test_kernel_draws_match_oracle(fa, V, temperature, seed, monkeypatch):
     rs = np.random.RandomState(V + seed)
     lg = (rs.randn(V) * 2.5).astype(np.float32)
     n = 400
@@ -49,6 +49,32 @@ def test_kernel_draws_match_oracle(fa, V, temperature, seed):
     assert got.max() < V
     n_diff = compare_draws(got, lg, seed, temperature)
     assert n_diff <= 1, n_diff
+    # the parallel ordered sum is the one-lane walk, bit for bit
+    monkeypatch.setenv("FL_SAMPLE_WALK", "1")
+    np.testing.assert_array_equal(fa.op_sample(lg, n, temperature, seed), got)
+
+
+@pytest.mark.parametrize("shape", ["flat", "peaked", "one_hot", "tiny_tail", "ties"])
+def test_ordered_sum_equals_walk_on_hard_inputs(fa, shape, monkeypatch):
+    """Distributions that stress the binade bookkeeping: totals that sit at a power of two, masses that
+    vanish against the running sum, exact half-ulp ties (values that are small powers of two)."""
+    V = 32768
+    rs = np.random.RandomState(7)
+    if shape == "flat":
+        lg = np.zeros(V, np.float32)                      # p = 1/V exactly: every add is exact, total = 1.0
+    elif shape == "peaked":
+        lg = (rs.randn(V) * 0.5).astype(np.float32); lg[12345] = 40.0
+    elif shape == "one_hot":
+        lg = np.full(V, -200.0, np.float32); lg[777] = 0.0  # all other exps are 0 / denormal
+    elif shape == "tiny_tail":
+        lg = np.concatenate([np.full(64, 5.0), np.full(V - 64, -12.0)]).astype(np.float32)
+    else:
+        lg = (np.log(2.0) * rs.randint(-20, 1, size=V)).astype(np.float32)   # powers of two: ties everywhere
+    a = fa.op_sample(lg, 300, 1.0, 1)
+    n_diff = compare_draws(a, lg, 1, 1.0)
+    assert n_diff <= 1, n_diff
+    monkeypatch.setenv("FL_SAMPLE_WALK", "1")
+    np.testing.assert_array_equal(fa.op_sample(lg, 300, 1.0, 1), a)
 
 
 def test_kernel_stream_position(fa):
