@@ -30,11 +30,11 @@ def make(host, name, dtype=0):
     return h, cfg, w
 
 
-def generate(host, h, prompt, n, eos=-1):
+def generate(host, h, prompt, n, eos=-1, temperature=0.0):
     prompt = np.ascontiguousarray(prompt, dtype=np.uint32)
     out = np.zeros(n, dtype=np.uint32)
     n_out, fw = C.c_size_t(0), C.c_size_t(0)
-    rc = host.flh_generate(h, prompt.ctypes.data, prompt.size, n, 0.0, eos, out.ctypes.data, C.byref(n_out), C.byref(fw))
+    rc = host.flh_generate(h, prompt.ctypes.data, prompt.size, n, temperature, eos, out.ctypes.data, C.byref(n_out), C.byref(fw))
     assert rc == 0, host.flh_last_error()
     return out[: n_out.value], fw.value
 
@@ -56,6 +56,29 @@ def test_generate_matches_oracle_generate(host, name, mode, monkeypatch):
     # a second request starts from a fresh cache (mod.rs:370)
     got2, _ = generate(host, h, prompt, 12)
     np.testing.assert_array_equal(got2, want)
+    host.flh_model_destroy(h)
+
+
+def test_generate_with_temperature_host_and_device_samplers_agree(host, monkeypatch):
+    """temperature > 0 (mod.rs:373-374): the mirror's host-side LogitsProcessor over fl_forward logits -- the
+    reference's own loop shape -- and the device-side sampler (fl_forward_sample + fl_decode_sample) draw the
+    same tokens from the same seed-0 stream."""
+    import fastllm_amd as fa
+    monkeypatch.setenv("FASTLLM_POS_MODE", "tokens")
+    monkeypatch.setenv("FASTLLM_MAX_SEQ", "64")
+    h, cfg, w = make(host, "llama_a", dtype=0)
+    prompt = synth.prompt_ids(cfg, 8)
+    got, forwards = generate(host, h, prompt, 16, temperature=0.8)
+    assert forwards == 17 and len(got) == 16
+    greedy, _ = generate(host, h, prompt, 16)
+    assert not np.array_equal(got, greedy)                      # it does sample
+    again, _ = generate(host, h, prompt, 16, temperature=0.8)   # a fresh seed-0 processor per request
+    np.testing.assert_array_equal(again, got)
+    gm = fa.Model(cfg, w, dtype="f32")
+    c = gm.new_cache(64)
+    first = gm.forward_sample(c, prompt, 0, 0.8)
+    rest = gm.decode_sample(c, first, len(prompt), 15, 0.8, draws_done=1)
+    np.testing.assert_array_equal(np.concatenate([[first], rest]).astype(np.uint32), got)
     host.flh_model_destroy(h)
 
 
