@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfastllm_mi355x.so")
+LIB_PATH = os.environ.get("FL_LIB_PATH") or os.path.join(_HERE, "lib", "libfastllm_mi355x.so")   # FL_LIB_PATH: kernel-variant experiments
 
 FAMILY = {"llama": 0, "mistral": 1, "qwen2": 2}
 F32, BF16, F16 = 0, 1, 2
@@ -94,6 +94,11 @@ def lib():
         L.fl_forward_sample.argtypes = [vp, vp, vp, sz, sz, C.POINTER(FlSampling), vp]
         L.fl_decode_sample.argtypes = [vp, vp, C.c_uint32, sz, sz, C.c_int64, C.POINTER(FlSampling), vp, C.POINTER(sz)]
         L.fl_op_sample.argtypes = [vp, C.c_int64, C.POINTER(FlSampling), C.c_int64, vp]
+        L.fl_batch_create.argtypes = [vp, vp, sz, C.POINTER(vp)]
+        L.fl_batch_destroy.argtypes = [vp]
+        L.fl_batch_destroy.restype = None
+        L.fl_batch_forward.argtypes = [vp, vp, vp, vp, vp]
+        L.fl_batch_decode.argtypes = [vp, vp, vp, sz, C.c_int64, C.POINTER(FlSampling), vp, vp]
         L.fl_synchronize.argtypes = [vp]
         L.fl_tp_slice.argtypes = [C.POINTER(FlConfig), C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
         L.fl_profile_begin.argtypes = [vp]
@@ -276,6 +281,48 @@ class Model:
     def close(self):
         if getattr(self, "_h", None):
             lib().fl_model_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """fl_batch: up to 8 caches of one model decoded together."""
+
+    def __init__(self, model, caches):
+        self._model, self._caches = model, list(caches)
+        arr = (C.c_void_p * len(caches))(*[c._h for c in caches])
+        h = C.c_void_p()
+        _check(lib().fl_batch_create(model._h, arr, len(caches), C.byref(h)))
+        self._h = h
+        self.n = len(caches)
+
+    def forward(self, tokens, pos, want_logits=True):
+        tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        lg = np.empty((self.n, self._model.V), dtype=np.float32) if want_logits else None
+        am = np.zeros(self.n, dtype=np.uint32)
+        _check(lib().fl_batch_forward(self._h, tokens.ctypes.data, pos.ctypes.data, lg.ctypes.data if want_logits else None,
+                                      am.ctypes.data))
+        return (lg, am) if want_logits else am
+
+    def decode(self, first_tokens, pos, n_steps, eos=-1, temperature=None, seed=0, draws_done=1):
+        first = np.ascontiguousarray(first_tokens, dtype=np.uint32)
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        out = np.zeros((self.n, max(n_steps, 1)), dtype=np.uint32)
+        n_out = np.zeros(self.n, dtype=np.uint64)
+        sp = FlSampling(temperature, seed, draws_done) if temperature is not None else None
+        _check(lib().fl_batch_decode(self._h, first.ctypes.data, pos.ctypes.data, n_steps, eos, C.byref(sp) if sp else None,
+                                     out.ctypes.data, n_out.ctypes.data))
+        return [out[i, : int(n_out[i])] for i in range(self.n)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().fl_batch_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -116,6 +116,28 @@ int fl_decode_sample(fl_model *m, fl_cache *c, uint32_t first_token, size_t pos,
     return decode_greedy(M(m), C(c), first_token, pos, n_steps, eos, tokens_out, n_out, sampling);
 }
 
+int fl_batch_create(fl_model *m, fl_cache *const *caches, size_t n, fl_batch **out) {
+    if (!out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null out");
+    Batch *b = nullptr;
+    FL_TRY(batch_create(M(m), reinterpret_cast<Cache *const *>(caches), n, &b));
+    *out = reinterpret_cast<fl_batch *>(b);
+    return FL_OK;
+}
+void fl_batch_destroy(fl_batch *b) {
+    if (!b) return;
+    Batch *bb = reinterpret_cast<Batch *>(b);
+    Model *m = bb->m;
+    delete bb;
+    if (m && m->refs.fetch_sub(1) == 1) delete m;
+}
+int fl_batch_forward(fl_batch *b, const uint32_t *tokens, const size_t *pos, float *logits_out, uint32_t *argmax_out) {
+    return batch_forward(reinterpret_cast<Batch *>(b), tokens, pos, logits_out, argmax_out);
+}
+int fl_batch_decode(fl_batch *b, const uint32_t *first_tokens, const size_t *pos, size_t n_steps, int64_t eos,
+                    const fl_sampling *sampling, uint32_t *tokens_out, size_t *n_out) {
+    return batch_decode(reinterpret_cast<Batch *>(b), first_tokens, pos, n_steps, eos, sampling, tokens_out, n_out);
+}
+
 int fl_synchronize(fl_model *m) {
     if (!m) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null model");
     for (auto &sh : M(m)->shards) { FL_HIP(hipSetDevice(sh.device)); FL_HIP(hipStreamSynchronize(sh.stream)); }

@@ -25,14 +25,12 @@ namespace fl {
 
 // ------------------------------------------------------------------------------- decode
 template <int D, int GMAX, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
-                                                               const bf16_t *__restrict__ vT, const StepState *__restrict__ st,
-                                                               float *__restrict__ part_m, float *__restrict__ part_l,
-                                                               float *__restrict__ part_o, unsigned *__restrict__ counters,
-                                                               bf16_t *__restrict__ out, int H, int Hkv, int seq_alloc,
-                                                               float scale, int nsplit) {
-    __shared__ float lds[NW * GMAX * (D + 2)];
-    __shared__ int is_last;
+__device__ inline void attn_decode_mfma_body(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
+                                             const bf16_t *__restrict__ vT, const StepState *__restrict__ st,
+                                             float *__restrict__ part_m, float *__restrict__ part_l,
+                                             float *__restrict__ part_o, unsigned *__restrict__ counters,
+                                             bf16_t *__restrict__ out, int H, int Hkv, int seq_alloc,
+                                             float scale, int nsplit, float *lds, int *is_last) {
     const int hk = blockIdx.x, split = blockIdx.y;
     const int G = H / Hkv, hq0 = hk * G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -61,7 +59,35 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const bf16_t 
 
     mfma_state_to_lds<D, GMAX>(s, lds, wave, G, lane);
     __syncthreads();
-    decode_tail<bf16_t, D, GMAX, NW>(lds, &is_last, G, hq0, hk, split, nsplit, part_m, part_l, part_o, counters, out);
+    decode_tail<bf16_t, D, GMAX, NW>(lds, is_last, G, hq0, hk, split, nsplit, part_m, part_l, part_o, counters, out);
+}
+
+template <int D, int GMAX, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
+                                                               const bf16_t *__restrict__ vT, const StepState *__restrict__ st,
+                                                               float *__restrict__ part_m, float *__restrict__ part_l,
+                                                               float *__restrict__ part_o, unsigned *__restrict__ counters,
+                                                               bf16_t *__restrict__ out, int H, int Hkv, int seq_alloc,
+                                                               float scale, int nsplit) {
+    __shared__ float lds[NW * GMAX * (D + 2)];
+    __shared__ int is_last;
+    attn_decode_mfma_body<D, GMAX, NW>(q, kc, vT, st, part_m, part_l, part_o, counters, out, H, Hkv, seq_alloc, scale, nsplit, lds, &is_last);
+}
+
+// The same for B sequences in one launch (blockIdx.z = sequence): each reads its own cache, length and
+// split scratch from its SeqRef; q / out are [B][H*D].  grid.y = the largest split count of the batch.
+template <int D, int GMAX, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_mfma_batch_kernel(const bf16_t *__restrict__ q, const SeqRef *__restrict__ seqs,
+                                                                     size_t kv_layer_off, bf16_t *__restrict__ out, int H, int Hkv,
+                                                                     float scale) {
+    __shared__ float lds[NW * GMAX * (D + 2)];
+    __shared__ int is_last;
+    const SeqRef sq = seqs[blockIdx.z];
+    if ((int)blockIdx.y >= sq.nsplit) return;                       // workgroup-uniform
+    const size_t off = kv_layer_off * (size_t)sq.seq_alloc;
+    attn_decode_mfma_body<D, GMAX, NW>(q + (size_t)blockIdx.z * H * D, reinterpret_cast<const bf16_t *>(sq.k) + off,
+                                       reinterpret_cast<const bf16_t *>(sq.v) + off, sq.st, sq.part_m, sq.part_l, sq.part_o,
+                                       sq.counters, out + (size_t)blockIdx.z * H * D, H, Hkv, sq.seq_alloc, scale, sq.nsplit, lds, &is_last);
 }
 
 template <int D, int GMAX, int NW>
@@ -96,6 +122,21 @@ int launch_attn_decode_mfma(Launcher &L, const void *q, const void *k_cache, con
     if (d == 128) { FL_GO(128) }
     if (d == 64) { FL_GO(64) }
 #undef FL_GO
+    FL_FAIL(FL_ERR_UNSUPPORTED, "mfma attention: head_dim %lld", (long long)d);
+}
+
+// batched decode: every sequence of the batch uses 4-wave split workgroups (its own nsplit >= 1)
+int launch_attn_decode_mfma_batch(Launcher &L, const void *q, const SeqRef *seqs_dev, int B, int max_nsplit, size_t kv_layer_off,
+                                  void *out, int64_t H, int64_t Hkv, int64_t d, float scale, double kv_bytes_hint) {
+    const int G = (int)(H / Hkv);
+    if (max_nsplit > 64 || max_nsplit < 1) FL_FAIL(FL_ERR_BAD_ARGUMENT, "attention: 1..64 splits");
+    dim3 grid((unsigned)Hkv, (unsigned)max_nsplit, (unsigned)B);
+#define FL_GOB(DD, GM)                                                                                                          \
+    return L.launch(KC_ATTN_DECODE, kv_bytes_hint, 0, attn_decode_mfma_batch_kernel<DD, GM, 4>, grid, dim3(256), 0, (const bf16_t *)q, \
+                    seqs_dev, kv_layer_off, (bf16_t *)out, (int)H, (int)Hkv, scale);
+    if (d == 128) { if (G <= 4) { FL_GOB(128, 4) } if (G <= 8) { FL_GOB(128, 8) } FL_GOB(128, 16) }
+    if (d == 64) { if (G <= 4) { FL_GOB(64, 4) } if (G <= 8) { FL_GOB(64, 8) } FL_GOB(64, 16) }
+#undef FL_GOB
     FL_FAIL(FL_ERR_UNSUPPORTED, "mfma attention: head_dim %lld", (long long)d);
 }
 

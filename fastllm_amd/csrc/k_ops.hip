@@ -460,14 +460,11 @@ __device__ inline int sample_all(const float *__restrict__ logits, int V, Sample
     return min(*count, V - 1);
 }
 
-__global__ __launch_bounds__(1024) void select_advance_kernel(const float *__restrict__ logits, int V,
-                                                              StepState *__restrict__ st, SampleState *__restrict__ ss,
-                                                              float *__restrict__ scratch, uint32_t *__restrict__ out_tokens,
-                                                              int advance) {
+__device__ inline void select_advance_body(const float *__restrict__ logits, int V, StepState *__restrict__ st,
+                                           SampleState *__restrict__ ss, float *__restrict__ scratch,
+                                           uint32_t *__restrict__ out_tokens, int advance, unsigned char *lds) {
     __shared__ float bv[16], bcast[2];
     __shared__ int bi[16], count;
-    constexpr size_t kLds = sizeof(OrderedSumLds) > 2 * kSelTile * 4 ? sizeof(OrderedSumLds) : 2 * kSelTile * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
     const int tid = threadIdx.x;
     int idx;
     if (ss->on) idx = sample_all(logits, V, ss, scratch, bv, lds, bcast, &count);
@@ -479,6 +476,29 @@ __global__ __launch_bounds__(1024) void select_advance_kernel(const float *__res
         if (st->eos >= 0 && tok == (uint32_t)st->eos) st->done = 1;
         if (advance) { st->pos += 1; st->len += 1; st->step += 1; }
     }
+}
+
+constexpr size_t kSelLds = sizeof(OrderedSumLds) > 2 * kSelTile * 4 ? sizeof(OrderedSumLds) : 2 * kSelTile * 4;
+
+__global__ __launch_bounds__(1024) void select_advance_kernel(const float *__restrict__ logits, int V,
+                                                              StepState *__restrict__ st, SampleState *__restrict__ ss,
+                                                              float *__restrict__ scratch, uint32_t *__restrict__ out_tokens,
+                                                              int advance) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kSelLds];
+    select_advance_body(logits, V, st, ss, scratch, out_tokens, advance, lds);
+}
+
+// one workgroup per sequence of a batch: logits [B][V], state and scratch from the SeqRef
+__global__ __launch_bounds__(1024) void select_advance_batch_kernel(const float *__restrict__ logits, int V,
+                                                                    const SeqRef *__restrict__ seqs, int advance) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kSelLds];
+    const SeqRef sq = seqs[blockIdx.x];
+    select_advance_body(logits + (size_t)blockIdx.x * V, V, sq.st, sq.ss, sq.sel_scratch, sq.out_tokens, advance, lds);
+}
+
+int launch_select_advance_batch(Launcher &L, const float *logits, int64_t V, const SeqRef *seqs_dev, int B, int advance) {
+    return L.launch(KC_ARGMAX, (double)V * 4 * B, 0, select_advance_batch_kernel, dim3((unsigned)B), dim3(1024), 0, logits, (int)V,
+                    seqs_dev, advance);
 }
 
 // scratch: V floats (probabilities / cumulative weights of the sampling path)

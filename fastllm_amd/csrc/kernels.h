@@ -67,6 +67,45 @@ int launch_gemv(Launcher &L, int dtype, const GemvArgs &a);
 bool gemv_norm_supported(int dtype, int64_t N, int64_t K);
 void gemv_set_tuning(int R, int U, int maxblocks, int maxblocks_norm);
 
+// ---- batched decode (k_gemv_batch.hip): B <= 8 sequences share one read of the weights ------------
+// Per-sequence device state and buffers of a batch member (a view of its cache).
+struct SeqRef {
+    StepState *st;
+    SampleState *ss;
+    void *k, *v;                    // cache bases [L][Hkv][seq_alloc][d] / V^T [L][Hkv][d][seq_alloc]
+    float *part_m, *part_l, *part_o;
+    unsigned *counters;
+    uint32_t *out_tokens;
+    float *sel_scratch;
+    int seq_alloc, nsplit;
+};
+struct GemvBatchArgs {
+    const void *W = nullptr;        // [N,K] bf16
+    const float *bias = nullptr;
+    void *out = nullptr;            // EPI_F32: float [nks][B][N]; EPI_GATEUP: bf16 [B][N/2]
+    int N = 0, K = 0, epi = EPI_F32, pro = PRO_X, B = 1, nks = 1;
+    const void *x = nullptr;        // PRO_X: bf16 [B][K]
+    // PRO_NORM: x[b] = rmsnorm(x_in[b] + sum_s delta[s][b]) * norm_w, or of the embedding row of seqs[b].st->token
+    const float *x_in = nullptr, *delta = nullptr, *norm_w = nullptr;
+    int n_slab = 1; long long slab_stride = 0;
+    float eps = 0.f;
+    float *x_out = nullptr;         // [B][K] updated residual (must differ from x_in)
+    const void *embed = nullptr;
+    const SeqRef *seqs = nullptr;   // device array [B]
+    // EPI_QKV_ROPE
+    const float *cos_tab = nullptr, *sin_tab = nullptr;
+    void *q_out = nullptr;          // bf16 [B][H*d]
+    size_t kv_layer_off = 0;        // layer * Hkv * d: multiplied by the sequence's seq_alloc inside
+    int H = 0, Hkv = 0, d = 0, max_pos = 0;
+};
+int gemv_batch_ksplit(int B, int64_t K, int64_t N, int epi);
+int launch_gemv_batch(Launcher &L, const GemvBatchArgs &a);
+// q / out bf16 [B][H*d]; kv_layer_off = layer * Hkv * d (times each sequence's seq_alloc inside)
+int launch_attn_decode_mfma_batch(Launcher &L, const void *q, const SeqRef *seqs_dev, int B, int max_nsplit, size_t kv_layer_off,
+                                  void *out, int64_t H, int64_t Hkv, int64_t d, float scale, double kv_bytes_hint);
+// logits fp32 [B][V] -> every sequence's token / step state
+int launch_select_advance_batch(Launcher &L, const float *logits, int64_t V, const SeqRef *seqs_dev, int B, int advance);
+
 // dst row of gate/up pair q in the 16-interleaved fused layout: 16 gate rows then 16 up rows
 __host__ __device__ inline int64_t gateup_row(int64_t q, int is_up) { return (q / 16) * 32 + (q % 16) + (is_up ? 16 : 0); }
 

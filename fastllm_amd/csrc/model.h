@@ -127,6 +127,36 @@ struct Cache {
     ~Cache();
 };
 
+// A fixed set of B <= 8 caches of one model decoded together (k_gemv_batch.hip): one read of the weights
+// per step serves every sequence.  Single GPU, bf16, MFMA-attention shapes.
+constexpr int kMaxBatch = 8;
+struct Batch {
+    Model *m = nullptr;
+    std::vector<Cache *> caches;
+    int B = 0, max_nsplit = 1, nks_o = 1, nks_down = 1;
+    SeqRef *seqs_dev = nullptr;
+    float *x_res = nullptr, *x_res2 = nullptr;   // [B][h]
+    float *delta = nullptr;                      // [max(nks_o, nks_down)][B][h]
+    void *q = nullptr, *ao = nullptr;            // [B][H*d]
+    void *act = nullptr;                         // [B][Ip]
+    float *logits = nullptr;                     // [B][V]
+    uint32_t *host_tokens = nullptr;             // pinned [B][kBatchChunk]
+    StepState *host_states = nullptr;            // pinned [B]
+    hipGraphExec_t graph = nullptr;
+    bool graph_failed = false;
+    int warm_steps = 0;
+    std::vector<void *> allocs;
+    ~Batch();
+};
+constexpr size_t kBatchChunk = 256;              // decode steps enqueued between two looks at the tokens
+
+int batch_create(Model *m, Cache *const *caches, size_t B, Batch **out);
+// one step for every sequence: tokens[b] at RoPE offset pos[b]; logits_out [B][V] (host) or null
+int batch_forward(Batch *b, const uint32_t *tokens, const size_t *pos, float *logits_out, uint32_t *tokens_out);
+// n_steps greedy / sampled steps; tokens_out [B][n_steps], n_out [B] (stops counting a sequence at its EOS)
+int batch_decode(Batch *b, const uint32_t *first, const size_t *pos, size_t n_steps, int64_t eos,
+                 const fl_sampling *sampling, uint32_t *tokens_out, size_t *n_out);
+
 int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int compute_dtype,
                  const fl_parallel *par, Model **out);
 int cache_create(Model *m, size_t max_seq, Cache **out);

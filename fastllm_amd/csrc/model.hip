@@ -1049,4 +1049,221 @@ int decode_greedy(Model *m, Cache *c, uint32_t first, size_t pos, size_t n_steps
     return FL_OK;
 }
 
+// ------------------------------------------------------------------------------- batched decode (row N4)
+Batch::~Batch() {
+    if (!m) return;
+    std::lock_guard<std::mutex> lock(m->mu);
+    Shard &sh = m->shards[0];
+    (void)hipSetDevice(sh.device);
+    (void)hipStreamSynchronize(sh.stream);
+    if (graph) (void)hipGraphExecDestroy(graph);
+    for (void *p : allocs) (void)hipFree(p);
+    if (host_tokens) (void)hipHostFree(host_tokens);
+    if (host_states) (void)hipHostFree(host_states);
+}
+
+int batch_create(Model *m, Cache *const *caches, size_t B, Batch **out) {
+    if (!m || !caches || !out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+    if (B < 1 || B > (size_t)kMaxBatch) FL_FAIL(FL_ERR_BAD_ARGUMENT, "batch size %zu not in 1..%d", B, kMaxBatch);
+    if (m->tp != 1 || m->shards.size() != 1) FL_FAIL(FL_ERR_UNSUPPORTED, "batched decode is single-GPU (tp = 1)");
+    if (m->dtype != FL_DTYPE_BF16) FL_FAIL(FL_ERR_UNSUPPORTED, "batched decode is bf16 only");
+    const Dims &D = m->D;
+    Shard &sh = m->shards[0];
+    for (size_t i = 0; i < B; i++) {
+        if (!caches[i] || caches[i]->m != m) FL_FAIL(FL_ERR_BAD_ARGUMENT, "cache %zu is null or belongs to another model", i);
+        if (!caches[i]->v_transposed) FL_FAIL(FL_ERR_UNSUPPORTED, "batched decode needs the MFMA attention layout (head_dim 64/128, group <= 8)");
+        for (size_t j = 0; j < i; j++) if (caches[j] == caches[i]) FL_FAIL(FL_ERR_BAD_ARGUMENT, "cache %zu appears twice in the batch", i);
+    }
+    std::unique_ptr<Batch> b(new Batch());
+    std::lock_guard<std::mutex> lock(m->mu);
+    b->m = m; b->B = (int)B;
+    b->caches.assign(caches, caches + B);
+    b->nks_o = gemv_batch_ksplit((int)B, sh.Hs * D.d, D.h, EPI_F32);
+    b->nks_down = gemv_batch_ksplit((int)B, sh.Ip, D.h, EPI_F32);
+    if (gemv_batch_ksplit((int)B, D.h, 2 * sh.Ip, EPI_GATEUP) != 1) FL_FAIL(FL_ERR_UNSUPPORTED, "hidden size %lld too large for the batched norm prologue", (long long)D.h);
+    FL_HIP(hipSetDevice(sh.device));
+    std::vector<SeqRef> refs(B);
+    for (size_t i = 0; i < B; i++) {
+        CacheShard &cs = caches[i]->shards[0];
+        refs[i] = SeqRef{cs.st, cs.ss, cs.k, cs.v, cs.part_m, cs.part_l, cs.part_o, cs.counters, cs.out_tokens, cs.sel_scratch,
+                         (int)caches[i]->seq_alloc, caches[i]->nsplit};
+        b->max_nsplit = std::max(b->max_nsplit, caches[i]->nsplit);
+    }
+    const size_t es = m->esize();
+    const int nsl = std::max(b->nks_o, b->nks_down);
+    FL_TRY(dev_alloc(b->allocs, (void **)&b->seqs_dev, sizeof(SeqRef) * B, nullptr));
+    FL_TRY(dev_alloc(b->allocs, (void **)&b->x_res, B * D.h * 4, nullptr));
+    FL_TRY(dev_alloc(b->allocs, (void **)&b->x_res2, B * D.h * 4, nullptr));
+    FL_TRY(dev_alloc(b->allocs, (void **)&b->delta, (size_t)nsl * B * D.h * 4, nullptr));
+    FL_TRY(dev_alloc(b->allocs, &b->q, B * sh.Hs * D.d * es, nullptr));
+    FL_TRY(dev_alloc(b->allocs, &b->ao, B * sh.Hs * D.d * es, nullptr));
+    FL_TRY(dev_alloc(b->allocs, &b->act, B * sh.Ip * es, nullptr));
+    FL_TRY(dev_alloc(b->allocs, (void **)&b->logits, B * D.V * 4, nullptr));
+    FL_HIP(hipMemcpyAsync(b->seqs_dev, refs.data(), sizeof(SeqRef) * B, hipMemcpyHostToDevice, sh.stream));
+    FL_HIP(hipStreamSynchronize(sh.stream));                  // refs is a stack vector
+    FL_HIP(hipHostMalloc((void **)&b->host_tokens, B * kBatchChunk * 4, hipHostMallocDefault));
+    FL_HIP(hipHostMalloc((void **)&b->host_states, B * sizeof(StepState), hipHostMallocDefault));
+    m->refs.fetch_add(1);
+    *out = b.release();
+    return FL_OK;
+}
+
+// One decode step of the whole batch: the 5-launch layer of enqueue_decode_fused with B activation rows.
+static int enqueue_batch_step(Batch *b) {
+    Model *m = b->m;
+    const Dims &D = m->D;
+    Shard &sh = m->shards[0];
+    Launcher L = make_launcher(m, sh);
+    const int B = b->B;
+    const long long slab = (long long)B * D.h;
+    for (int64_t l = 0; l < D.L; l++) {
+        LayerW &ly = sh.layers[l];
+        GemvBatchArgs a;
+        a.B = B; a.seqs = b->seqs_dev;
+        a.W = ly.wqkv; a.bias = ly.bqkv; a.N = (int)((sh.Hs + 2 * sh.Hkvs) * D.d); a.K = (int)D.h; a.nks = 1;
+        a.epi = EPI_QKV_ROPE; a.pro = PRO_NORM; a.norm_w = ly.ln1; a.eps = D.eps;
+        if (l == 0) { a.embed = sh.embed; a.x_out = b->x_res2; }
+        else { a.x_in = b->x_res; a.delta = b->delta; a.n_slab = b->nks_down; a.slab_stride = slab; a.x_out = b->x_res2; }
+        a.cos_tab = sh.cos_tab; a.sin_tab = sh.sin_tab; a.q_out = b->q; a.kv_layer_off = (size_t)l * sh.Hkvs * D.d;
+        a.H = (int)sh.Hs; a.Hkv = (int)sh.Hkvs; a.d = (int)D.d; a.max_pos = (int)D.max_pos;
+        FL_TRY(launch_gemv_batch(L, a));
+        FL_TRY(launch_attn_decode_mfma_batch(L, b->q, b->seqs_dev, B, b->max_nsplit, (size_t)l * sh.Hkvs * D.d, b->ao, sh.Hs, sh.Hkvs,
+                                             D.d, D.scale, 0.0));
+        GemvBatchArgs o;
+        o.B = B; o.W = ly.wo; o.x = b->ao; o.out = b->delta; o.N = (int)D.h; o.K = (int)(sh.Hs * D.d); o.nks = b->nks_o;
+        FL_TRY(launch_gemv_batch(L, o));
+        GemvBatchArgs g;
+        g.B = B; g.seqs = b->seqs_dev; g.W = ly.wgu; g.out = b->act; g.N = (int)(2 * sh.Ip); g.K = (int)D.h; g.epi = EPI_GATEUP; g.pro = PRO_NORM;
+        g.x_in = b->x_res2; g.delta = b->delta; g.n_slab = b->nks_o; g.slab_stride = slab; g.norm_w = ly.ln2; g.eps = D.eps; g.x_out = b->x_res;
+        FL_TRY(launch_gemv_batch(L, g));
+        GemvBatchArgs d;
+        d.B = B; d.W = ly.wd; d.x = b->act; d.out = b->delta; d.N = (int)D.h; d.K = (int)sh.Ip; d.nks = b->nks_down;
+        FL_TRY(launch_gemv_batch(L, d));
+    }
+    GemvBatchArgs h;
+    h.B = B; h.seqs = b->seqs_dev; h.W = sh.lm_head; h.out = b->logits; h.N = (int)D.V; h.K = (int)D.h; h.pro = PRO_NORM;
+    h.x_in = b->x_res; h.delta = b->delta; h.n_slab = b->nks_down; h.slab_stride = slab; h.norm_w = sh.norm; h.eps = D.eps;
+    FL_TRY(launch_gemv_batch(L, h));
+    return launch_select_advance_batch(L, b->logits, D.V, b->seqs_dev, B, 1);
+}
+
+static int batch_step(Batch *b) {
+    Model *m = b->m;
+    Shard &sh = m->shards[0];
+    const bool graphable = m->use_graph && !m->profiling && !b->graph_failed;
+    if (graphable && b->graph) { FL_HIP(hipGraphLaunch(b->graph, sh.stream)); return FL_OK; }
+    if (graphable && b->warm_steps >= 1) {
+        hipGraph_t g = nullptr;
+        bool ok = hipStreamBeginCapture(sh.stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            const int rc = enqueue_batch_step(b);
+            const hipError_t e = hipStreamEndCapture(sh.stream, &g);
+            ok = rc == FL_OK && e == hipSuccess && g != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&b->graph, g, nullptr, nullptr, 0) == hipSuccess;
+        if (g) (void)hipGraphDestroy(g);
+        if (ok) { FL_HIP(hipGraphLaunch(b->graph, sh.stream)); return FL_OK; }
+        (void)hipGetLastError();
+        b->graph_failed = true; b->graph = nullptr;
+    }
+    FL_TRY(enqueue_batch_step(b));
+    b->warm_steps++;
+    return FL_OK;
+}
+
+static int batch_check(Batch *b, const size_t *pos, size_t n_steps) {
+    if (!b || !pos) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+    for (int i = 0; i < b->B; i++) FL_TRY(check_call(b->m, b->caches[i], n_steps, pos[i]));
+    return FL_OK;
+}
+
+int batch_decode(Batch *b, const uint32_t *first, const size_t *pos, size_t n_steps, int64_t eos,
+                 const fl_sampling *sampling, uint32_t *tokens_out, size_t *n_out) {
+    if (!b || !first || !tokens_out || !n_out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+    const int B = b->B;
+    for (int i = 0; i < B; i++) n_out[i] = 0;
+    if (n_steps == 0) return FL_OK;
+    FL_TRY(batch_check(b, pos, n_steps));
+    Model *m = b->m;
+    for (int i = 0; i < B; i++) if ((int64_t)first[i] >= m->D.V) FL_FAIL(FL_ERR_BAD_ARGUMENT, "token id %u out of range", first[i]);
+    const SampleState sampler = make_sampler(sampling);
+    std::lock_guard<std::mutex> lock(m->mu);
+    Shard &sh = m->shards[0];
+    FL_HIP(hipSetDevice(sh.device));
+    std::vector<uint32_t> tok(first, first + B);
+    std::vector<char> finished(B, 0);
+    std::vector<size_t> len0(B);
+    for (int i = 0; i < B; i++) len0[i] = b->caches[i]->len;
+    size_t done = 0;
+    while (done < n_steps) {
+        const size_t nb = std::min(n_steps - done, kBatchChunk);
+        for (int i = 0; i < B; i++) {
+            Cache *c = b->caches[i];
+            hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(64), 0, sh.stream, c->shards[0].st, tok[i], (uint32_t)(pos[i] + done),
+                               (uint32_t)(len0[i] + done), (uint32_t)(len0[i] + done), 0u, (int32_t)eos, c->shards[0].heads_done, (int)m->D.L,
+                               c->shards[0].ss, sampler, done == 0 ? 1 : 0);
+            FL_HIP(hipGetLastError());
+        }
+        for (size_t s = 0; s < nb; s++) FL_TRY(batch_step(b));
+        for (int i = 0; i < B; i++) {
+            FL_HIP(hipMemcpyAsync(b->host_tokens + (size_t)i * kBatchChunk, b->caches[i]->shards[0].out_tokens, nb * 4, hipMemcpyDeviceToHost, sh.stream));
+            FL_HIP(hipMemcpyAsync(b->host_states + i, b->caches[i]->shards[0].st, sizeof(StepState), hipMemcpyDeviceToHost, sh.stream));
+        }
+        FL_HIP(hipStreamSynchronize(sh.stream));
+        bool all_finished = true;
+        for (int i = 0; i < B; i++) {
+            if (b->host_states[i].error) FL_FAIL(FL_ERR_HIP, "device-side wait gave up (code 0x%x) in sequence %d", b->host_states[i].error, i);
+            if (!finished[i]) {
+                for (size_t s = 0; s < nb; s++) {
+                    const uint32_t t = b->host_tokens[(size_t)i * kBatchChunk + s];
+                    if (eos >= 0 && (int64_t)t == eos) {             // as fl_decode_greedy: the EOS forward counts, the token does not
+                        finished[i] = 1;
+                        b->caches[i]->len = len0[i] + done + s + 1;
+                        break;
+                    }
+                    tokens_out[(size_t)i * n_steps + done + s] = t;
+                    n_out[i] = done + s + 1;
+                }
+                if (!finished[i]) b->caches[i]->len = len0[i] + done + nb;
+            }
+            tok[i] = b->host_tokens[(size_t)i * kBatchChunk + nb - 1];
+            all_finished = all_finished && finished[i];
+        }
+        done += nb;
+        if (all_finished) break;
+    }
+    return FL_OK;
+}
+
+int batch_forward(Batch *b, const uint32_t *tokens, const size_t *pos, float *logits_out, uint32_t *tokens_out) {
+    if (!b || !tokens) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+    FL_TRY(batch_check(b, pos, 1));
+    Model *m = b->m;
+    const int B = b->B;
+    for (int i = 0; i < B; i++) if ((int64_t)tokens[i] >= m->D.V) FL_FAIL(FL_ERR_BAD_ARGUMENT, "token id %u out of range", tokens[i]);
+    const SampleState sampler{};
+    std::lock_guard<std::mutex> lock(m->mu);
+    Shard &sh = m->shards[0];
+    FL_HIP(hipSetDevice(sh.device));
+    for (int i = 0; i < B; i++) {
+        Cache *c = b->caches[i];
+        hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(64), 0, sh.stream, c->shards[0].st, tokens[i], (uint32_t)pos[i], (uint32_t)c->len,
+                           (uint32_t)c->len, 0u, (int32_t)-1, c->shards[0].heads_done, (int)m->D.L, c->shards[0].ss, sampler, 1);
+        FL_HIP(hipGetLastError());
+    }
+    FL_TRY(batch_step(b));
+    if (logits_out) FL_HIP(hipMemcpyAsync(logits_out, b->logits, (size_t)B * m->D.V * 4, hipMemcpyDeviceToHost, sh.stream));
+    for (int i = 0; i < B; i++) {
+        FL_HIP(hipMemcpyAsync(b->host_tokens + (size_t)i * kBatchChunk, b->caches[i]->shards[0].out_tokens, 4, hipMemcpyDeviceToHost, sh.stream));
+        FL_HIP(hipMemcpyAsync(b->host_states + i, b->caches[i]->shards[0].st, sizeof(StepState), hipMemcpyDeviceToHost, sh.stream));
+    }
+    FL_HIP(hipStreamSynchronize(sh.stream));
+    for (int i = 0; i < B; i++) {
+        if (b->host_states[i].error) FL_FAIL(FL_ERR_HIP, "device-side wait gave up (code 0x%x) in sequence %d", b->host_states[i].error, i);
+        b->caches[i]->len += 1;
+        if (tokens_out) tokens_out[i] = b->host_tokens[(size_t)i * kBatchChunk];
+    }
+    return FL_OK;
+}
+
 }  // namespace fl

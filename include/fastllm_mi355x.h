@@ -207,6 +207,24 @@ int fl_forward_sample(fl_model *m, fl_cache *c, const uint32_t *ids, size_t T, s
 int fl_decode_sample(fl_model *m, fl_cache *c, uint32_t first_token, size_t pos, size_t n_steps, int64_t eos,
                      const fl_sampling *sampling, uint32_t *tokens_out, size_t *n_out);
 
+/* Batched decode: B <= 8 caches of one model advanced together, one read of the weights per step for all
+ * of them.  New capability: the reference runs concurrent streams as independent single-sequence loops
+ * (mod.rs:137-238), each paying for the whole weight stream.  Every sequence keeps its own cache, RoPE
+ * position and sampler state; per sequence the results are those of the single-sequence entry points
+ * (same kernels' arithmetic, up to fp32 summation order in the norm).  Single GPU, bf16.
+ * The caches stay usable on their own (prefill them with fl_forward*, then batch the decode). */
+typedef struct fl_batch fl_batch;
+int  fl_batch_create(fl_model *m, fl_cache *const *caches, size_t n, fl_batch **out);
+void fl_batch_destroy(fl_batch *b);
+/* one step: tokens[i] at RoPE offset pos[i]; logits_out [n][V] fp32 host or NULL; argmax_out [n] or NULL */
+int  fl_batch_forward(fl_batch *b, const uint32_t *tokens, const size_t *pos, float *logits_out, uint32_t *argmax_out);
+/* the loop of fl_decode_greedy / fl_decode_sample for every sequence: tokens_out [n][n_steps], n_out [n];
+ * a sequence stops counting at its EOS (its cache length is that of fl_decode_greedy); sampling may be NULL
+ * (ArgMax); with sampling every sequence draws from its own copy of the seeded stream, as every request of
+ * the reference does (seed 0 per request, mod.rs:373-374) */
+int  fl_batch_decode(fl_batch *b, const uint32_t *first_tokens, const size_t *pos, size_t n_steps, int64_t eos,
+                     const fl_sampling *sampling, uint32_t *tokens_out, size_t *n_out);
+
 int fl_synchronize(fl_model *m);
 
 /* Which slice of a full HF tensor does tp_rank own?  Pure host function (no GPU):
