@@ -273,17 +273,17 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #ifndef FL_MFMA_NT
 #define FL_MFMA_NT 0
 #endif
-#ifndef FL_MFMA_U
-#define FL_MFMA_U 4
-#endif
-constexpr int kMU = FL_MFMA_U;
 #if FL_MFMA_NT
 #define FL_MLOAD(p) __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(p))
 #else
 #define FL_MLOAD(p) (*reinterpret_cast<const uint4v *>(p))
 #endif
-template <int PRO>
+// MODE 0: per-unit loop; 1: pipelined across units (PIPE); 2: PIPE + per-wave LDS transpose (STAGED).
+// Tried and dropped (profiles/r01/README.md): K steps dealt round-robin to the waves (3.5 vs 4.05 TB/s), and
+// workgroup-cooperative 32-row x 512-k stages with 1 KiB-per-row loads and a barrier per stage (3.3 TB/s).
+template <int PRO, int MU, int MODE>
 __global__ __launch_bounds__(kBThreads) void gemv_batch_mfma_kernel(const GemvBatchArgs a) {
+    constexpr bool PIPE = MODE == 1 || MODE == 2, STAGED = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float red[kBThreads / 64][8];
     __shared__ float inv_lds[8];
@@ -300,6 +300,8 @@ __global__ __launch_bounds__(kBThreads) void gemv_batch_mfma_kernel(const GemvBa
     bf16_t *xs = reinterpret_cast<bf16_t *>(lds_raw);                 // [8][XS]
     float *part = reinterpret_cast<float *>(lds_raw + (size_t)8 * XS * 2);   // [8 waves][2 tiles][16 cols][16 rows]
     float *fin = part + nwv * 2 * 256;                                 // [2][16][16] summed tiles for the paired epilogues
+    unsigned char *stage_base = reinterpret_cast<unsigned char *>(fin + 2 * 256);
+    unsigned char *stage = stage_base + (size_t)wave * 8192;          // STAGED: 32 rows x 256 B per wave
     const int half = a.d >> 1;
     const int m = lane & 15, kg = lane >> 4;
 
@@ -380,43 +382,22 @@ __global__ __launch_bounds__(kBThreads) void gemv_batch_mfma_kernel(const GemvBa
     const int spw = (nsteps + nwv - 1) / nwv;
     const int s0 = min(nsteps, wave * spw), s1 = min(nsteps, s0 + spw);
     const bf16_t *xb = xs + (size_t)(m & 7) * XS + kg * 8;
-    for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
-        int ra0, rb0;
+    float4v ca = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};
+    auto unit_rows = [&](int unit, int &ra0, int &rb0) {
         if (epi == EPI_QKV_ROPE) {
             const int upr = half / 16;                                 // units per head
             const int hd = unit / upr, i = unit - hd * upr;
             ra0 = hd * a.d + 16 * i; rb0 = ra0 + half;
         } else { ra0 = unit * 32; rb0 = ra0 + 16; }
-        const bf16_t *pa = W + (size_t)min(ra0 + m, N - 1) * K + (size_t)cs0 * 8 + kg * 8;
-        const bf16_t *pb = W + (size_t)min(rb0 + m, N - 1) * K + (size_t)cs0 * 8 + kg * 8;
-        float4v ca = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};
-        int s = s0;
-#pragma nounroll
-        for (; s + kMU <= s1; s += kMU) {                              // straight-line block: 8 loads in flight, counted waits
-            uint4v wa[kMU], wb[kMU];
-#pragma unroll
-            for (int u = 0; u < kMU; u++) {
-                wa[u] = FL_MLOAD(pa + (size_t)(s + u) * 32);
-                wb[u] = FL_MLOAD(pb + (size_t)(s + u) * 32);
-            }
-#pragma unroll
-            for (int u = 0; u < kMU; u++) {
-                const bf16x8_t xf = *reinterpret_cast<const bf16x8_t *>(xb + (size_t)(s + u) * 32);
-                ca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa[u]), xf, ca, 0, 0, 0);
-                cb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb[u]), xf, cb, 0, 0, 0);
-            }
-        }
-#pragma nounroll
-        for (; s < s1; s++) {
-            const uint4v wa = FL_MLOAD(pa + (size_t)s * 32);
-            const uint4v wb = FL_MLOAD(pb + (size_t)s * 32);
-            const bf16x8_t xf = *reinterpret_cast<const bf16x8_t *>(xb + (size_t)s * 32);
-            ca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa), xf, ca, 0, 0, 0);
-            cb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb), xf, cb, 0, 0, 0);
-        }
+    };
+    // sum the 8 waves' partial tiles in wave order, apply 1/rms, run the epilogue; clears ca / cb
+    auto finish_unit = [&](int unit) {
+        int ra0, rb0;
+        unit_rows(unit, ra0, rb0);
         // C fragment: column n = m (sequence), rows 4*kg .. 4*kg+3  ->  part[wave][tile][n][row]
         *reinterpret_cast<float4v *>(part + ((wave * 2 + 0) * 16 + m) * 16 + 4 * kg) = ca;
         *reinterpret_cast<float4v *>(part + ((wave * 2 + 1) * 16 + m) * 16 + 4 * kg) = cb;
+        ca = float4v{0.f, 0.f, 0.f, 0.f}; cb = float4v{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
         const int tile = tid >> 8, n = (tid >> 4) & 15, r = tid & 15;
         float sum = 0.f;
@@ -428,7 +409,7 @@ __global__ __launch_bounds__(kBThreads) void gemv_batch_mfma_kernel(const GemvBa
             if (n < B && row < N)
                 reinterpret_cast<float *>(a.out)[(size_t)ks * B * N + (size_t)n * N + row] = sum + (a.bias && ks == 0 ? a.bias[row] : 0.f);
             __syncthreads();                                           // part[] is rewritten by the next unit
-            continue;
+            return;
         }
         if (epi == EPI_QKV_ROPE && a.bias && row < N) sum += a.bias[row];
         fin[(tile * 16 + n) * 16 + r] = sum;
@@ -460,6 +441,109 @@ __global__ __launch_bounds__(kBThreads) void gemv_batch_mfma_kernel(const GemvBa
             }
         }
         __syncthreads();
+    };
+
+    if constexpr (PIPE) {
+        // Host-checked: every wave has the same number nbw >= 1 of MU-step blocks per unit.  The blocks of all
+        // the workgroup's units form one flat sequence; block f+1 is requested before block f is consumed, so
+        // the weight stream does not drain while a unit's tiles are reduced and written out.
+        const int nbw = (s1 - s0) / MU;
+        const int myunits = (int)blockIdx.x < nunits ? (nunits - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+        const int total = myunits * nbw;
+        int iu = 0, ib = 0;                                            // issue cursor: unit index (of mine), block in unit
+        int cu = 0, cbk = 0;                                           // compute cursor
+        auto issue = [&](uint4v (&wa)[MU], uint4v (&wb)[MU]) {
+            int ra0, rb0;
+            unit_rows((int)blockIdx.x + iu * (int)gridDim.x, ra0, rb0);
+            if constexpr (STAGED) {
+                // MU == 4: a block is 32 rows x 128 k.  Instruction i (wa[u] = 2u, wb[u] = 2u+1) reads rows 4i..4i+3
+                // of the unit, 256 contiguous bytes (two full cache lines) per row: lane = (row & 3) * 16 + chunk.
+                // 64 bytes per row per instruction -- the MFMA A-fragment pattern -- costs ~17 % of the stream rate.
+                const size_t koff = (size_t)cs0 * 8 + (size_t)(s0 + ib * MU) * 32 + (size_t)(lane & 15) * 8;
+#pragma unroll
+                for (int u = 0; u < MU; u++) {
+                    const int r0 = 8 * u + (lane >> 4), r1 = r0 + 4;                  // unit rows 0..31 (16.. = tile B)
+                    const int g0 = (r0 < 16 ? ra0 + r0 : rb0 + r0 - 16), g1 = (r1 < 16 ? ra0 + r1 : rb0 + r1 - 16);
+                    wa[u] = FL_MLOAD(W + (size_t)min(g0, N - 1) * K + koff);
+                    wb[u] = FL_MLOAD(W + (size_t)min(g1, N - 1) * K + koff);
+                }
+            } else {
+                const size_t koff = (size_t)cs0 * 8 + kg * 8 + (size_t)(s0 + ib * MU) * 32;
+                const bf16_t *pa = W + (size_t)min(ra0 + m, N - 1) * K + koff;
+                const bf16_t *pb = W + (size_t)min(rb0 + m, N - 1) * K + koff;
+#pragma unroll
+                for (int u = 0; u < MU; u++) { wa[u] = FL_MLOAD(pa + (size_t)u * 32); wb[u] = FL_MLOAD(pb + (size_t)u * 32); }
+            }
+            if (++ib == nbw) { ib = 0; iu++; }
+        };
+        auto compute = [&](const uint4v (&wa)[MU], const uint4v (&wb)[MU]) {
+            if constexpr (STAGED) {
+                // registers (row-major pieces) -> this wave's LDS stage, chunk c of row r at position c ^ (r & 15);
+                // back out as A fragments: lane (m, kg) of k step t takes row m, chunk 4t + kg.  Wave-private: no barrier.
+                const int c = lane & 15;
+#pragma unroll
+                for (int u = 0; u < MU; u++) {
+                    const int r0 = 8 * u + (lane >> 4), r1 = r0 + 4;
+                    *reinterpret_cast<uint4v *>(stage + r0 * 256 + ((c ^ (r0 & 15)) << 4)) = wa[u];
+                    *reinterpret_cast<uint4v *>(stage + r1 * 256 + ((c ^ (r1 & 15)) << 4)) = wb[u];
+                }
+                const int sb = s0 + cbk * MU;
+#pragma unroll
+                for (int t = 0; t < MU; t++) {
+                    const bf16x8_t fa = *reinterpret_cast<const bf16x8_t *>(stage + m * 256 + (((4 * t + kg) ^ m) << 4));
+                    const bf16x8_t fb = *reinterpret_cast<const bf16x8_t *>(stage + (16 + m) * 256 + (((4 * t + kg) ^ m) << 4));
+                    const bf16x8_t xf = *reinterpret_cast<const bf16x8_t *>(xb + (size_t)(sb + t) * 32);
+                    ca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, xf, ca, 0, 0, 0);
+                    cb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, xf, cb, 0, 0, 0);
+                }
+            } else {
+                const int sb = s0 + cbk * MU;
+#pragma unroll
+                for (int u = 0; u < MU; u++) {
+                    const bf16x8_t xf = *reinterpret_cast<const bf16x8_t *>(xb + (size_t)(sb + u) * 32);
+                    ca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa[u]), xf, ca, 0, 0, 0);
+                    cb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb[u]), xf, cb, 0, 0, 0);
+                }
+            }
+            if (++cbk == nbw) { cbk = 0; finish_unit((int)blockIdx.x + cu * (int)gridDim.x); cu++; }
+        };
+        uint4v a0[MU], b0[MU], a1[MU], b1[MU];
+        if (total > 0) issue(a0, b0);
+#pragma nounroll
+        for (int f = 0; f < total; f += 2) {
+            if (f + 1 < total) issue(a1, b1);
+            compute(a0, b0);
+            if (f + 2 < total) issue(a0, b0);
+            if (f + 1 < total) compute(a1, b1);
+        }
+    } else {
+        for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+            int ra0, rb0;
+            unit_rows(unit, ra0, rb0);
+            const bf16_t *pa = W + (size_t)min(ra0 + m, N - 1) * K + (size_t)cs0 * 8 + kg * 8;
+            const bf16_t *pb = W + (size_t)min(rb0 + m, N - 1) * K + (size_t)cs0 * 8 + kg * 8;
+            int s = s0;
+#pragma nounroll
+            for (; s + MU <= s1; s += MU) {                            // straight-line block, counted waits
+                uint4v wa[MU], wb[MU];
+#pragma unroll
+                for (int u = 0; u < MU; u++) { wa[u] = FL_MLOAD(pa + (size_t)(s + u) * 32); wb[u] = FL_MLOAD(pb + (size_t)(s + u) * 32); }
+#pragma unroll
+                for (int u = 0; u < MU; u++) {
+                    const bf16x8_t xf = *reinterpret_cast<const bf16x8_t *>(xb + (size_t)(s + u) * 32);
+                    ca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa[u]), xf, ca, 0, 0, 0);
+                    cb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb[u]), xf, cb, 0, 0, 0);
+                }
+            }
+#pragma nounroll
+            for (; s < s1; s++) {
+                const uint4v wa = FL_MLOAD(pa + (size_t)s * 32), wb = FL_MLOAD(pb + (size_t)s * 32);
+                const bf16x8_t xf = *reinterpret_cast<const bf16x8_t *>(xb + (size_t)s * 32);
+                ca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa), xf, ca, 0, 0, 0);
+                cb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb), xf, cb, 0, 0, 0);
+            }
+            finish_unit(unit);
+        }
     }
 }
 
@@ -513,11 +597,11 @@ static int launch_gemv_batch_t(Launcher &L, const GemvBatchArgs &a) {
     return LL.launch(KC_GEMV, (double)a.N * a.K * 2, 2.0 * a.N * a.K * a.B, kern, dim3((unsigned)blocks, (unsigned)a.nks), dim3(kBThreads), lds, a);
 }
 
-template <int PRO>
-static int launch_gemv_batch_mfma_t(Launcher &L, const GemvBatchArgs &a) {
-    auto kern = gemv_batch_mfma_kernel<PRO>;
+template <int PRO, int MU, int MODE>
+static int launch_gemv_batch_mfma_k(Launcher &L, const GemvBatchArgs &a) {
+    auto kern = gemv_batch_mfma_kernel<PRO, MU, MODE>;
     const int64_t per = (((a.K / 8) + a.nks - 1) / a.nks + 63) & ~(int64_t)63;
-    const size_t lds = (size_t)8 * (per * 8 + 8) * 2 + (size_t)(8 * 2 * 256 + 2 * 256) * 4;
+    const size_t lds = (size_t)8 * (per * 8 + 8) * 2 + (size_t)(8 * 2 * 256 + 2 * 256) * 4 + (MODE >= 2 ? 8 * 8192 : 0);
     if (lds > 64 * 1024) {
         static std::atomic<size_t> raised{0};
         if (raised.load() < lds) {
@@ -531,6 +615,31 @@ static int launch_gemv_batch_mfma_t(Launcher &L, const GemvBatchArgs &a) {
     snprintf(tag, sizeof tag, "b%dm:%dx%d%s%s", a.B, a.N, a.K, PRO == PRO_NORM ? ",norm" : "", a.epi == EPI_GATEUP ? ",glu" : (a.epi == EPI_QKV_ROPE ? ",rope" : ""));
     Launcher LL = L; LL.tag = tag;
     return LL.launch(KC_GEMV, (double)a.N * a.K * 2, 2.0 * a.N * a.K * a.B, kern, dim3((unsigned)blocks, (unsigned)a.nks), dim3(kBThreads), lds, a);
+}
+
+template <int PRO>
+static int launch_gemv_batch_mfma_t(Launcher &L, const GemvBatchArgs &a) {
+    // pipelined variant: every K slice must give each of the 8 waves the same whole number of MU-step blocks
+    const int64_t nchunk_all = a.K / 8;
+    const int64_t per = ((nchunk_all + a.nks - 1) / a.nks + 63) & ~(int64_t)63;
+    int mu = 4;
+    bool pipe = !(getenv("FL_BATCH_MODE") && atoi(getenv("FL_BATCH_MODE")) == 0);
+    for (int k = 0; k < a.nks; k++) {
+        const int64_t c0 = std::min(nchunk_all, k * per), c1 = std::min(nchunk_all, c0 + per);
+        const int64_t steps = (c1 - c0) / 4;
+        if (steps == 0 || steps % 8) { pipe = false; break; }
+        while (mu > 1 && (steps / 8) % mu) mu /= 2;
+    }
+    // staging variants need room for 64 KB next to the activations
+    const size_t lds_staged = (size_t)8 * (per * 8 + 8) * 2 + (size_t)(8 * 2 * 256 + 2 * 256) * 4 + 8 * 8192;
+    static const int mode_env = getenv("FL_BATCH_MODE") ? atoi(getenv("FL_BATCH_MODE")) : 2;
+    if (pipe) {
+        if (mu == 4 && mode_env >= 2 && lds_staged <= 160 * 1024 - 1024) return launch_gemv_batch_mfma_k<PRO, 4, 2>(L, a);
+        if (mu == 4) return launch_gemv_batch_mfma_k<PRO, 4, 1>(L, a);
+        if (mu == 2) return launch_gemv_batch_mfma_k<PRO, 2, 1>(L, a);
+        return launch_gemv_batch_mfma_k<PRO, 1, 1>(L, a);
+    }
+    return launch_gemv_batch_mfma_k<PRO, 4, 0>(L, a);
 }
 
 int launch_gemv_batch(Launcher &L, const GemvBatchArgs &a) {
