@@ -14,6 +14,12 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 16 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 16 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err || exit 1
 cd $R
+# next-row components and the multi-rank rehearsal (all ranks on this one GPU: protocol check, not a scaling figure)
+timeout -k 10 300 python3 tools/batch_bench.py --profile --batches 1,2,3,4,6,8 > $O/batch_decode_mistral7b.txt 2> $O/batch.err || exit 1
+timeout -k 10 200 python3 tools/sample_cost.py > $O/sample_cost.txt 2> $O/sample.err || exit 1
+for n in 2 4; do
+  FL_BENCH_SAME_DEVICE=1 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29520 + n)) bench.py --gpus $n --steps 64 --warmup 8 > $O/bench_tp${n}_same_device.json 2> $O/bench_tp${n}.err || exit 1
+done
 python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/traffic_gemv.json > /dev/null
 # keep the merged output small: the per-dispatch traces are large
 find $O -name '*kernel_trace.csv' -size +20M -delete

@@ -26,7 +26,29 @@ def per_kernel(dirname, counter, match):
     return n, tot
 
 
+def summary(dirname, counter):
+    """per-kernel average of `counter` (KiB) over the NEWEST pass found under dirname"""
+    files = glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        return {}
+    newest = max(files, key=os.path.getmtime)
+    acc = {}
+    for r in csv.DictReader(open(newest)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].split("(")[0]
+        a = acc.setdefault(name, [0, 0.0])
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return {k: {"dispatches": n, "avg_kib": t / n} for k, (n, t) in acc.items() if k.startswith(("void fl::", "fl::"))}
+
+
 def main():
+    if sys.argv[1] == "--summary":                # pmc_traffic.py --summary fetch_dir write_dir out.json
+        json.dump({"FETCH_SIZE": summary(sys.argv[2], "FETCH_SIZE"), "WRITE_SIZE": summary(sys.argv[3], "WRITE_SIZE"),
+                   "note": "raw counter averages in KiB per dispatch; gfx950: FETCH_SIZE is half the bytes of wide coalesced reads"},
+                  open(sys.argv[4], "w"), indent=1)
+        return
     fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
     nf, fetch = per_kernel(fetch_dir, "FETCH_SIZE", "gemv_kernel")
     nw, write = per_kernel(write_dir, "WRITE_SIZE", "gemv_kernel")
