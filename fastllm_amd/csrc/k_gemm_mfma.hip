@@ -254,6 +254,17 @@ int gemm_mfma_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
 
 int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bias, void *y,
                      int64_t T, int64_t N, int64_t K, int epi, const float *row_scale, int ksplit) {
+    // 256x256 phase-interleaved kernel (k_gemm_8p.hip).  FL_GEMM_8P: 0 off, 1 when the grid fills the chip, 2 always
+    const char *e8 = getenv("FL_GEMM_8P");                      // read per call: tests switch it
+    const int use8p = e8 && *e8 ? atoi(e8) : 1;
+    if (use8p && K % 64 == 0 && (K / 64) / ksplit >= 2 && (ksplit == 1 || (!bias && epi == EPI_F32))) {
+        // one workgroup per CU: worth it when the last round of tiles is nearly full (measured, gemm_probe: 224 tiles
+        // +13..29 %, 2368 tiles +15 %; 288 tiles -6 %, 48..128 tiles -40 %)
+        const int64_t t8 = ((T + 255) / 256) * ((N + 255) / 256) * ksplit;
+        const int64_t rounds = (t8 + 255) / 256;
+        if (use8p >= 2 || (T >= 256 && t8 >= 200 && t8 * 10 >= rounds * 256 * 8))
+            return launch_gemm_8p(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
+    }
     static const int use256 = getenv("FL_GEMM_256") ? atoi(getenv("FL_GEMM_256")) : 1;
     if (use256 && ksplit == 1 && T >= 192 && K / BK >= 3) {
         const int tm2 = (int)((T + BM2 - 1) / BM2), tn2 = (int)((N + BN - 1) / BN);

@@ -120,6 +120,8 @@ __host__ __device__ inline int64_t gateup_row(int64_t q, int is_up) { return (q 
 int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const float *bias, void *y,
                   int64_t T, int64_t N, int64_t K, int epi, const float *row_scale = nullptr,
                   int max_split = 1, int *n_split_out = nullptr);
+int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
+                   int epi, const float *row_scale, int ksplit);
 // cheap capability probes used by tests / DESIGN numbers
 bool gemv_supported(int dtype, int64_t N, int64_t K);
 bool gemm_mfma_supported(int dtype, int64_t T, int64_t N, int64_t K);

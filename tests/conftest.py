@@ -25,3 +25,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_collection_finish(session):
+    """tests/test_gpu_fullsize_7b.py generates its weights in HBM with torch (as bench.py does).  torch brings
+    its own copy of the HIP runtime, which only sees the GPU if it initialises BEFORE the product library's
+    (linked against /opt/rocm) does -- the order bench.py has -- so when that module is selected, let torch
+    go first."""
+    if any(getattr(item, "fspath", None) is not None and item.fspath.basename == "test_gpu_fullsize_7b.py" for item in session.items):
+        try:
+            import torch
+            torch.cuda.is_available()
+        except Exception:
+            pass

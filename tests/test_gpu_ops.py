@@ -79,3 +79,35 @@ def test_mfma_operand_maps_with_asymmetric_data(fa):
     y = fa.op_linear(synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w))
     ref = x @ w.T
     np.testing.assert_array_equal(y, ref)
+
+
+# 256x256 phase-interleaved GEMM (k_gemm_8p.hip): forced on shapes with ragged M / N tails, a single K pair, split-K
+# slabs, bias and the SiLU-gate epilogue; and picked by the default heuristic on a chip-filling grid
+@pytest.mark.parametrize("T,N,K,epi,bias", [(256, 256, 128, 0, True), (300, 700, 256, 0, True), (513, 1000, 1024, 0, False),
+                                            (512, 4096, 4096, 0, False), (700, 1300, 192, 1, False), (260, 4096, 640, 1, False)])
+@pytest.mark.parametrize("force", ["2", None])
+def test_linear_8phase_kernel(fa, T, N, K, epi, bias, force, monkeypatch):
+    if force:
+        monkeypatch.setenv("FL_GEMM_8P", force)
+    x, w = _rand((T, K), 11), _rand((N, K), 12, 0.05)
+    b = _rand((N,), 13) if bias else None
+    xb, wb = synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w)
+    y = fa.op_linear(xb, wb, b, epilogue=epi)
+    ref = _ref(synth.bf16_bits_to_f32(xb), synth.bf16_bits_to_f32(wb), b, epi)
+    if epi:
+        np.testing.assert_allclose(y, ref, atol=1e-3, rtol=2 ** -8)
+    else:
+        np.testing.assert_allclose(y, ref, atol=2e-5 * np.sqrt(K) + 1e-5, rtol=1e-5)
+
+
+def test_8phase_kernel_is_race_free_over_repeats(fa, monkeypatch):
+    """The LDS-DMA hand-offs are ordered only by counted waits and barriers: a misplaced one shows up as rare
+    wrong tiles.  Same inputs 30 times (different workgroup timing each launch): bit-identical outputs."""
+    monkeypatch.setenv("FL_GEMM_8P", "2")
+    T, N, K = 1024, 2048, 2048
+    xb, wb = synth.f32_to_bf16_bits(_rand((T, K), 21)), synth.f32_to_bf16_bits(_rand((N, K), 22, 0.05))
+    first = fa.op_linear(xb, wb, None)
+    ref = _ref(synth.bf16_bits_to_f32(xb), synth.bf16_bits_to_f32(wb), None, 0)
+    np.testing.assert_allclose(first, ref, atol=2e-5 * np.sqrt(K) + 1e-5, rtol=1e-5)
+    for _ in range(30):
+        np.testing.assert_array_equal(fa.op_linear(xb, wb, None), first)
