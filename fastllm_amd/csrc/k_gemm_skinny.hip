@@ -1,0 +1,177 @@
+// k_gemm_skinny.hip -- projection GEMM for SHORT prompts (T <= 128): Y[T,N] = X[T,K] . W[N,K]^T.
+//
+// With a few dozen tokens the projection is a weight stream (Mistral-7B: 14.5 GB per pass), not MFMA work,
+// and the 128x128 kernel moves it at ~2 TB/s: 48..224 workgroups with two 32 KB stages each do not keep
+// enough bytes in flight.  This kernel is built for that regime:
+//   * a workgroup owns ALL T tokens (BM = 32 / 64 / 128 rows of X) and a narrow strip of W rows
+//     (BN = 64 or 128), so the grid is N / BN workgroups -- times a K split for the fp32 epilogue;
+//   * four LDS stages, LDS-DMA three K tiles ahead, ONE raw barrier per K tile and a counted vmcnt (the two
+//     youngest tiles stay in flight across it): up to 48 KB of W per workgroup outstanding;
+//   * 4 waves, each owning 16 (BN = 64) or 32 (BN = 128: a gate/up pair) W rows against every token
+//     tile, so the W bytes are read from LDS exactly once and the X tile (L2-resident) by all four waves.
+// LDS image as the other GEMM kernels: [rows][64 bf16], chunk index XOR (row >> 1) & 7 on DMA source and read.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace fl {
+
+typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+constexpr int S_BK = 64, S_NSTG = 4;
+// (BM = 256 with three stages was tried for 128 < T <= 256: 9.6 ms vs 8.9 ms for the 128x128 kernel on the
+// Mistral-7B prefill -- the X tile, re-read by every workgroup, then costs more than the stream gains.)
+
+__device__ inline void glds16s(const void *g, unsigned char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+__device__ inline bf16x8s frag_s(const unsigned char *tile, int row, int chunk) {
+    return *reinterpret_cast<const bf16x8s *>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+
+template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// BM tokens x (64 * NT) weight rows per workgroup; NT n-tiles of 16 rows per wave
+template <int BM, int NT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
+                                                          const float *__restrict__ bias, void *__restrict__ out,
+                                                          int T, int N, int K, int epi, const float *__restrict__ row_scale,
+                                                          int ksplit) {
+    constexpr int BN = 64 * NT, MT = BM / 16;
+    constexpr int XB = BM * 128, STG = XB + BN * 128;             // bytes per stage
+    constexpr int NI = (BM + BN) / 8;                              // 1 KiB DMA instructions per stage
+    constexpr int PW = NI / 4;                                     // ... per wave (BM, BN multiples of 32)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m16 = lane & 15, kg = lane >> 4;
+    const int n0 = blockIdx.x * BN;
+    const int nk_all = K / S_BK, kz = blockIdx.y;
+    const int kt0 = (int)((long long)nk_all * kz / ksplit), nk = (int)((long long)nk_all * (kz + 1) / ksplit) - kt0;
+    X += (size_t)kt0 * S_BK; W += (size_t)kt0 * S_BK;
+    if (ksplit > 1) out = reinterpret_cast<float *>(out) + (size_t)kz * T * N;
+
+    float4v acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int kt) {
+        unsigned char *base = lds + (kt % S_NSTG) * STG;
+#pragma unroll
+        for (int s = 0; s < PW; s++) {
+            const int q = wave * PW + s;                           // instruction index: 8 rows each
+            const int rb = q * 8, r = rb + (lane >> 3), pc = lane & 7, c = pc ^ ((r >> 1) & 7);
+            if (rb < BM) {                                         // X rows (uniform per instruction)
+                int gr = r; if (gr > T - 1) gr = T - 1;
+                glds16s(X + (size_t)gr * K + kt * S_BK + c * 8, base + rb * 128);
+            } else {
+                int gr = n0 + r - BM; if (gr > N - 1) gr = N - 1;
+                glds16s(W + (size_t)gr * K + kt * S_BK + c * 8, base + rb * 128);
+            }
+        }
+    };
+    // note: the swizzle of a W row uses its row index inside the W tile: r - BM keeps (r >> 1) & 7 since BM % 16 == 0
+#pragma unroll
+    for (int p = 0; p < S_NSTG - 1; p++)
+        if (p < nk) stage(p);
+    for (int kt = 0; kt < nk; kt++) {
+        // tile kt has landed for this wave when at most the two younger tiles' loads are outstanding
+        if (kt + 2 < nk) wait_vmcnt<2 * PW>();
+        else if (kt + 1 < nk) wait_vmcnt<PW>();
+        else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // everyone's tile kt landed; slot (kt+3)%4 is free
+        if (kt + S_NSTG - 1 < nk) stage(kt + S_NSTG - 1);
+        const unsigned char *xt = lds + (kt % S_NSTG) * STG, *wt = xt + XB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int chunk = ks * 4 + kg;
+            bf16x8s b[NT];
+#pragma unroll
+            for (int j = 0; j < NT; j++) b[j] = frag_s(wt, wave * 16 * NT + j * 16 + m16, chunk);
+#pragma unroll
+            for (int i = 0; i < MT; i++) {
+                const bf16x8s a = frag_s(xt, i * 16 + m16, chunk);
+#pragma unroll
+                for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // C/D map of 16x16 MFMA: col = lane & 15 (W row), row = (lane >> 4) * 4 + reg (token)
+    const int cn = lane & 15, rm = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int m = i * 16 + rm + rg;
+            if (m >= T) continue;
+            const float rs = row_scale ? row_scale[m] : 1.0f;
+            if (epi == EPI_GATEUP) {
+                if constexpr (NT == 2) {
+                    const int n = n0 + wave * 32 + cn;               // gate row; up = n + 16
+                    if (n + 16 < N) {
+                        const int qq = (n >> 5) * 16 + (n & 15);
+                        const float gt = acc[i][0][rg] * rs, up = acc[i][1][rg] * rs;
+                        const float a = gt / (1.0f + expf(-gt)) * up;
+                        reinterpret_cast<bf16_t *>(out)[(size_t)m * (N / 2) + qq] = float_to_bf16_bits(a);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    const int n = n0 + wave * 16 * NT + j * 16 + cn;
+                    if (n < N) reinterpret_cast<float *>(out)[(size_t)m * N + n] = acc[i][j][rg] * rs + (bias ? bias[n] : 0.f);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int NT>
+static int launch_skinny_t(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
+                           int epi, const float *row_scale, int ksplit) {
+    constexpr int BN = 64 * NT;
+    constexpr size_t lds = (size_t)S_NSTG * (BM * 128 + BN * 128);
+    auto kern = gemm_skinny_kernel<BM, NT>;
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) {
+        FL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const double bytes = ((double)N * K + (double)T * K) * 2.0;
+    Launcher LL = L; LL.tag = "skinny";
+    return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, dim3((unsigned)((N + BN - 1) / BN), (unsigned)ksplit), dim3(256), lds,
+                     (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, row_scale, ksplit);
+}
+
+bool gemm_skinny_supported(int64_t T, int64_t N, int64_t K) { return T > 1 && T <= 128 && K % S_BK == 0 && K / S_BK >= 4 && N >= 64; }
+
+// K slices for the fp32 epilogue: enough workgroups to cover the chip twice, at least 8 K tiles per slice
+int gemm_skinny_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
+    if (epi != EPI_F32 || max_split <= 1) return 1;
+    const int64_t wgs = (N + 63) / 64;
+    int ks = 1;
+    while (ks < max_split && wgs * ks < 512 && (K / S_BK) / (ks + 1) >= 8) ks++;
+    return ks;
+}
+
+int launch_gemm_skinny(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
+                       int epi, const float *row_scale, int ksplit) {
+    if (!gemm_skinny_supported(T, N, K)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_skinny: unsupported shape");
+    if (ksplit > 1 && (bias || epi != EPI_F32)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "split-K GEMM: fp32 epilogue without bias only");
+    if ((K / S_BK) / ksplit < 1) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_skinny: too many K slices");
+    const bool pair = epi == EPI_GATEUP;                          // a wave must hold gate and up rows
+#define FL_SK(BMV)                                                                                             \
+    return pair ? launch_skinny_t<BMV, 2>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)                   \
+                : launch_skinny_t<BMV, 1>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
+    if (T <= 32) { FL_SK(32) }
+    if (T <= 64) { FL_SK(64) }
+    FL_SK(128)
+#undef FL_SK
+}
+
+}  // namespace fl

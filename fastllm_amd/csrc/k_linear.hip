@@ -110,6 +110,12 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
     static const int force_generic = env_int("FL_FORCE_GENERIC_GEMM", 0);
     if (dtype == FL_DTYPE_BF16) {
         if (T == 1 && gemv_supported(dtype, N, K)) return launch_gemv(L, dtype, plain_args(W, x, bias, y, N, K, epi, row_scale));
+        static const int use_skinny = env_int("FL_GEMM_SKINNY", 1);
+        if (!force_generic && use_skinny && gemm_skinny_supported(T, N, K)) {     // short prompts: a weight stream
+            const int ks = (n_split_out && !bias) ? gemm_skinny_ksplit(T, N, K, epi, max_split) : 1;
+            if (n_split_out) *n_split_out = ks;
+            return launch_gemm_skinny(L, W, x, bias, y, T, N, K, epi, row_scale, ks);
+        }
         if (!force_generic && gemm_mfma_supported(dtype, T, N, K)) {
             const int ks = (n_split_out && !bias) ? gemm_mfma_ksplit(T, N, K, epi, max_split) : 1;
             if (n_split_out) *n_split_out = ks;

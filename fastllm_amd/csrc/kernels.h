@@ -122,6 +122,10 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
                   int max_split = 1, int *n_split_out = nullptr);
 int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
                    int epi, const float *row_scale, int ksplit);
+bool gemm_skinny_supported(int64_t T, int64_t N, int64_t K);
+int gemm_skinny_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split);
+int launch_gemm_skinny(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
+                       int epi, const float *row_scale, int ksplit);
 // cheap capability probes used by tests / DESIGN numbers
 bool gemv_supported(int dtype, int64_t N, int64_t K);
 bool gemm_mfma_supported(int dtype, int64_t T, int64_t N, int64_t K);

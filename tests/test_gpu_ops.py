@@ -111,3 +111,23 @@ def test_8phase_kernel_is_race_free_over_repeats(fa, monkeypatch):
     np.testing.assert_allclose(first, ref, atol=2e-5 * np.sqrt(K) + 1e-5, rtol=1e-5)
     for _ in range(30):
         np.testing.assert_array_equal(fa.op_linear(xb, wb, None), first)
+
+
+# short-prompt GEMM (k_gemm_skinny.hip): every BM bucket (32/64/128/256), ragged T and N, K slices, bias, SiLU gate
+@pytest.mark.parametrize("T,N,K,epi,bias", [(2, 4096, 4096, 0, False), (17, 1000, 1024, 0, True), (33, 6144, 512, 0, True),
+                                            (64, 4096, 2048, 0, False), (65, 200, 256, 0, True), (129, 1000, 1024, 0, False),
+                                            (200, 4096, 4096, 0, False), (256, 3000, 768, 0, True),
+                                            (9, 1792, 1024, 1, False), (48, 704, 512, 1, False), (100, 5632, 2048, 1, False),
+                                            (256, 1408, 1024, 1, False)])
+def test_linear_skinny_kernel(fa, T, N, K, epi, bias):
+    x, w = _rand((T, K), 31), _rand((N if not epi else 2 * N, K), 32, 0.05)
+    b = _rand((N,), 33) if bias else None
+    xb, wb = synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w)
+    y = fa.op_linear(xb, wb, b, epilogue=epi)
+    ref = _ref(synth.bf16_bits_to_f32(xb), synth.bf16_bits_to_f32(wb), b, epi)
+    if epi:
+        np.testing.assert_allclose(y, ref, atol=1e-3, rtol=2 ** -8)
+    else:
+        np.testing.assert_allclose(y, ref, atol=2e-5 * np.sqrt(K) + 1e-5, rtol=1e-5)
+    for _ in range(5):                                            # counted-wait pipeline: same bits every launch
+        np.testing.assert_array_equal(fa.op_linear(xb, wb, b, epilogue=epi), y)
