@@ -243,8 +243,27 @@ bool gemm_mfma_supported(int dtype, int64_t T, int64_t N, int64_t K) {
     return dtype == FL_DTYPE_BF16 && T > 1 && K % BK == 0 && K >= BK && N >= 1;
 }
 
+// K slices that let the 256x256 kernel (one workgroup per CU) cover the chip: 0 if none does
+static int gemm_8p_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
+    if (T < 256 || K % 64) return 0;
+    const int64_t tiles = ((T + 255) / 256) * ((N + 255) / 256);
+    for (int ks = 1; ks <= (epi == EPI_F32 ? max_split : 1); ks++) {
+        if ((K / 64) / ks < 16) break;                              // keep the pipeline long enough to pay for its ramp
+        const int64_t t8 = tiles * ks, rounds = (t8 + 255) / 256;
+        if (t8 >= 200 && t8 * 10 >= rounds * 256 * 8) return ks;
+    }
+    return 0;
+}
+
 // how many K splits the launcher will use for this shape when the caller allows up to max_split slabs
 int gemm_mfma_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
+    {
+        const char *e8 = getenv("FL_GEMM_8P");
+        if (!(e8 && *e8 && atoi(e8) == 0)) {
+            const int k8 = gemm_8p_ksplit(T, N, K, epi, max_split);
+            if (k8 > 0) return k8;
+        }
+    }
     const int64_t tiles = ((T + BM - 1) / BM) * ((N + BN - 1) / BN);
     if (epi != EPI_F32 || max_split <= 1 || tiles >= 256 || K < 2048) return 1;
     int ks = (int)std::min<int64_t>(max_split, 512 / tiles);
