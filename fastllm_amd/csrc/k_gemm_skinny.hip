@@ -7,7 +7,7 @@
 //     (BN = 64 or 128), so the grid is N / BN workgroups -- times a K split for the fp32 epilogue;
 //   * four LDS stages, LDS-DMA three K tiles ahead, ONE raw barrier per K tile and a counted vmcnt (the two
 //     youngest tiles stay in flight across it): up to 48 KB of W per workgroup outstanding;
-//   * 4 waves, each owning 16 (BN = 64) or 32 (BN = 128: a gate/up pair) W rows against every token
+//   * 4 waves (2 when N is small), each owning 16 or 32 (a gate/up pair) W rows against every token
 //     tile, so the W bytes are read from LDS exactly once and the X tile (L2-resident) by all four waves.
 // LDS image as the other GEMM kernels: [rows][64 bf16], chunk index XOR (row >> 1) & 7 on DMA source and read.
 #include <stdlib.h>
@@ -33,16 +33,17 @@ __device__ inline bf16x8s frag_s(const unsigned char *tile, int row, int chunk) 
 
 template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// BM tokens x (64 * NT) weight rows per workgroup; NT n-tiles of 16 rows per wave
-template <int BM, int NT>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
+// BM tokens x (NW * 16 * NT) weight rows per workgroup of NW waves; NT n-tiles of 16 rows per wave
+template <int BM, int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
                                                           const float *__restrict__ bias, void *__restrict__ out,
                                                           int T, int N, int K, int epi, const float *__restrict__ row_scale,
                                                           int ksplit) {
-    constexpr int BN = 64 * NT, MT = BM / 16;
+    constexpr int BN = NW * 16 * NT, MT = BM / 16;
     constexpr int XB = BM * 128, STG = XB + BN * 128;             // bytes per stage
     constexpr int NI = (BM + BN) / 8;                              // 1 KiB DMA instructions per stage
-    constexpr int PW = NI / 4;                                     // ... per wave (BM, BN multiples of 32)
+    constexpr int PW = NI / NW;                                    // ... per wave
+    static_assert(NI % NW == 0, "stage instructions must divide evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m16 = lane & 15, kg = lane >> 4;
@@ -131,12 +132,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t *__restri
     }
 }
 
-template <int BM, int NT>
+template <int BM, int NT, int NW>
 static int launch_skinny_t(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
                            int epi, const float *row_scale, int ksplit) {
-    constexpr int BN = 64 * NT;
+    constexpr int BN = NW * 16 * NT;
     constexpr size_t lds = (size_t)S_NSTG * (BM * 128 + BN * 128);
-    auto kern = gemm_skinny_kernel<BM, NT>;
+    auto kern = gemm_skinny_kernel<BM, NT, NW>;
     static bool attr = false;
     if (!attr && lds > 64 * 1024) {
         FL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -144,7 +145,7 @@ static int launch_skinny_t(Launcher &L, const void *W, const void *x, const floa
     }
     const double bytes = ((double)N * K + (double)T * K) * 2.0;
     Launcher LL = L; LL.tag = "skinny";
-    return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, dim3((unsigned)((N + BN - 1) / BN), (unsigned)ksplit), dim3(256), lds,
+    return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, dim3((unsigned)((N + BN - 1) / BN), (unsigned)ksplit), dim3(NW * 64), lds,
                      (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, row_scale, ksplit);
 }
 
@@ -165,9 +166,13 @@ int launch_gemm_skinny(Launcher &L, const void *W, const void *x, const float *b
     if (ksplit > 1 && (bias || epi != EPI_F32)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "split-K GEMM: fp32 epilogue without bias only");
     if ((K / S_BK) / ksplit < 1) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_skinny: too many K slices");
     const bool pair = epi == EPI_GATEUP;                          // a wave must hold gate and up rows
+    // narrow strips (2 waves) when 4-wave strips would leave most CUs without a workgroup
+    const bool narrow = (N + (pair ? 127 : 63)) / (pair ? 128 : 64) * ksplit < 160;
 #define FL_SK(BMV)                                                                                             \
-    return pair ? launch_skinny_t<BMV, 2>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)                   \
-                : launch_skinny_t<BMV, 1>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
+    if (narrow) return pair ? launch_skinny_t<BMV, 2, 2>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)    \
+                            : launch_skinny_t<BMV, 1, 2>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);   \
+    return pair ? launch_skinny_t<BMV, 2, 4>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)                \
+                : launch_skinny_t<BMV, 1, 4>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
     if (T <= 32) { FL_SK(32) }
     if (T <= 64) { FL_SK(64) }
     FL_SK(128)

@@ -17,6 +17,8 @@ cd $R
 # next-row components and the multi-rank rehearsal (all ranks on this one GPU: protocol check, not a scaling figure)
 timeout -k 10 300 python3 tools/batch_bench.py --profile --batches 1,2,3,4,6,8 > $O/batch_decode_mistral7b.txt 2> $O/batch.err || exit 1
 timeout -k 10 200 python3 tools/sample_cost.py > $O/sample_cost.txt 2> $O/sample.err || exit 1
+timeout -k 10 200 python3 tools/gemm_probe.py > $O/gemm_probe.txt 2> $O/gemm_probe.err || exit 1
+(timeout -k 10 200 python3 tools/prefill_sweep.py mistral-7b; timeout -k 10 200 python3 tools/prefill_sweep.py tinyllama-1.1b) 2> $O/prefill_sweep.err | grep 'T=' > $O/prefill_sweep.txt || exit 1
 for n in 2 4; do
   FL_BENCH_SAME_DEVICE=1 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29520 + n)) bench.py --gpus $n --steps 64 --warmup 8 > $O/bench_tp${n}_same_device.json 2> $O/bench_tp${n}.err || exit 1
 done
