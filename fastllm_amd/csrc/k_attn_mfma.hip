@@ -19,6 +19,10 @@
 // Decode: grid (Hkv, nsplit), 4 waves per workgroup, 32-key tiles round-robin over the waves; the
 // cross-wave and cross-split merge is shared with the VALU kernel (attn_common.h).
 // Prefill: each wave owns one (16-token tile, head); causal + sliding-window mask per column.
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "attn_mfma.h"
 
 namespace fl {
@@ -173,7 +177,7 @@ __device__ inline void stage_kv(const bf16_t *__restrict__ kb, const bf16_t *__r
 }
 
 template <int D>
-__global__ __launch_bounds__(512) void attn_prefill_mfma_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
+__global__ __launch_bounds__(1024) void attn_prefill_mfma_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
                                                                 const bf16_t *__restrict__ vT, const StepState *__restrict__ st,
                                                                 bf16_t *__restrict__ out, int T, int H, int Hkv, int seq_alloc,
                                                                 float scale, int window, int TT) {
@@ -252,7 +256,12 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
                              int64_t window) {
     const int G = (int)(H / Hkv);
     if (G > 8) FL_FAIL(FL_ERR_UNSUPPORTED, "mfma prefill attention: at most 8 query heads per kv head");
-    const int TT = G >= 4 ? 1 : 4 / G;                       // token sub-tiles per workgroup: at least 4 waves
+    // token sub-tiles per workgroup: every staged K/V tile then serves TT x G x 16 query rows.  Measured: G = 4
+    // (Mistral, T = 2048) 4.75 ms with 4 waves, 4.25 with 8, 4.06 with 16; G = 7 (Qwen2, T = 4096) 10.8 ms with 7
+    // waves, 12.3 with 14 (126 VGPRs: 16 waves per CU either way, and a longer token block is more lopsided under
+    // the causal mask)
+    static const int tt_waves = getenv("FL_ATTN_PF_WAVES") ? atoi(getenv("FL_ATTN_PF_WAVES")) : 0;
+    const int TT = tt_waves > 0 ? std::max(1, std::min(16, tt_waves) / G) : (G <= 4 ? 16 / G : 1);
     dim3 grid((unsigned)((T + 16 * TT - 1) / (16 * TT)), (unsigned)Hkv);
     dim3 block((unsigned)(G * TT * 64));
     const size_t lds = 2 * (size_t)(2 * 32 * d * 2);

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__
     if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs half a phase behind
+    if (wr == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs half a phase behind (+10 %, gemm_probe)
 
     bf16x8p fa[4][2], fb0[2][2], fb1[2][2];
     const int arow = wr * 64 + m16, brow = wc * 32 + m16;
@@ -110,13 +110,11 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__
 #define P_MFMA(MI0, NJ0, FB)                                                           \
     __builtin_amdgcn_s_barrier();                                                      \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-    __builtin_amdgcn_s_setprio(1);                                                     \
+    __builtin_amdgcn_sched_barrier(0);   /* pins the cluster between the barriers; s_setprio around it: -2.5 % */ \
     _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                   \
         _Pragma("unroll") for (int i = 0; i < 4; i++)                                  \
             _Pragma("unroll") for (int j = 0; j < 2; j++)                              \
                 acc[MI0 + i][NJ0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], FB[j][ks], acc[MI0 + i][NJ0 + j], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                 \
     __builtin_amdgcn_s_barrier();
 
