@@ -170,3 +170,27 @@ def test_window_4096_crossed_vs_oracle(env, dtype):
         check_logits(gm.forward(g2, ids[:T], 0), om.forward(o2, ids[:T], 0), dtype, "chunked 4300-token prefill, window 4096")
     finally:
         del os.environ["FL_PREFILL_CHUNK"]
+
+
+def test_mistral_7b_long_prompt_chunked(env, monkeypatch):
+    """A 20000-token prompt at full size (max_position_embeddings 32768, window 4096): the library cuts it into
+    8192-token chunks; a different chunking gives the same logits, and decoding on from S = 20000 works."""
+    torch, fa, bench = env
+    from fastllm_amd.configs import MODEL_CONFIGS
+    cfg = MODEL_CONFIGS["mistral-7b"]
+    wts = bench.synth_device_weights(torch, cfg, torch.device("cuda", 0), seed=12)
+    gm = fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16")
+    del wts
+    torch.cuda.empty_cache()
+    T = 20000
+    p = synth.prompt_ids(cfg, T, seed=6)
+    c1 = gm.new_cache(T + 16)
+    a = gm.forward(c1, p, 0)
+    d1 = gm.forward(c1, [5], T)
+    monkeypatch.setenv("FL_PREFILL_CHUNK", "3000")
+    c2 = gm.new_cache(T + 16)
+    close_bf16(gm.forward(c2, p, 0), a, "20000-token prompt, 3000- vs 8192-token chunks")
+    close_bf16(gm.forward(c2, [5], T), d1, "decode at S = 20001")
+    toks = gm.decode_greedy(c1, int(np.argmax(d1)), T + 1, 8)
+    assert len(toks) == 8 and len(c1) == T + 9
+    gm.close()
