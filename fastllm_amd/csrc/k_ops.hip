@@ -140,6 +140,63 @@ int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st
                     (int)Hkv, (int)d, (int)max_seq, (int)v_transposed);
 }
 
+// ------------------------------------------------------------------------------- batched variants (row N4)
+// One row per sequence of a batch: the token, RoPE position, KV slot and caches come from its SeqRef.
+__global__ __launch_bounds__(256) void embed_batch_kernel(const bf16_t *__restrict__ E, const SeqRef *__restrict__ seqs,
+                                                          float *__restrict__ x, int h) {
+    const int b = blockIdx.x;
+    const bf16_t *row = E + (size_t)seqs[b].st->token * h;
+    float *dst = x + (size_t)b * h;
+    for (int c = threadIdx.x; c * 8 < h; c += 256) {
+        float v[8];
+        load8(row + c * 8, v);
+        store8(dst + c * 8, v);
+    }
+}
+
+int launch_embed_batch(Launcher &L, const void *E, const SeqRef *seqs_dev, float *x_res, int B, int64_t h) {
+    return L.launch(KC_EMBED, (double)B * h * 6, 0, embed_batch_kernel, dim3((unsigned)B), dim3(256), 0, (const bf16_t *)E, seqs_dev,
+                    x_res, (int)h);
+}
+
+// qkv fp32 [B][(H+2Hkv)*d] -> RoPE -> q bf16 [B][H*d], rotated k and v appended to each sequence's own cache
+// (V transposed, the MFMA attention layout); kv_layer_off = layer * Hkv * d, times the sequence's seq_alloc
+__global__ __launch_bounds__(256) void rope_kv_batch_kernel(const float *__restrict__ qkv, const SeqRef *__restrict__ seqs,
+                                                            const float *__restrict__ cos_tab, const float *__restrict__ sin_tab,
+                                                            int max_pos, bf16_t *__restrict__ q_out, size_t kv_layer_off, int B,
+                                                            int H, int Hkv, int d) {
+    const int half = d >> 1;
+    const int nheads = H + 2 * Hkv;
+    const int per_t = nheads * half;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * per_t) return;
+    const int b = (int)(idx / per_t), rem = (int)(idx % per_t);
+    const int hd = rem / half, j = rem % half;
+    const SeqRef &sq = seqs[b];
+    const float *src = qkv + (size_t)b * nheads * d + (size_t)hd * d;
+    const float a = src[j], bb = src[j + half];
+    const uint32_t pos = sq.st->pos, slot = sq.st->len;
+    const size_t sa = (size_t)sq.seq_alloc;
+    if (hd < H + Hkv) {
+        const uint32_t p = pos < (uint32_t)max_pos ? pos : (uint32_t)max_pos - 1;
+        const float c = cos_tab[(size_t)p * half + j], s = sin_tab[(size_t)p * half + j];
+        const float ra = a * c - bb * s, rb = a * s + bb * c;
+        bf16_t *o = hd < H ? q_out + ((size_t)b * H + hd) * d
+                           : reinterpret_cast<bf16_t *>(sq.k) + kv_layer_off * sa + ((size_t)(hd - H) * sa + slot) * d;
+        elem<bf16_t>::st(o + j, ra); elem<bf16_t>::st(o + j + half, rb);
+    } else {
+        bf16_t *o = reinterpret_cast<bf16_t *>(sq.v) + kv_layer_off * sa + (size_t)(hd - H - Hkv) * d * sa + slot;
+        elem<bf16_t>::st(o + (size_t)j * sa, a); elem<bf16_t>::st(o + (size_t)(j + half) * sa, bb);
+    }
+}
+
+int launch_rope_kv_batch(Launcher &L, const float *qkv, const SeqRef *seqs_dev, const float *cos_tab, const float *sin_tab,
+                         int64_t max_pos, void *q_out, size_t kv_layer_off, int B, int64_t H, int64_t Hkv, int64_t d) {
+    const int64_t total = (int64_t)B * (H + 2 * Hkv) * (d / 2);
+    return L.launch(KC_ROPE_KV, (double)B * (H + 2 * Hkv) * d * 6, 0, rope_kv_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
+                    0, qkv, seqs_dev, cos_tab, sin_tab, (int)max_pos, (bf16_t *)q_out, kv_layer_off, B, (int)H, (int)Hkv, (int)d);
+}
+
 // ------------------------------------------------------------------------------- token selection + advance
 // LogitsProcessor::sample (mod.rs:308-310,425-428) on the device, then the loop-carried state of
 // mod.rs:411-453 (token, pos, len, step, eos) is advanced so that a captured decode graph can be

@@ -103,6 +103,9 @@ int launch_gemv_batch(Launcher &L, const GemvBatchArgs &a);
 // q / out bf16 [B][H*d]; kv_layer_off = layer * Hkv * d (times each sequence's seq_alloc inside)
 int launch_attn_decode_mfma_batch(Launcher &L, const void *q, const SeqRef *seqs_dev, int B, int max_nsplit, size_t kv_layer_off,
                                   void *out, int64_t H, int64_t Hkv, int64_t d, float scale, double kv_bytes_hint);
+int launch_embed_batch(Launcher &L, const void *E, const SeqRef *seqs_dev, float *x_res, int B, int64_t h);
+int launch_rope_kv_batch(Launcher &L, const float *qkv, const SeqRef *seqs_dev, const float *cos_tab, const float *sin_tab,
+                         int64_t max_pos, void *q_out, size_t kv_layer_off, int B, int64_t H, int64_t Hkv, int64_t d);
 // logits fp32 [B][V] -> every sequence's token / step state
 int launch_select_advance_batch(Launcher &L, const float *logits, int64_t V, const SeqRef *seqs_dev, int B, int advance);
 

@@ -134,6 +134,8 @@ struct Batch {
     Model *m = nullptr;
     std::vector<Cache *> caches;
     int B = 0, max_nsplit = 1, nks_o = 1, nks_down = 1;
+    bool unfused = false;                        // large B: norm / GEMM / RoPE as separate launches around the short-prompt GEMM
+    Scratch sc;                                  // ... with the prefill scratch layout at T = B
     SeqRef *seqs_dev = nullptr;
     float *x_res = nullptr, *x_res2 = nullptr;   // [B][h]
     float *delta = nullptr;                      // [max(nks_o, nks_down)][B][h]
