@@ -31,6 +31,10 @@ __device__ inline bf16x8s frag_s(const unsigned char *tile, int row, int chunk) 
     return *reinterpret_cast<const bf16x8s *>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
+// beyond BM = 128 tokens the kernel can run ceil(T / 128) token blocks per strip (FL_GEMM_SKINNY_MAXT moves the
+// limit), but the 128x128 kernel is then faster: Mistral-7B prefill T = 256 9.8 vs 9.2 ms, T = 512 18.3 vs 11.7 ms
+static const int kSkinnyMaxT = getenv("FL_GEMM_SKINNY_MAXT") ? atoi(getenv("FL_GEMM_SKINNY_MAXT")) : 128;
+
 template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // BM tokens x (NW * 16 * NT) weight rows per workgroup of NW waves; NT n-tiles of 16 rows per wave
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t *__re
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m16 = lane & 15, kg = lane >> 4;
-    const int n0 = blockIdx.x * BN;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.z * BM;       // blockIdx.z: token block (T > BM: W strips are re-read through L2)
     const int nk_all = K / S_BK, kz = blockIdx.y;
     const int kt0 = (int)((long long)nk_all * kz / ksplit), nk = (int)((long long)nk_all * (kz + 1) / ksplit) - kt0;
     X += (size_t)kt0 * S_BK; W += (size_t)kt0 * S_BK;
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t *__re
             const int q = wave * PW + s;                           // instruction index: 8 rows each
             const int rb = q * 8, r = rb + (lane >> 3), pc = lane & 7, c = pc ^ ((r >> 1) & 7);
             if (rb < BM) {                                         // X rows (uniform per instruction)
-                int gr = r; if (gr > T - 1) gr = T - 1;
+                int gr = m0 + r; if (gr > T - 1) gr = T - 1;
                 glds16s(X + (size_t)gr * K + kt * S_BK + c * 8, base + rb * 128);
             } else {
                 int gr = n0 + r - BM; if (gr > N - 1) gr = N - 1;
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t *__re
     for (int i = 0; i < MT; i++) {
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
-            const int m = i * 16 + rm + rg;
+            const int m = m0 + i * 16 + rm + rg;
             if (m >= T) continue;
             const float rs = row_scale ? row_scale[m] : 1.0f;
             if (epi == EPI_GATEUP) {
@@ -145,11 +149,11 @@ static int launch_skinny_t(Launcher &L, const void *W, const void *x, const floa
     }
     const double bytes = ((double)N * K + (double)T * K) * 2.0;
     Launcher LL = L; LL.tag = "skinny";
-    return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, dim3((unsigned)((N + BN - 1) / BN), (unsigned)ksplit), dim3(NW * 64), lds,
+    return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, dim3((unsigned)((N + BN - 1) / BN), (unsigned)ksplit, (unsigned)((T + BM - 1) / BM)), dim3(NW * 64), lds,
                      (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, row_scale, ksplit);
 }
 
-bool gemm_skinny_supported(int64_t T, int64_t N, int64_t K) { return T > 1 && T <= 128 && K % S_BK == 0 && K / S_BK >= 4 && N >= 64; }
+bool gemm_skinny_supported(int64_t T, int64_t N, int64_t K) { return T > 1 && T <= kSkinnyMaxT && K % S_BK == 0 && K / S_BK >= 4 && N >= 64; }
 
 // K slices for the fp32 epilogue: enough workgroups to cover the chip twice, at least 8 K tiles per slice
 int gemm_skinny_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
@@ -167,7 +171,7 @@ int launch_gemm_skinny(Launcher &L, const void *W, const void *x, const float *b
     if ((K / S_BK) / ksplit < 1) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_skinny: too many K slices");
     const bool pair = epi == EPI_GATEUP;                          // a wave must hold gate and up rows
     // narrow strips (2 waves) when 4-wave strips would leave most CUs without a workgroup
-    const bool narrow = (N + (pair ? 127 : 63)) / (pair ? 128 : 64) * ksplit < 160;
+    const bool narrow = (N + (pair ? 127 : 63)) / (pair ? 128 : 64) * ksplit * ((T + 127) / 128) < 160;
 #define FL_SK(BMV)                                                                                             \
     if (narrow) return pair ? launch_skinny_t<BMV, 2, 2>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)    \
                             : launch_skinny_t<BMV, 1, 2>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);   \
