@@ -337,11 +337,10 @@ __device__ inline float sequential_sum(float *__restrict__ p, int V, float *tile
 // exactly (incoming exponent == k, outgoing m <= 2^24).  Runs that cross a binade, start at 0 or sit too
 // close to a power of two to be guessed are "slow": their elements are parked in LDS and the lane adds
 // them one by one in fp32.  A distribution crosses ~25 binades on its way to 1, so a few dozen runs
-// are slow and the rest cost one chain step each.  Measured (MI355X, one workgroup): the chain step is ~45
-// scalar instructions at a single wave's issue rate (one per ~5 cycles), so the 1024 steps take ~120 us; the
-// one-lane walk costs ~7 cycles per element, i.e. the two meet at V ~ 32k and ordered_sum is 2.6x faster at
-// Qwen2's V = 152k.  Next step: compose same-binade stretches with a parity-transducer scan (the step map
-// m -> m + inc[m & 1] is associative on (inc[0], inc[1])) so that the serial part is one step per stretch.
+// are slow and the rest cost one chain step each.  A chain step is ~45 scalar instructions at a single wave's issue
+// rate (one per ~5 cycles): 1024 of them took ~120 us, so each wave first composes its 64 runs (phase C0) and the
+// chain is per 64-run group wherever a group is uniform.  Measured per sampled token (one workgroup): 0.15 ms at
+// V = 32000, 0.34 ms at V = 152064; the one-lane walk: 0.45 / 2.6 ms.
 constexpr int kSlowSlots = 56;          // LDS slots for slow runs (more fall back to global reads)
 constexpr int kMaxRun = 152;            // elements per thread: V <= 1024 * 152 = 155648 (Qwen2: 152064)
 struct OrderedSumLds {
@@ -350,6 +349,8 @@ struct OrderedSumLds {
     short kexp[1024];                   // guessed biased exponent of a fast run, -1: slow
     short slot[1024];                   // LDS slot of a slow run, -1: read from global
     float wtot[16];
+    int g_mode[16], g_ke[16], g_inc0[16], g_inc1[16];   // per 64-run group: 0 chain it, 1 uniform (one step), 2 empty
+    uint32_t g_sb[16];                    // bits of the sum entering a uniform / empty group
     int nslots;
     float parked[kSlowSlots * kMaxRun];
 };
@@ -421,12 +422,49 @@ __device__ inline float ordered_sum(const float *__restrict__ p, int V, OrderedS
     }
     L.slot[tid] = myslot;
     __syncthreads();
-    // phase C: wave 0 chains the runs.  The per-run data sits in vector registers (lane j = run 64g + j)
-    // and is read back with v_readlane, so the chain itself is wave-uniform integer arithmetic; a slow
-    // run is walked in fp32 by a separate function.
+    // phase C0 (all 16 waves): a wave composes its 64 runs.  The fast step m -> m + inc[m & 1] acts on the mantissa
+    // parity only through inc, so two consecutive steps compose to another such pair,
+    //     (L then R)[p] = L[p] + R[(p + L[p]) & 1],
+    // which is associative: a wave-level scan gives every run its increment from the start of the group for either
+    // entering parity, and the group's total.  A group is "uniform" when all its runs are fast in the same binade.
+    const int c_me = tid, ke_me = L.kexp[c_me];
+    const bool empty_me = n == 0;
+    int t0 = empty_me ? 0 : L.inc0[c_me], t1 = empty_me ? 0 : L.inc1[c_me];        // inclusive transducer prefix (so far: own)
+    {
+        const unsigned long long fastm = __ballot(!empty_me && ke_me >= 0), usedm = __ballot(!empty_me);
+        const int first = usedm ? __builtin_ctzll(usedm) : 0;
+        const int ke_ref = __shfl(ke_me, first, 64);
+        const bool uniform = usedm != 0 && fastm == usedm && __ballot(!empty_me && ke_me != ke_ref) == 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int l0 = __shfl_up(t0, o, 64), l1 = __shfl_up(t1, o, 64);
+            if (lane >= o) {
+                const int n0v = l0 + ((l0 & 1) ? t1 : t0), n1v = l1 + (((1 + l1) & 1) ? t1 : t0);
+                t0 = n0v; t1 = n1v;
+            }
+        }
+        if (lane == 63) { L.g_mode[wave] = usedm == 0 ? 2 : (uniform ? 1 : 0); L.g_ke[wave] = ke_ref; L.g_inc0[wave] = t0; L.g_inc1[wave] = t1; }
+    }
+    __syncthreads();
+    // phase C1: wave 0 chains the 16 groups.  A uniform group is one integer step (checked exactly: entering
+    // exponent == its binade, leaving mantissa <= 2^24); any other group is chained run by run -- per-run data in vector
+    // registers (lane j = run 64g + j) read back with v_readlane, slow runs walked in fp32.
     if (wave == 0) {
         uint32_t sb = 0;                                             // bits of the running sum (>= 0)
         for (int g = 0; g < 16; g++) {
+            const int mode = L.g_mode[g];
+            if (mode == 2) { if (lane == 0) L.g_sb[g] = sb; continue; }
+            if (mode == 1) {
+                const int ke = L.g_ke[g];
+                const uint32_t m = (sb & 0x7fffffu) | 0x800000u;
+                const uint32_t m2 = m + (uint32_t)((m & 1) ? L.g_inc1[g] : L.g_inc0[g]);
+                if ((int)(sb >> 23) == ke && m2 <= 0x1000000u) {
+                    if (lane == 0) L.g_sb[g] = sb;
+                    sb = ((uint32_t)ke << 23) + (m2 - 0x800000u);
+                    continue;
+                }
+                if (lane == 0) L.g_mode[g] = 0;                      // the guess did not hold: chain it
+            }
             const int c = g * 64 + lane;
             const int ke_v = L.kexp[c], a0_v = L.inc0[c], a1_v = L.inc1[c], sl_v = L.slot[c];
             uint32_t sin_v = 0;
@@ -447,6 +485,22 @@ __device__ inline float ordered_sum(const float *__restrict__ p, int V, OrderedS
             L.s_in[c] = __uint_as_float(sin_v);
         }
         if (lane == 0) L.s_in[1024] = __uint_as_float(sb);
+    }
+    __syncthreads();
+    // phase C2 (all waves): runs of a uniform group get their entering sum from the group's and their scan prefix
+    {
+        const int mode = L.g_mode[wave];
+        if (mode != 0) {
+            const uint32_t gsb = L.g_sb[wave];
+            uint32_t mine = gsb;
+            if (mode == 1) {
+                const int e0 = __shfl_up(t0, 1, 64), e1 = __shfl_up(t1, 1, 64);        // exclusive prefix = inclusive of lane - 1
+                const uint32_t m = (gsb & 0x7fffffu) | 0x800000u;
+                const int excl = lane == 0 ? 0 : ((m & 1) ? e1 : e0);
+                mine = ((uint32_t)L.g_ke[wave] << 23) + (m + (uint32_t)excl - 0x800000u);
+            }
+            L.s_in[tid] = __uint_as_float(mine);
+        }
     }
     __syncthreads();
     return L.s_in[1024];
