@@ -36,6 +36,8 @@ const char *last_error() { return g_err; }
 
 static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
 static int comm_alloc(Model *m, Shard &sh);
+struct PeerComm;
+static void comm_set_entry(PeerComm &pc, int r, void *base);
 static int comm_bootstrap_over_rccl(Model *m);
 static int comm_check(Model *m);
 
@@ -427,10 +429,41 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
 
     // communicators
     if (tp > 1 && P.mode == FL_TP_SINGLE_PROCESS) {
+        // One process drives all tp GPUs (the reference's process model).  The inboxes of the one-shot collectives
+        // are then plain peer pointers -- no IPC -- and because those collectives synchronise through memory, every
+        // shard's decode step is an independent hipGraph on its own stream.  RCCL (group calls) carries the large
+        // prefill collectives; it refuses two ranks on one device, so a group with repeated device ids (a one-GPU
+        // rehearsal) runs everything one-shot.
+        if (tp > FL_MAX_TP) FL_FAIL(FL_ERR_UNSUPPORTED, "tp_size %d > %d", tp, FL_MAX_TP);
         std::vector<int> devs; for (auto &sh : m->shards) devs.push_back(sh.device);
-        std::vector<ncclComm_t> comms(tp);
-        FL_NCCL(ncclCommInitAll(comms.data(), tp, devs.data()));
-        for (int i = 0; i < tp; i++) m->shards[i].comm = comms[i];
+        bool distinct = true;
+        for (int i = 0; i < tp; i++) for (int j = 0; j < i; j++) distinct = distinct && devs[i] != devs[j];
+        if (distinct) {
+            std::vector<ncclComm_t> comms(tp);
+            FL_NCCL(ncclCommInitAll(comms.data(), tp, devs.data()));
+            for (int i = 0; i < tp; i++) m->shards[i].comm = comms[i];
+        }
+        if (env_int("FL_ONESHOT", 1) || !distinct) {
+            bool ok = true;
+            for (int i = 0; i < tp && ok; i++) ok = comm_alloc(m.get(), m->shards[i]) == FL_OK;
+            for (int i = 0; i < tp && ok; i++) {
+                (void)hipSetDevice(devs[i]);
+                for (int j = 0; j < tp && ok; j++) {
+                    if (devs[j] == devs[i]) continue;
+                    const hipError_t e = hipDeviceEnablePeerAccess(devs[j], 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = false;
+                    (void)hipGetLastError();
+                }
+            }
+            if (ok) {
+                for (int i = 0; i < tp; i++) {
+                    for (int r = 0; r < tp; r++) comm_set_entry(m->shards[i].pc, r, m->shards[r].pc.local);
+                    m->shards[i].pc.connected = true;
+                }
+            } else if (!distinct) {
+                FL_FAIL(FL_ERR_RCCL, "cannot connect the shards of a single-device tensor-parallel group");
+            }
+        }
     } else if (tp > 1 && P.mode == FL_TP_MULTI_PROCESS) {
         // Small collectives (decode) go over peer-mapped inboxes; RCCL carries the large prefill ones.
         // Without a unique_id there is no RCCL communicator: the host must connect the inboxes itself
@@ -727,7 +760,17 @@ static int all_reduce_delta(Model *m, bool pre, int64_t count) {
         Launcher L = make_launcher(m, s0);
         return launch_reduce_shards(L, tab, m->tp, count);
     }
-    if (m->tp_mode == FL_TP_MULTI_PROCESS || m->shards[0].pc.connected) {
+    if (m->tp_mode == FL_TP_SINGLE_PROCESS) {
+        Shard &s0 = m->shards[0];
+        if (s0.pc.connected && (count <= s0.pc.nmax || !s0.comm)) {
+            for (auto &sh : m->shards) {
+                FL_HIP(hipSetDevice(sh.device));
+                float *buf = pre ? sh.pre.delta : sh.dec.delta;
+                FL_TRY(oneshot(m, sh, false, buf, buf, count, 0));
+            }
+            return FL_OK;
+        }
+    } else if (m->tp_mode == FL_TP_MULTI_PROCESS || m->shards[0].pc.connected) {
         Shard &sh = m->shards[0];
         float *buf = pre ? sh.pre.delta : sh.dec.delta;
         if (sh.pc.connected && (count <= sh.pc.nmax || !sh.comm)) return oneshot(m, sh, false, buf, buf, count, 0);
@@ -757,6 +800,13 @@ static int gather_logits(Model *m) {
         for (auto &dst : m->shards)
             for (auto &src : m->shards)
                 FL_HIP(hipMemcpyAsync(dst.logits_full + src.v0, src.logits_local, (size_t)src.Vs * 4, hipMemcpyDeviceToDevice, s0.stream));
+        return FL_OK;
+    }
+    if (m->tp_mode == FL_TP_SINGLE_PROCESS && m->shards[0].pc.connected && (m->shards[0].Vs <= m->shards[0].pc.nmax || !m->shards[0].comm)) {
+        for (auto &sh : m->shards) {
+            FL_HIP(hipSetDevice(sh.device));
+            FL_TRY(oneshot(m, sh, true, sh.logits_local, sh.logits_full, sh.Vs, sh.Vs));
+        }
         return FL_OK;
     }
     if (m->tp_mode == FL_TP_MULTI_PROCESS) {
@@ -934,36 +984,56 @@ static int sync_all(Model *m) {
 // TinyLlama scale); captured lazily on the second step of a cache so that all lazy module /
 // attribute initialisation has already happened eagerly.
 static int decode_step(Model *m, Cache *c, int64_t len_hint) {
-    // one shard per process: plain single-GPU, or one rank of a multi-process TP group (RCCL collectives
-    // are stream-ordered and capturable; every rank captures the same sequence)
+    // Graphs: one shard per process (plain single GPU, or one rank of a multi-process TP group: RCCL collectives are
+    // stream-ordered and capturable, every rank captures the same sequence); or all shards of a single-process group
+    // whose collectives are one-shot (they synchronise through memory, so each shard's step is its own graph).
     static const int tp_graph = env_int("FL_TP_GRAPH", 1);
-    const bool one_shard = m->shards.size() == 1 && (m->tp == 1 || (m->tp_mode == FL_TP_MULTI_PROCESS && tp_graph));
-    const bool graphable = m->use_graph && !m->profiling && one_shard && !c->graph_failed;
+    const size_t ns = m->shards.size();
+    const bool one_shard = ns == 1 && (m->tp == 1 || (m->tp_mode == FL_TP_MULTI_PROCESS && tp_graph));
+    const bool local_group = ns > 1 && m->tp_mode == FL_TP_SINGLE_PROCESS && tp_graph && m->shards[0].pc.connected &&
+                             m->D.h <= m->shards[0].pc.nmax && m->shards[0].Vs <= m->shards[0].pc.nmax;
+    const bool graphable = m->use_graph && !m->profiling && (one_shard || local_group) && !c->graph_failed;
     if (graphable && c->shards[0].graph) {
-        FL_HIP(hipSetDevice(m->shards[0].device));
-        FL_HIP(hipGraphLaunch(c->shards[0].graph, m->shards[0].stream));
+        for (size_t i = 0; i < ns; i++) {
+            FL_HIP(hipSetDevice(m->shards[i].device));
+            FL_HIP(hipGraphLaunch(c->shards[i].graph, m->shards[i].stream));
+        }
         return FL_OK;
     }
     if (graphable && c->warm_steps >= 1) {
-        Shard &sh = m->shards[0];
-        FL_HIP(hipSetDevice(sh.device));
-        hipGraph_t g = nullptr;
-        bool ok = hipStreamBeginCapture(sh.stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        std::vector<hipGraph_t> gs(ns, nullptr);
+        bool ok = true;
+        size_t begun = 0;
+        for (; begun < ns && ok; begun++) {
+            FL_HIP(hipSetDevice(m->shards[begun].device));
+            ok = hipStreamBeginCapture(m->shards[begun].stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (!ok) break;
+        }
         int rc = FL_OK;
         if (ok) {
             rc = enqueue_forward(m, c, false, 1, false, len_hint);
             if (rc == FL_OK) rc = enqueue_argmax(m, c, 1);
-            hipError_t e = hipStreamEndCapture(sh.stream, &g);
-            ok = rc == FL_OK && e == hipSuccess && g != nullptr;
         }
-        if (ok) ok = hipGraphInstantiate(&c->shards[0].graph, g, nullptr, nullptr, 0) == hipSuccess;
-        if (g) (void)hipGraphDestroy(g);
+        for (size_t i = 0; i < begun; i++) {
+            (void)hipSetDevice(m->shards[i].device);
+            const hipError_t e = hipStreamEndCapture(m->shards[i].stream, &gs[i]);
+            ok = ok && rc == FL_OK && e == hipSuccess && gs[i] != nullptr;
+        }
+        for (size_t i = 0; i < ns && ok; i++) {
+            (void)hipSetDevice(m->shards[i].device);
+            ok = hipGraphInstantiate(&c->shards[i].graph, gs[i], nullptr, nullptr, 0) == hipSuccess;
+        }
+        for (auto g : gs) if (g) (void)hipGraphDestroy(g);
         if (ok) {
-            FL_HIP(hipGraphLaunch(c->shards[0].graph, sh.stream));
+            for (size_t i = 0; i < ns; i++) {
+                FL_HIP(hipSetDevice(m->shards[i].device));
+                FL_HIP(hipGraphLaunch(c->shards[i].graph, m->shards[i].stream));
+            }
             return FL_OK;
         }
         (void)hipGetLastError();
-        c->graph_failed = true; c->shards[0].graph = nullptr;      // fall through to eager launches
+        for (size_t i = 0; i < ns; i++) if (c->shards[i].graph) { (void)hipGraphExecDestroy(c->shards[i].graph); c->shards[i].graph = nullptr; }
+        c->graph_failed = true;                                     // fall through to eager launches
     }
     FL_TRY(enqueue_forward(m, c, false, 1, false, len_hint));
     FL_TRY(enqueue_argmax(m, c, 1));

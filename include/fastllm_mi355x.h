@@ -97,7 +97,9 @@ typedef struct fl_tensor {
 typedef enum fl_tp_mode {
     FL_TP_NONE = 0,                 /* one GPU: device_ids[0] (or device 0 if NULL) */
     FL_TP_SINGLE_PROCESS = 1,       /* this process drives tp_size GPUs (device_ids[tp_size]); the
-                                       shape of the reference's one-process server (main.rs:128) */
+                                       shape of the reference's one-process server (main.rs:128).  Decode
+                                       collectives are one-shot pushes over peer pointers, one hipGraph per
+                                       shard; RCCL group calls carry the large prefill collectives */
     FL_TP_MULTI_PROCESS = 2,        /* one process per GPU: this process is tp_rank of tp_size.  With a
                                        unique_id it joins that RCCL communicator (large prefill
                                        collectives) and connects the peer inboxes for the small decode

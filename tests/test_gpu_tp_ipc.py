@@ -90,3 +90,30 @@ def test_unconnected_group_fails_loudly():
     with pytest.raises(fa.FastLLMError) as e:
         m.forward(c, [1, 2, 3], 0)
     assert "not connected" in str(e.value)
+
+
+@pytest.mark.parametrize("name,tp,dtype", [("llama_a", 2, "bf16"), ("qwen2_a", 2, "f32"), ("mistral_a", 2, "bf16")])
+def test_single_process_group_on_one_device(name, tp, dtype):
+    """FL_TP_SINGLE_PROCESS (one process drives all shards: the reference's process model) with every shard on
+    device 0: the one-shot collectives over plain peer pointers, one hipGraph per shard replayed side by side.
+    Same partition and summation order as FL_TP_EMULATED, so the results must be the same bits.  (Two shards only:
+    on ONE device the shards' streams share the process's few hardware queues, and a shard whose launches queue
+    behind another shard's waiting collective can never signal it; with one device per shard that cannot happen.)"""
+    import fastllm_amd as fa
+    from fastllm_amd import binding
+    cfg = synth.CONFIGS[name]
+    w = synth.synth_weights(cfg)
+    gS = fa.Model(cfg, w, dtype=dtype, tp_mode=binding.TP_SINGLE_PROCESS, tp_size=tp, device_ids=[0] * tp)
+    gE = fa.Model(cfg, w, dtype=dtype, tp_mode=binding.TP_EMULATED, tp_size=tp)
+    assert gS.info().small_collectives == 2
+    ids = synth.prompt_ids(cfg, 14, seed=11)
+    cS, cE = gS.new_cache(64), gE.new_cache(64)
+    np.testing.assert_array_equal(gS.forward(cS, ids[:10], 0), gE.forward(cE, ids[:10], 0))
+    for i in range(10, 14):
+        np.testing.assert_array_equal(gS.forward(cS, ids[i:i + 1], i), gE.forward(cE, ids[i:i + 1], i))
+    f = gS.forward_argmax(cS, ids[:1], 14)
+    assert f == gE.forward_argmax(cE, ids[:1], 14)
+    np.testing.assert_array_equal(gS.decode_greedy(cS, f, 15, 20), gE.decode_greedy(cE, f, 15, 20))
+    assert len(cS) == 35
+    gS.close()
+    gE.close()
