@@ -50,6 +50,7 @@ def synth_device_weights(torch, cfg, device, seed=1234, n_layers=None):
         else:
             t = 0.02 * t
         out[name] = t.to(torch.bfloat16).contiguous()
+    torch.cuda.synchronize(device)      # the library reads these on its own streams: they must be complete
     return out
 
 

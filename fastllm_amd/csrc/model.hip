@@ -409,9 +409,16 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
     }
 
     Builder B; B.m = m.get();
+    bool device_sources = false;
     for (size_t i = 0; i < n; i++) {
         if (!tensors[i].name) FL_FAIL(FL_ERR_BAD_ARGUMENT, "tensor %zu has no name", i);
         B.map[tensors[i].name] = &tensors[i];
+        device_sources = device_sources || tensors[i].device >= 0;
+    }
+    if (device_sources) {
+        // source tensors already in HBM may still be in flight on the caller's streams (a framework's generator or
+        // loader); the conversion kernels run on this model's own streams, so wait for the devices first
+        for (auto &sh : m->shards) { FL_HIP(hipSetDevice(sh.device)); FL_HIP(hipDeviceSynchronize()); }
     }
     FL_TRY(build_weights(B));
     FL_TRY(build_rope(m.get()));

@@ -189,7 +189,8 @@ def test_mistral_7b_long_prompt_chunked(env, monkeypatch):
     d1 = gm.forward(c1, [5], T)
     monkeypatch.setenv("FL_PREFILL_CHUNK", "3000")
     c2 = gm.new_cache(T + 16)
-    close_bf16(gm.forward(c2, p, 0), a, "20000-token prompt, 3000- vs 8192-token chunks")
+    b = gm.forward(c2, p, 0)
+    close_bf16(b, a, "20000-token prompt, 3000- vs 8192-token chunks")
     close_bf16(gm.forward(c2, [5], T), d1, "decode at S = 20001")
     toks = gm.decode_greedy(c1, int(np.argmax(d1)), T + 1, 8)
     assert len(toks) == 8 and len(c1) == T + 9
