@@ -82,7 +82,8 @@ typedef struct fl_config {
  * Borrowed for the duration of fl_model_create only; the library copies, shards and
  * re-lays-out into HBM.  `device` < 0: `data` is host memory; >= 0: `data` is a device
  * pointer on that HIP device (the reference loads safetensors straight onto `device`,
- * huggingface.rs:88,125). */
+ * huggingface.rs:88,125); fl_model_create synchronises the devices before it reads such
+ * tensors, so work still in flight on the caller's streams is waited for. */
 typedef struct fl_tensor {
     const char *name;               /* HF name, e.g. "model.layers.0.self_attn.q_proj.weight" */
     int32_t dtype;                  /* fl_dtype */
