@@ -135,6 +135,9 @@ def main():
     same_device = world > 1 and os.environ.get("FL_BENCH_SAME_DEVICE", "0") == "1"
     if same_device:
         local_rank = 0
+        # two processes with two live HIP queues each on ONE card make every launch of both ~25 us slower (measured:
+        # profiles/r01/README.md); that is an artefact of the rehearsal, so keep the prefill's side stream out of it
+        os.environ.setdefault("FL_TP_OVERLAP", "0")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:

@@ -62,6 +62,8 @@ struct Shard {
     int device = 0;
     int rank = 0;                // TP rank this shard plays
     hipStream_t stream = nullptr;
+    hipStream_t comm_stream = nullptr;   // prefill all-reduces of one token chunk run here while the next chunk computes
+    hipEvent_t ev[8] = {};               // e0 e1 (o_proj chunk done) h0 h1 (its all-reduce done) f0 f1 (down done) g0 g1 (reduced)
     int64_t Hs = 0, Hkvs = 0, Is = 0, Ip = 0, Vs = 0, v0 = 0;
     void *embed = nullptr;       // [V,h]
     std::vector<LayerW> layers;

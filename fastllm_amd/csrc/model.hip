@@ -115,6 +115,8 @@ Model::~Model() {
         (void)hipSetDevice(s.device);
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         if (s.comm) ncclCommDestroy(s.comm);
+        if (s.comm_stream) { (void)hipStreamSynchronize(s.comm_stream); (void)hipStreamDestroy(s.comm_stream); }
+        for (auto &e : s.ev) if (e) (void)hipEventDestroy(e);
         for (void *mp : s.pc.mapped) if (mp) (void)hipIpcCloseMemHandle(mp);
         if (s.pc.local) (void)hipFree(s.pc.local);
         if (s.pc.epoch) (void)hipFree(s.pc.epoch);
@@ -581,9 +583,10 @@ static int comm_connect_impl(Model *m, const void *handles) {
 
 // n floats in chunks of at most nmax; reduce: out = sum over ranks (in == out allowed);
 // gather: out[r * out_stride + i] = in_r[i]
-static int oneshot(Model *m, Shard &sh, bool gather, const float *in, float *out, int64_t n, int64_t out_stride) {
+static int oneshot(Model *m, Shard &sh, bool gather, const float *in, float *out, int64_t n, int64_t out_stride, hipStream_t on = nullptr) {
     PeerComm &pc = sh.pc;
     Launcher L = make_launcher(m, sh);
+    if (on) L.stream = on;
     for (int64_t off = 0; off < n; off += pc.nmax) {
         const int64_t c = std::min(pc.nmax, n - off);
         FL_TRY(launch_oneshot(L, gather, in + off, out + off, pc.tab, sh.rank, m->tp, c, pc.nmax, out_stride, pc.epoch, pc.err, pc.timeout_ticks));
@@ -889,10 +892,122 @@ static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
     return gather_logits(m);
 }
 
+// all-reduce(sum) of rows [off, off + count) floats of every local shard's prefill delta, on the shards' comm streams
+static int all_reduce_span_side(Model *m, size_t off, int64_t count) {
+    const bool local = m->tp_mode == FL_TP_SINGLE_PROCESS;
+    Shard &s0 = m->shards[0];
+    if (s0.pc.connected && (count <= s0.pc.nmax || !s0.comm)) {
+        for (auto &sh : m->shards) {
+            FL_HIP(hipSetDevice(sh.device));
+            FL_TRY(oneshot(m, sh, false, sh.pre.delta + off, sh.pre.delta + off, count, 0, sh.comm_stream));
+        }
+        return FL_OK;
+    }
+    if (!s0.comm) FL_FAIL(FL_ERR_RCCL, "tensor-parallel group is not connected: call fl_comm_ipc_connect first");
+    if (local) FL_NCCL(ncclGroupStart());
+    for (auto &sh : m->shards)
+        FL_NCCL(ncclAllReduce(sh.pre.delta + off, sh.pre.delta + off, (size_t)count, ncclFloat, ncclSum, sh.comm, sh.comm_stream));
+    if (local) FL_NCCL(ncclGroupEnd());
+    return FL_OK;
+}
+
+// Tensor-parallel prefill with the all-reduces on a side stream (north_star: "RCCL all-reduce ... overlapped on a side
+// HIP stream").  The T tokens are cut into two row chunks; every op between attention and the next attention is
+// row-wise, so while chunk 0's o_proj output is being all-reduced, chunk 1's o_proj runs; while chunk 1's is reduced,
+// chunk 0's norm / gate-up / down run; and so on into the next layer's norm + QKV.  Only RoPE / attention wait for both.
+//   main:  ... attn(all) | o(c0) e0 | o(c1) e1 | wait h0: mlp(c0) f0 | wait h1: mlp(c1) f1 | wait g0: qkv(c0) | wait g1: qkv(c1) | rope, attn ...
+//   comm:                 wait e0: AR(c0) h0 | wait e1: AR(c1) h1 | wait f0: AR(c0) g0 | wait f1: AR(c1) g1
+static int enqueue_prefill_tp_overlap(Model *m, Cache *c, int64_t T) {
+    const Dims &D = m->D;
+    const int dt = m->dtype;
+    const size_t es = m->esize();
+    const int64_t T0 = std::min<int64_t>(T - 1, ((T / 2 + 255) / 256) * 256), T1 = T - T0;
+    const int64_t rows[2] = {T0, T1}, row0[2] = {0, T0};
+    enum { E0 = 0, E1, H0, H1, F0, F1, G0, G1 };
+    for (auto &sh : m->shards) {
+        FL_HIP(hipSetDevice(sh.device));
+        if (!sh.comm_stream) FL_HIP(hipStreamCreateWithFlags(&sh.comm_stream, hipStreamNonBlocking));
+        for (auto &e : sh.ev) if (!e) FL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        Launcher L = make_launcher(m, sh);
+        FL_TRY(launch_embed(L, dt, sh.embed, sh.pre.ids, c->shards[&sh - &m->shards[0]].st, sh.pre.x_res, T, D.h));
+    }
+    auto each = [&](auto fn) -> int {
+        for (size_t i = 0; i < m->shards.size(); i++) {
+            Shard &sh = m->shards[i];
+            FL_HIP(hipSetDevice(sh.device));
+            FL_TRY(fn(sh, c->shards[i]));
+        }
+        return FL_OK;
+    };
+    auto rec = [&](int ev, bool side) { return each([&](Shard &sh, CacheShard &) -> int { FL_HIP(hipEventRecord(sh.ev[ev], side ? sh.comm_stream : sh.stream)); return FL_OK; }); };
+    auto wait = [&](int ev, bool side) { return each([&](Shard &sh, CacheShard &) -> int { FL_HIP(hipStreamWaitEvent(side ? sh.comm_stream : sh.stream, sh.ev[ev], 0)); return FL_OK; }); };
+    for (int64_t l = 0; l < D.L; l++) {
+        for (int k = 0; k < 2; k++) {                                  // norm1 + QKV per chunk, as soon as its rows are reduced
+            if (l > 0) FL_TRY(wait(G0 + k, false));
+            FL_TRY(each([&](Shard &sh, CacheShard &) -> int {
+                Scratch &sc = sh.pre; LayerW &ly = sh.layers[l]; Launcher L = make_launcher(m, sh);
+                const int64_t nq = (sh.Hs + 2 * sh.Hkvs) * D.d;
+                const size_t r = (size_t)row0[k];
+                FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res + r * D.h, l == 0 ? nullptr : sc.delta + r * D.h, ly.ln1, D.eps, (char *)sc.xn + r * D.h * es,
+                                          sc.inv_rms + r, rows[k], D.h, 1, 0));
+                return launch_linear(L, dt, ly.wqkv, (char *)sc.xn + r * D.h * es, ly.bqkv, sc.qkv + r * nq, rows[k], nq, D.h, EPI_F32, sc.inv_rms + r);
+            }));
+        }
+        FL_TRY(each([&](Shard &sh, CacheShard &cs) -> int {
+            Scratch &sc = sh.pre; Launcher L = make_launcher(m, sh);
+            const size_t kv_layer = (size_t)l * sh.Hkvs * c->seq_alloc * D.d * es;
+            void *kc = (char *)cs.k + kv_layer, *vc = (char *)cs.v + kv_layer;
+            const int64_t sa = (int64_t)c->seq_alloc;
+            FL_TRY(launch_rope_kv(L, dt, sc.qkv, cs.st, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, kc, vc, T, sh.Hs, sh.Hkvs, D.d, sa, c->v_transposed));
+            if (c->v_transposed) return launch_attn_prefill_mfma(L, sc.q, kc, vc, cs.st, sc.ao, T, sh.Hs, sh.Hkvs, D.d, sa, D.scale, D.window);
+            return launch_attn_prefill(L, dt, sc.q, kc, vc, cs.st, sc.ao, T, sh.Hs, sh.Hkvs, D.d, sa, D.scale, D.window);
+        }));
+        for (int k = 0; k < 2; k++) {                                  // o_proj per chunk; its all-reduce goes to the side stream
+            FL_TRY(each([&](Shard &sh, CacheShard &) -> int {
+                Scratch &sc = sh.pre; Launcher L = make_launcher(m, sh);
+                const size_t r = (size_t)row0[k];
+                return launch_linear(L, dt, sh.layers[l].wo, (char *)sc.ao + r * sh.Hs * D.d * es, nullptr, sc.delta + r * D.h, rows[k], D.h, sh.Hs * D.d, EPI_F32);
+            }));
+            FL_TRY(rec(E0 + k, false));
+            FL_TRY(wait(E0 + k, true));
+            FL_TRY(all_reduce_span_side(m, (size_t)row0[k] * D.h, rows[k] * D.h));
+            FL_TRY(rec(H0 + k, true));
+        }
+        for (int k = 0; k < 2; k++) {                                  // MLP per chunk
+            FL_TRY(wait(H0 + k, false));
+            FL_TRY(each([&](Shard &sh, CacheShard &) -> int {
+                Scratch &sc = sh.pre; LayerW &ly = sh.layers[l]; Launcher L = make_launcher(m, sh);
+                const size_t r = (size_t)row0[k];
+                FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res + r * D.h, sc.delta + r * D.h, ly.ln2, D.eps, (char *)sc.xn + r * D.h * es, sc.inv_rms + r, rows[k], D.h, 1, 0));
+                FL_TRY(launch_linear(L, dt, ly.wgu, (char *)sc.xn + r * D.h * es, nullptr, (char *)sc.act + r * sh.Ip * es, rows[k], 2 * sh.Ip, D.h, EPI_GATEUP, sc.inv_rms + r));
+                return launch_linear(L, dt, ly.wd, (char *)sc.act + r * sh.Ip * es, nullptr, sc.delta + r * D.h, rows[k], D.h, sh.Ip, EPI_F32);
+            }));
+            FL_TRY(rec(F0 + k, false));
+            FL_TRY(wait(F0 + k, true));
+            FL_TRY(all_reduce_span_side(m, (size_t)row0[k] * D.h, rows[k] * D.h));
+            FL_TRY(rec(G0 + k, true));
+        }
+    }
+    FL_TRY(wait(G1, false));                                           // the last token lives in chunk 1
+    FL_TRY(each([&](Shard &sh, CacheShard &) -> int {
+        Scratch &sc = sh.pre; Launcher L = make_launcher(m, sh);
+        float *xl = sc.x_res + (size_t)(T - 1) * D.h, *dl = sc.delta + (size_t)(T - 1) * D.h;
+        void *xnl = (char *)sc.xn + (size_t)(T - 1) * D.h * es;
+        FL_TRY(launch_rmsnorm_add(L, dt, xl, dl, sh.norm, D.eps, xnl, sc.inv_rms + (T - 1), 1, D.h, 1, 0));
+        return launch_linear(L, dt, sh.lm_head, xnl, nullptr, sh.logits_local, 1, sh.Vs, D.h, EPI_F32, sc.inv_rms + (T - 1));
+    }));
+    FL_TRY(wait(G0, false));                                           // nothing of this call may still run on the side stream afterwards
+    return gather_logits(m);
+}
+
 // Enqueue one forward over T tokens on every local shard.  The step state (pos, len, token) of the
 // cache must already be set on the device.  ids_dev == null: the single token comes from the state.
 static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_scratch, int64_t len_hint) {
     if (T == 1 && !pre && !ids_in_scratch && m->fused_decode) return enqueue_decode_fused(m, c, len_hint);
+    static const int tp_overlap = env_int("FL_TP_OVERLAP", 1);
+    if (pre && ids_in_scratch && tp_overlap && m->tp > 1 && T >= env_int("FL_TP_OVERLAP_MIN_T", 512) && !m->profiling &&
+        (m->tp_mode == FL_TP_MULTI_PROCESS || m->tp_mode == FL_TP_SINGLE_PROCESS))
+        return enqueue_prefill_tp_overlap(m, c, T);
     const Dims &D = m->D;
     const int dt = m->dtype;
     const size_t ns = m->shards.size();

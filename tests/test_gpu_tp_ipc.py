@@ -117,3 +117,32 @@ def test_single_process_group_on_one_device(name, tp, dtype):
     assert len(cS) == 35
     gS.close()
     gE.close()
+
+
+def test_overlapped_prefill_multiprocess_and_single_process(tmp_path, monkeypatch):
+    """Prompts of FL_TP_OVERLAP_MIN_T tokens and more take the two-chunk prefill whose all-reduces run on a side
+    stream while the other chunk computes: same rows, same sums -> the same bits as the plain schedule
+    (FL_TP_EMULATED), in a 2-rank multi-process group and in a 2-shard single-process group."""
+    import fastllm_amd as fa
+    from fastllm_amd import binding
+    name, tp, dtype, T = "mistral_a", 2, "bf16", 400
+    cfg = synth.CONFIGS[name]
+    w = synth.synth_weights(cfg)
+    ids = synth.prompt_ids(cfg, T + 4, seed=11)
+    gE = fa.Model(cfg, w, dtype=dtype, tp_mode=binding.TP_EMULATED, tp_size=tp)
+    cE = gE.new_cache(512)
+    want = gE.forward(cE, ids[:T], 0)
+    want_d = gE.forward(cE, ids[T:T + 1], T)
+    res = run_group(tmp_path, name, dtype, tp, T=T, n_tf=4, n_greedy=4, env_extra={"FL_TP_OVERLAP_MIN_T": "256"})
+    for r in range(tp):
+        np.testing.assert_array_equal(res[r]["prefill"], want)
+        np.testing.assert_array_equal(res[r]["decode"][0], want_d)
+    monkeypatch.setenv("FL_TP_OVERLAP_MIN_T", "256")
+    gS = fa.Model(cfg, w, dtype=dtype, tp_mode=binding.TP_SINGLE_PROCESS, tp_size=tp, device_ids=[0] * tp)
+    cS = gS.new_cache(512)
+    np.testing.assert_array_equal(gS.forward(cS, ids[:T], 0), want)
+    np.testing.assert_array_equal(gS.forward(cS, ids[T:T + 1], T), want_d)
+    # and against the same group with the overlap switched off
+    monkeypatch.setenv("FL_TP_OVERLAP_MIN_T", "100000")
+    cS2 = gS.new_cache(512)
+    np.testing.assert_array_equal(gS.forward(cS2, ids[:T], 0), want)
