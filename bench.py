@@ -18,6 +18,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -138,6 +139,10 @@ def main():
         # two processes with two live HIP queues each on ONE card make every launch of both ~25 us slower (measured:
         # profiles/r01/README.md); that is an artefact of the rehearsal, so keep the prefill's side stream out of it
         os.environ.setdefault("FL_TP_OVERLAP", "0")
+        # the all-reduce fused into the GEMV epilogues spins inside full-chip grids: N ranks on one card would wait
+        # for each other's workgroups to leave.  FL_BENCH_SAME_DEVICE_FUSED=1 rehearses it anyway at full model
+        # size with the GEMV grids cut to 1/N of the card (see below); the default rehearsal keeps the kernel form.
+        os.environ.setdefault("FL_TP_FUSED_AR", "2" if os.environ.get("FL_BENCH_SAME_DEVICE_FUSED", "0") == "1" else "0")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -167,6 +172,9 @@ def main():
     model = fa.Model(cfg, as_fl_tensors(wts, local_rank), dtype="bf16",
                      tp_mode=binding.TP_MULTI_PROCESS if world > 1 else binding.TP_NONE, tp_size=world, tp_rank=rank,
                      device_ids=[local_rank], unique_id=uid)
+    if same_device and os.environ.get("FL_BENCH_SAME_DEVICE_FUSED", "0") == "1":      # (FL_TP_FUSED_AR=0 on top: same grids, kernel form)
+        fa.tune("gemv_blocks", 192 // world)
+        fa.tune("gemv_waves", 4)
     if same_device:
         hs = [None] * world
         dist.all_gather_object(hs, model.ipc_export())
@@ -176,6 +184,8 @@ def main():
     collectives = {0: None, 1: "rccl", 2: "one-shot peer inboxes (k_comm.hip) + rccl for prefill", 3: "local"}[info.small_collectives]
     if same_device:
         collectives = "one-shot peer inboxes (k_comm.hip); all ranks on ONE GPU (rehearsal)"
+    if info.fused_all_reduce:
+        collectives += "; decode all-reduces fused into the o_proj/down_proj GEMV epilogues (comm_ll.h)"
     log("decode collectives:", collectives)
 
     do_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
@@ -304,6 +314,7 @@ def main():
             "cpu_baseline": cpu,
             "e2e_hbm": {"bytes_per_token": b_tok, "achieved_GBps": round(tok_s * b_tok / world / 1e9, 1),
                         "frac_of_8TBps_per_gpu": round(tok_s * b_tok / world / 8e12, 4)},
+            "tokens_crc32": zlib.crc32(np.asarray(toks, dtype=np.uint32).tobytes()),
             "batched_decode": batch8,
             "host_loop": {"tokens_per_sec": round(1.0 / t_host_loop, 2),
                           "note": "fl_forward per token: logits (V fp32) to the host + host argmax, PCIe-inclusive"},

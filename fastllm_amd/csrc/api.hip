@@ -70,6 +70,7 @@ int fl_model_get_info(const fl_model *m, fl_model_info *out) {
     out->kv_bytes_per_position = es * D.L * D.Hkv * D.d * 2;
     out->hbm_bytes_allocated = mm->hbm_bytes;
     out->small_collectives = mm->shards[0].pc.connected ? 2 : mm->tp == 1 ? 0 : mm->tp_mode == FL_TP_EMULATED ? 3 : 1;
+    out->fused_all_reduce = fused_all_reduce_ready(mm) ? 1 : 0;
     return FL_OK;
 }
 

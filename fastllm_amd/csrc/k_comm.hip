@@ -14,6 +14,7 @@
 // collective ahead of the slowest peer (it needs that peer's flag to finish), so the half it
 // overwrites is never still being read.  Epochs count collectives and live on the device, so a
 // captured decode graph replays with no argument update.
+#include "comm_ll.h"
 #include "kernels.h"
 
 namespace fl {
@@ -99,6 +100,24 @@ int launch_oneshot(Launcher &L, bool gather, const float *in, float *out, const 
         rc = L.launch(KC_COMM, bytes, 0, oneshot_kernel<true>, dim3(1), dim3(1024), 0, in, out, tab, rank, tp, (int)n, (int)nmax, (long long)out_stride, epoch_ctr, err, timeout_ticks);
     else
         rc = L.launch(KC_COMM, bytes, 0, oneshot_kernel<false>, dim3(1), dim3(1024), 0, in, out, tab, rank, tp, (int)n, (int)nmax, (long long)out_stride, epoch_ctr, err, timeout_ticks);
+    L.tag = "";
+    return rc;
+}
+
+// The epilogue exchange of comm_ll.h on its own: four waves per workgroup, two rows per wave, like the GEMV that
+// normally carries it.  in == out is allowed (a wave reads its rows before it writes them).
+__global__ __launch_bounds__(256) void ll_allreduce_kernel(const LLTable *__restrict__ ll, int slot, const float *__restrict__ in,
+                                                           float *__restrict__ out, int n) {
+    const int lane = threadIdx.x & 63, row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (row0 >= n) return;
+    const float s[2] = {in[row0], row0 + 1 < n ? in[row0 + 1] : 0.f};
+    ll_allreduce_rows<2>(ll, slot, row0, n, s, out, lane);
+}
+
+int launch_ll_allreduce(Launcher &L, const LLTable *ll_dev, int slot, const float *in, float *out, int64_t n) {
+    if (!ll_dev || n <= 0 || slot <= 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "fused all-reduce: bad arguments");
+    L.tag = "ll_allreduce";
+    const int rc = L.launch(KC_COMM, (double)n * 8 * 2, 0, ll_allreduce_kernel, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, ll_dev, slot, in, out, (int)n);
     L.tag = "";
     return rc;
 }

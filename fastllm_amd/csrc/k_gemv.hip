@@ -21,7 +21,8 @@
 // staging; 1/m is applied to the accumulator in the epilogue.  Workgroup 0 also writes the updated
 // residual v to x_out (a different buffer than x_in: other workgroups still read x_in).
 //
-// Epilogues: EPI_F32 (+bias) -> fp32;  EPI_GATEUP: silu(gate)*up on the 16-interleaved layout;
+// Epilogues: EPI_F32 (+bias) -> fp32, or -- GemvArgs::ll, the row-parallel o_proj / down_proj of a tensor-parallel
+// group -- summed over the ranks right here (comm_ll.h);  EPI_GATEUP: silu(gate)*up on the 16-interleaved layout;
 // EPI_QKV_ROPE (fused K4/K5): rows are paired (j, j+d/2) per head, RoPE is applied with the
 // position from the device step state and q / rotated k / v go straight to the q buffer and
 // the KV cache slot `len`.
@@ -30,6 +31,7 @@
 #include <atomic>
 #include <type_traits>
 
+#include "comm_ll.h"
 #include "kernels.h"
 
 namespace fl {
@@ -199,6 +201,10 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
         float sum[R];
 #pragma unroll
         for (int r = 0; r < R; r++) { sum[r] = wave_sum(acc[r]) * inv_m; acc[r] = 0.f; }
+        if (a.ll) {                                   // row-parallel projection of a tensor-parallel group (EPI_F32, no bias: host-checked)
+            ll_allreduce_rows<R>(a.ll, a.ll_slot, g * R, N, sum, reinterpret_cast<float *>(a.out), lane);
+            return;
+        }
         if (lane != 0) return;
         if (epi == EPI_GATEUP) {
 #pragma unroll
@@ -448,6 +454,7 @@ int launch_gemv(Launcher &L, int dtype, const GemvArgs &a) {
     if (!gemv_supported(dtype, a.N, a.K)) FL_FAIL(FL_ERR_UNSUPPORTED, "launch_gemv: K=%d unsupported", a.K);
     if (a.pro == PRO_NORM && !gemv_norm_supported(dtype, a.N, a.K)) FL_FAIL(FL_ERR_UNSUPPORTED, "fused norm needs K <= 6144");
     if (a.epi == EPI_GATEUP && a.N % 32) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gate/up matrix rows must be a multiple of 32");
+    if (a.ll && (a.epi != EPI_F32 || a.bias || a.ll_slot <= 0)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "fused all-reduce: plain fp32 epilogue without bias only");
     if (a.epi == EPI_QKV_ROPE && (a.d <= 0 || a.d % 2 || a.N != (a.H + 2 * a.Hkv) * a.d)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "bad qkv shape");
     if (dtype == FL_DTYPE_BF16)
         return a.pro == PRO_NORM ? launch_gemv_ru<bf16_t, bf16_t, PRO_NORM>(L, a) : launch_gemv_ru<bf16_t, bf16_t, PRO_X>(L, a);

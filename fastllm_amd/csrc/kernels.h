@@ -43,6 +43,7 @@ struct Launcher {
 enum { EPI_F32 = 0, EPI_GATEUP = 1, EPI_QKV_ROPE = 2 };
 enum { PRO_X = 0, PRO_NORM = 1 };
 
+struct LLTable;
 // Arguments of the decode weight-streaming kernel (k_gemv.hip), passed by value as kernarg.
 struct GemvArgs {
     const void *W = nullptr;        // [N,K] compute dtype
@@ -62,6 +63,9 @@ struct GemvArgs {
     void *q_out = nullptr, *k_cache = nullptr, *v_cache = nullptr;
     int H = 0, Hkv = 0, d = 0, max_seq = 0, max_pos = 0;
     int v_ld = 0;                   // > 0: value cache is transposed [Hkv][d][v_ld] (MFMA attention layout)
+    // EPI_F32 of a row-parallel projection in a tensor-parallel group: out = sum over ranks, exchanged in the epilogue
+    const LLTable *ll = nullptr;    // device-resident; null = plain local output
+    int ll_slot = 0;                // 1 .. LLTable::slots: which all-reduce of the decode step this is
 };
 int launch_gemv(Launcher &L, int dtype, const GemvArgs &a);
 bool gemv_norm_supported(int dtype, int64_t N, int64_t K);
@@ -163,6 +167,22 @@ constexpr int FL_MAX_TP = 8;
 struct CommTable { float *inbox[FL_MAX_TP]; uint32_t *flags[FL_MAX_TP]; };
 int launch_oneshot(Launcher &L, bool gather, const float *in, float *out, const CommTable &tab, int rank, int tp,
                    int64_t n, int64_t nmax, int64_t out_stride, uint32_t *epoch_ctr, uint32_t *err, long long timeout_ticks);
+
+// All-reduce fused into the epilogue of a row-parallel decode GEMV ("LL" protocol: a value and the epoch that
+// validates it travel in ONE 8-byte store, so there is no fence, no flag round and no separate kernel).  Every
+// wave pushes its rows' partial sums into slot [rank] of every peer's LL region, polls the tp slots of its own
+// region for the same rows and adds them in rank order -- bit-identical to oneshot_kernel's sum.
+// Region layout (uint64 {lo: fp32 bits, hi: epoch}): [2 halves by epoch parity][tp source ranks][n rows].
+// epoch = *epoch_ctr * slots + slot: the one-shot counter moves at least once per decode step (logits gather).
+struct LLTable {
+    uint64_t *peer[FL_MAX_TP];      // rank r's LL region as mapped here
+    const uint32_t *epoch_ctr;      // the one-shot collectives' device counter
+    uint32_t *err;                  // pinned host word
+    long long timeout_ticks;
+    int rank, tp, n, slots;
+};
+// stand-alone exerciser of ll_allreduce_rows (bootstrap self-test, tests): out[i] = sum_r in_r[i], i < n
+int launch_ll_allreduce(Launcher &L, const LLTable *ll_dev, int slot, const float *in, float *out, int64_t n);
 
 // ---- attention -----------------------------------------------------------------------------
 struct AttnScratch { float *part_m, *part_l, *part_o; unsigned *counters; int nsplit; int64_t kv_len_hint; };

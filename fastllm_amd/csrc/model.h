@@ -47,7 +47,7 @@ struct Scratch {                 // activations of one forward chunk on one shar
 
 // One-shot collectives over peer-mapped HBM (k_comm.hip): this rank's inbox and its view of the peers'.
 struct PeerComm {
-    void *local = nullptr;       // hipDeviceMallocUncached: [flags, 4 KB | inbox: 2 halves x tp slots x nmax floats]
+    void *local = nullptr;       // hipDeviceMallocUncached: [flags, 4 KB | inbox: 2 halves x tp slots x nmax floats | LL: 2 x tp x h x 8 B]
     size_t bytes = 0;
     int64_t nmax = 0;            // floats per slot
     CommTable tab{};
@@ -56,6 +56,12 @@ struct PeerComm {
     uint32_t *err = nullptr;     // pinned host word a kernel writes when a peer never showed up
     long long timeout_ticks = 0; // wall_clock64 ticks (100 MHz)
     bool connected = false;
+    // all-reduce fused into the row-parallel decode GEMVs (comm_ll.h): a region behind the inbox halves
+    size_t ll_off = 0;           // byte offset of the LL region in `local` (same on every rank)
+    LLTable ll{};                // host copy; `ll_dev` is what the kernels read
+    LLTable *ll_dev = nullptr;
+    bool ll_ok = false;          // region connected (and, with RCCL, proven against ncclAllReduce by all ranks)
+    bool shares_device = false;  // a peer lives on this same GPU (rehearsals): full-chip grids that wait for each other cannot co-reside
 };
 
 struct Shard {
@@ -167,6 +173,7 @@ int cache_create(Model *m, size_t max_seq, Cache **out);
 // FL_TP_MULTI_PROCESS: export this rank's inbox / map the peers' (handles: tp x FL_IPC_HANDLE_BYTES in rank order)
 int comm_ipc_export(Model *m, void *handle_out);
 int comm_ipc_connect(Model *m, const void *handles);
+bool fused_all_reduce_ready(const Model *m);   // decode all-reduces ride in the GEMV epilogues (comm_ll.h)
 // mode: 0 = logits to host, 1 = argmax token to host
 // device token-selection state for a LogitsProcessor::new(seed, Some(temperature), None); null: ArgMax
 SampleState make_sampler(const fl_sampling *sampling);

@@ -38,6 +38,7 @@ static int env_int(const char *name, int dflt) { const char *s = getenv(name); r
 static int comm_alloc(Model *m, Shard &sh);
 struct PeerComm;
 static void comm_set_entry(PeerComm &pc, int r, void *base);
+static int comm_ll_publish(Model *m, Shard &sh);
 static int comm_bootstrap_over_rccl(Model *m);
 static int comm_check(Model *m);
 
@@ -120,6 +121,7 @@ Model::~Model() {
         for (void *mp : s.pc.mapped) if (mp) (void)hipIpcCloseMemHandle(mp);
         if (s.pc.local) (void)hipFree(s.pc.local);
         if (s.pc.epoch) (void)hipFree(s.pc.epoch);
+        if (s.pc.ll_dev) (void)hipFree(s.pc.ll_dev);
         if (s.pc.err) (void)hipHostFree(s.pc.err);
         for (void *p : s.allocs) (void)hipFree(p);
         if (s.stream && std::find(closed.begin(), closed.end(), s.stream) == closed.end()) {
@@ -468,6 +470,8 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
                 for (int i = 0; i < tp; i++) {
                     for (int r = 0; r < tp; r++) comm_set_entry(m->shards[i].pc, r, m->shards[r].pc.local);
                     m->shards[i].pc.connected = true;
+                    m->shards[i].pc.shares_device = !distinct;
+                    FL_TRY(comm_ll_publish(m.get(), m->shards[i]));
                 }
             } else if (!distinct) {
                 FL_FAIL(FL_ERR_RCCL, "cannot connect the shards of a single-device tensor-parallel group");
@@ -516,12 +520,15 @@ static int comm_export_impl(Shard &sh, void *handle_out);
 static int comm_alloc(Model *m, Shard &sh) {
     PeerComm &pc = sh.pc;
     FL_HIP(hipSetDevice(sh.device));
-    pc.nmax = std::max<int64_t>(env_int("FL_AR_INBOX_FLOATS", 65536), 4) / 4 * 4;
-    pc.bytes = kCommFlagBytes + (size_t)2 * m->tp * pc.nmax * 4;
+    // a slot holds at least one rank's share of the logits, so the per-step gather is always a one-shot collective
+    pc.nmax = (std::max<int64_t>(std::max<int64_t>(env_int("FL_AR_INBOX_FLOATS", 65536), sh.Vs), 4) + 3) / 4 * 4;
+    pc.ll_off = (kCommFlagBytes + (size_t)2 * m->tp * pc.nmax * 4 + 255) & ~(size_t)255;
+    pc.bytes = pc.ll_off + (size_t)2 * m->tp * m->D.h * 8;
     FL_HIP(hipExtMallocWithFlags(&pc.local, pc.bytes, hipDeviceMallocUncached));
     FL_HIP(hipMemset(pc.local, 0, pc.bytes));
     FL_HIP(hipMalloc((void **)&pc.epoch, 64));
     FL_HIP(hipMemset(pc.epoch, 0, 64));
+    FL_HIP(hipMalloc((void **)&pc.ll_dev, sizeof(LLTable)));
     FL_HIP(hipHostMalloc((void **)&pc.err, 64, hipHostMallocDefault));
     *pc.err = 0;
     pc.timeout_ticks = (long long)env_int("FL_AR_TIMEOUT_MS", 20000) * 100000LL;       // 100 MHz wall clock
@@ -533,6 +540,18 @@ static int comm_alloc(Model *m, Shard &sh) {
 static void comm_set_entry(PeerComm &pc, int r, void *base) {
     pc.tab.flags[r] = (uint32_t *)base;
     pc.tab.inbox[r] = (float *)((char *)base + kCommFlagBytes);
+    pc.ll.peer[r] = (uint64_t *)((char *)base + pc.ll_off);
+}
+
+// every entry of the table is set: hand the fused all-reduce's view of the group to the device
+static int comm_ll_publish(Model *m, Shard &sh) {
+    PeerComm &pc = sh.pc;
+    FL_HIP(hipSetDevice(sh.device));
+    pc.ll.epoch_ctr = pc.epoch; pc.ll.err = pc.err; pc.ll.timeout_ticks = pc.timeout_ticks;
+    pc.ll.rank = sh.rank; pc.ll.tp = m->tp; pc.ll.n = (int)m->D.h; pc.ll.slots = (int)(2 * m->D.L);
+    FL_HIP(hipMemcpy(pc.ll_dev, &pc.ll, sizeof(LLTable), hipMemcpyHostToDevice));
+    pc.ll_ok = true;
+    return FL_OK;
 }
 
 int comm_ipc_export(Model *m, void *handle_out) {
@@ -576,9 +595,12 @@ static int comm_connect_impl(Model *m, const void *handles) {
         }
         pc.mapped[r] = p;
         comm_set_entry(pc, r, p);
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) == hipSuccess) pc.shares_device = pc.shares_device || at.device == sh.device;
+        else (void)hipGetLastError();
     }
     pc.connected = true;
-    return FL_OK;
+    return comm_ll_publish(m, sh);
 }
 
 // n floats in chunks of at most nmax; reduce: out = sum over ranks (in == out allowed);
@@ -637,6 +659,28 @@ static int comm_bootstrap_over_rccl(Model *m) {
         FL_HIP(hipMemcpyAsync(b, x.data(), test_n * 4, hipMemcpyHostToDevice, sh.stream));
         const long long keep = pc.timeout_ticks;
         pc.timeout_ticks = 200000000LL;              // 2 s: a path that does not work must fail fast here
+        // the exchange fused into the GEMV epilogues first (epoch counter still 0: it uses epoch 1, never seen again)
+        {
+            const size_t ll_n = std::min<size_t>(test_n, (size_t)m->D.h);
+            int ll_good = comm_ll_publish(m, sh) == FL_OK;
+            if (ll_good) {
+                Launcher L = make_launcher(m, sh);
+                ll_good = launch_ll_allreduce(L, pc.ll_dev, 1, a, a, (int64_t)ll_n) == FL_OK;
+                FL_HIP(hipMemcpyAsync(ya.data(), a, ll_n * 4, hipMemcpyDeviceToHost, sh.stream));
+                FL_HIP(hipStreamSynchronize(sh.stream));
+                ll_good = ll_good && *pc.err == 0;
+                for (size_t i = 0; i < ll_n && ll_good; i++) ll_good = ya[i] == (float)tp * (float)(i % 251) + 1000.f * (float)(tp * (tp - 1) / 2);
+                FL_HIP(hipMemcpyAsync(a, x.data(), test_n * 4, hipMemcpyHostToDevice, sh.stream));
+            }
+            int ll_all = 0;
+            if (agree(ll_good, &ll_all) != FL_OK) return finish(FL_ERR_RCCL);
+            if (!ll_good && verbose) fprintf(stderr, "[fastllm_mi355x] rank %d: fused all-reduce self-test failed (err 0x%x)\n", sh.rank, *pc.err);
+            *pc.err = 0;
+            pc.timeout_ticks = keep;
+            if (ll_all) { if (comm_ll_publish(m, sh) != FL_OK) return finish(FL_ERR_HIP); }    // with the real timeout
+            pc.ll_ok = ll_all != 0;
+            pc.timeout_ticks = 200000000LL;
+        }
         int rc = oneshot(m, sh, false, a, a, (int64_t)test_n, 0);
         pc.timeout_ticks = keep;
         if (rc != FL_OK) return finish(rc);
@@ -650,9 +694,11 @@ static int comm_bootstrap_over_rccl(Model *m) {
     }
     if (!all) {                                      // stay on RCCL; the epoch counters may differ now, so the path is closed for good
         pc.connected = false;
+        pc.ll_ok = false;
         *pc.err = 0;
     }
-    if (verbose && sh.rank == 0) fprintf(stderr, "[fastllm_mi355x] small collectives: %s\n", all ? "one-shot over peer-mapped HBM" : "RCCL");
+    if (verbose && sh.rank == 0)
+        fprintf(stderr, "[fastllm_mi355x] small collectives: %s%s\n", all ? "one-shot over peer-mapped HBM" : "RCCL", all && pc.ll_ok ? ", all-reduce fused into the GEMV epilogues" : "");
     return finish(FL_OK);
 }
 
@@ -837,10 +883,36 @@ static int gather_logits(Model *m) {
 //   K4 gemv[norm2(+add) -> gate/up -> silu*up]        K5 gemv[down]   -> delta   (all-reduce)
 // and finally gemv[final norm -> lm_head].  The residual ping-pongs x_res <-> x_res2 because the
 // norm prologue of every workgroup reads x_in while workgroup 0 writes the updated residual.
+// In a tensor-parallel group whose LL regions are connected, K3 and K5 carry their all-reduce in the epilogue
+// (comm_ll.h): the layer stays at 5 launches.
+bool fused_all_reduce_ready(const Model *m) {
+    // 0: never; 1: when every rank has a GPU of its own (two full-chip GEMV grids that wait for each other's rows
+    // cannot both be resident on one card -- the same-device rehearsals); 2: regardless (tests with small grids)
+    const int allow = env_int("FL_TP_FUSED_AR", 1);
+    if (!allow || !m->fused_decode) return false;
+    if (allow < 2) for (auto &sh : m->shards) if (sh.pc.shares_device) return false;
+    const bool group_of_one = m->tp == 1 && m->shards[0].pc.connected;          // FL_DEBUG_RCCL_SELF: the bootstrap rehearsal
+    if (m->tp_mode != FL_TP_MULTI_PROCESS && m->tp_mode != FL_TP_SINGLE_PROCESS && !group_of_one) return false;   // emulated shards share one stream
+    for (auto &sh : m->shards) {
+        if (!sh.pc.connected || !sh.pc.ll_ok || sh.Vs > sh.pc.nmax) return false;   // the per-step logits gather must move the epoch counter
+        if (!gemv_supported(m->dtype, m->D.h, sh.Hs * m->D.d) || !gemv_supported(m->dtype, m->D.h, sh.Ip)) return false;
+    }
+    return true;
+}
+static bool fused_all_reduce(Model *m, Cache *c) { return !c->fuse_oproj && fused_all_reduce_ready(m); }
+
 static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
     const Dims &D = m->D;
     const int dt = m->dtype;
     const size_t ns = m->shards.size();
+    const bool far = fused_all_reduce(m, c);
+    // out = sum over ranks of W[h, K] . x  -- the row-parallel projection with the exchange in its epilogue
+    auto row_parallel = [&](Launcher &L, Shard &sh, const void *W, const void *x, int64_t K, float *out, int slot) -> int {
+        GemvArgs a;
+        a.W = W; a.x = x; a.out = out; a.N = (int)D.h; a.K = (int)K; a.epi = EPI_F32; a.pro = PRO_X;
+        a.ll = sh.pc.ll_dev; a.ll_slot = slot;
+        return launch_gemv(L, dt, a);
+    };
     for (int64_t l = 0; l < D.L; l++) {
         for (size_t i = 0; i < ns; i++) {
             Shard &sh = m->shards[i]; Scratch &sc = sh.dec; CacheShard &cs = c->shards[i]; LayerW &ly = sh.layers[l];
@@ -864,10 +936,11 @@ static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
             } else {
                 if (c->v_transposed) FL_TRY(launch_attn_decode_mfma(L, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->seq_alloc, D.scale));
                 else FL_TRY(launch_attn_decode(L, dt, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->seq_alloc, D.scale));
-                FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, 1, D.h, sh.Hs * D.d, EPI_F32));
+                if (far) FL_TRY(row_parallel(L, sh, ly.wo, sc.ao, sh.Hs * D.d, sc.delta, (int)(2 * l + 1)));
+                else FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, 1, D.h, sh.Hs * D.d, EPI_F32));
             }
         }
-        FL_TRY(all_reduce_delta(m, false, D.h));
+        if (!far) FL_TRY(all_reduce_delta(m, false, D.h));
         for (size_t i = 0; i < ns; i++) {
             Shard &sh = m->shards[i]; Scratch &sc = sh.dec; LayerW &ly = sh.layers[l];
             FL_HIP(hipSetDevice(sh.device));
@@ -876,9 +949,10 @@ static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
             a.W = ly.wgu; a.out = sc.act; a.N = (int)(2 * sh.Ip); a.K = (int)D.h; a.epi = EPI_GATEUP; a.pro = PRO_NORM;
             a.x_in = sc.x_res2; a.delta = sc.delta; a.norm_w = ly.ln2; a.eps = D.eps; a.x_out = sc.x_res; a.st = c->shards[i].st;
             FL_TRY(launch_gemv(L, dt, a));
-            FL_TRY(launch_linear(L, dt, ly.wd, sc.act, nullptr, sc.delta, 1, D.h, sh.Ip, EPI_F32));
+            if (far) FL_TRY(row_parallel(L, sh, ly.wd, sc.act, sh.Ip, sc.delta, (int)(2 * l + 2)));
+            else FL_TRY(launch_linear(L, dt, ly.wd, sc.act, nullptr, sc.delta, 1, D.h, sh.Ip, EPI_F32));
         }
-        FL_TRY(all_reduce_delta(m, false, D.h));
+        if (!far) FL_TRY(all_reduce_delta(m, false, D.h));
     }
     for (size_t i = 0; i < ns; i++) {
         Shard &sh = m->shards[i]; Scratch &sc = sh.dec;

@@ -156,7 +156,7 @@ typedef struct fl_model_info {
     int64_t kv_bytes_per_position;  /* K+V bytes one cached position adds to a decode step */
     int64_t hbm_bytes_allocated;    /* this process, all shards */
     int32_t small_collectives;      /* decode collectives: 0 none (tp 1), 1 RCCL, 2 one-shot peer inboxes, 3 local (emulated) */
-    int32_t _pad;
+    int32_t fused_all_reduce;       /* 1: decode all-reduces ride in the o_proj / down_proj GEMV epilogues (no kernel of their own) */
 } fl_model_info;
 int fl_model_get_info(const fl_model *m, fl_model_info *out);
 

@@ -135,8 +135,11 @@ def test_rccl_plumbing_single_rank(monkeypatch, oneshot, graph):
     monkeypatch.setenv("FL_DEBUG_RCCL_SELF", "1")
     m = fa.Model(cfg, w, dtype="f32")
     assert m.info().small_collectives == (2 if oneshot == "1" else 0)
+    # ... and the exchange fused into the GEMV epilogues passed its self-test and vote (comm_ll.h); the decode steps below use it
+    assert m.info().fused_all_reduce == (1 if oneshot == "1" else 0)
     c = m.new_cache(32)
     np.testing.assert_array_equal(m.forward(c, ids[:9], 0), a1)
     np.testing.assert_array_equal(m.forward(c, ids[9:], 9), a2)
-    toks = m.decode_greedy(c, 3, 10, 5)
-    assert len(toks) == 5
+    c0 = plain.new_cache(32)
+    plain.forward(c0, ids[:9], 0); plain.forward(c0, ids[9:], 9)
+    np.testing.assert_array_equal(m.decode_greedy(c, 3, 10, 5), plain.decode_greedy(c0, 3, 10, 5))

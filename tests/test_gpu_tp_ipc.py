@@ -146,3 +146,52 @@ def test_overlapped_prefill_multiprocess_and_single_process(tmp_path, monkeypatc
     monkeypatch.setenv("FL_TP_OVERLAP_MIN_T", "100000")
     cS2 = gS.new_cache(512)
     np.testing.assert_array_equal(gS.forward(cS2, ids[:T], 0), want)
+
+
+@pytest.mark.parametrize("name,tp,dtype,tune", [("llama_tp4", 2, "bf16", ""), ("llama_tp4", 4, "bf16", ""), ("qwen2_a", 2, "f32", ""),
+                                                ("llama_tp4", 2, "bf16", "gemv_blocks=6,gemv_waves=4"),
+                                                ("mistral_wide", 2, "bf16", "gemv_blocks=96,gemv_waves=4")])
+def test_all_reduce_fused_into_gemv_epilogue(tmp_path, name, tp, dtype, tune, monkeypatch):
+    """Decode steps of a connected group exchange o_proj / down_proj partial sums in the GEMV epilogue (comm_ll.h)
+    instead of a one-shot kernel per all-reduce.  Same addends in the same rank order: greedy AND sampled tokens
+    (which follow the logits bit for bit) equal the unfused group's and the emulated group's, on every rank."""
+    import fastllm_amd as fa
+    from fastllm_amd import binding
+    cfg = synth.CONFIGS[name]
+    T, n_s = 12, 40
+    (tmp_path / "fused").mkdir(); (tmp_path / "plain").mkdir()
+    fused = run_group(tmp_path / "fused", name, dtype, tp, T, 2, 24, env_extra={"TP_WORKER_SAMPLED": str(n_s), "FL_TP_FUSED_AR": "2", "TP_WORKER_TUNE": tune})
+    plain = run_group(tmp_path / "plain", name, dtype, tp, T, 2, 24, env_extra={"TP_WORKER_SAMPLED": str(n_s), "FL_TP_FUSED_AR": "0", "TP_WORKER_TUNE": tune})
+    for r in range(tp):
+        for k in ("tokens", "sampled", "decode"):
+            np.testing.assert_array_equal(fused[r][k], fused[0][k], err_msg="fused rank %d vs 0: %s" % (r, k))
+            np.testing.assert_array_equal(fused[r][k], plain[r][k], err_msg="fused vs one-shot kernel, rank %d: %s" % (r, k))
+    w = synth.synth_weights(cfg)
+    ids = synth.prompt_ids(cfg, T + 2, seed=11)
+    # the workgroup size sets the order of the fused norm's sum of squares: compare like with like
+    tuned = dict((k, int(v)) for k, v in (kv.split("=") for kv in filter(None, tune.split(","))))
+    try:
+        for k, v in tuned.items():
+            fa.tune(k, v)
+        gE = fa.Model(cfg, w, dtype=dtype, tp_mode=binding.TP_EMULATED, tp_size=tp)
+        cE = gE.new_cache(T + n_s + 8)
+        f = gE.forward_sample(cE, ids[:T], 0, 0.9, seed=5)
+        want = np.concatenate([[f], gE.decode_sample(cE, f, T, n_s, 0.9, seed=5)]).astype(np.uint32)
+    finally:
+        for k in tuned:
+            fa.tune(k, 0)
+    np.testing.assert_array_equal(fused[0]["sampled"], want)
+    # one process, two shards on this device, per-shard graphs: the same exchange over plain peer pointers
+    if tp == 2 and not tune:
+        monkeypatch.setenv("FL_TP_FUSED_AR", "2")         # both shards on this one GPU: allowed because the grids are small
+        gS = fa.Model(cfg, w, dtype=dtype, tp_mode=binding.TP_SINGLE_PROCESS, tp_size=tp, device_ids=[0] * tp)
+        cS = gS.new_cache(T + n_s + 8)
+        f = gS.forward_sample(cS, ids[:T], 0, 0.9, seed=5)
+        np.testing.assert_array_equal(np.concatenate([[f], gS.decode_sample(cS, f, T, n_s, 0.9, seed=5)]).astype(np.uint32), want)
+        gS.profile_begin()                                # ... and it really is the fused form: no all-reduce kernels in a step
+        gS.decode_greedy(cS, f, T + n_s, 2)
+        names = [k["name"] for k in gS.profile_end()]
+        assert names and not any("allreduce" in n for n in names), names
+        assert any("allgather" in n for n in names), names
+        gS.close()
+    gE.close()

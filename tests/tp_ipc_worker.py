@@ -39,6 +39,9 @@ def main():
     from fastllm_amd import binding
     import synth
     cfg = synth.CONFIGS[name] if name in synth.CONFIGS else fa.MODEL_CONFIGS[name]
+    for kv in filter(None, os.environ.get("TP_WORKER_TUNE", "").split(",")):       # e.g. gemv_blocks=8,gemv_waves=4
+        k, v = kv.split("=")
+        fa.tune(k, int(v))
     w = synth.synth_weights(cfg)
     m = fa.Model(cfg, w, dtype=dtype, tp_mode=binding.TP_MULTI_PROCESS, tp_size=world, tp_rank=rank, device_ids=[0])
     m.ipc_connect(exchange(outdir, rank, world, m.ipc_export(), "handle"))
@@ -54,6 +57,12 @@ def main():
     rest = m.decode_greedy(c, first, T + n_tf + 1, n_greedy)
     res["greedy_s"] = np.array(time.time() - t0)
     res["tokens"] = np.concatenate([[first], rest]).astype(np.uint32)
+    n_sampled = int(os.environ.get("TP_WORKER_SAMPLED", "0"))
+    if n_sampled:                                        # temperature sampling follows the logits bit for bit
+        c2 = m.new_cache(T + n_sampled + 8)
+        f2 = m.forward_sample(c2, ids[:T], 0, 0.9, seed=5)
+        res["sampled"] = np.concatenate([[f2], m.decode_sample(c2, f2, T, n_sampled, 0.9, seed=5)]).astype(np.uint32)
+        c2.close()
     np.savez(os.path.join(outdir, "out_%d.npz" % rank), **res)
     exchange(outdir, rank, world, b"done", "done")      # nobody unmaps an inbox a peer may still push to
     c.close()
