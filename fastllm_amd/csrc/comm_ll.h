@@ -40,7 +40,7 @@ __device__ inline void ll_allreduce_rows(const LLTable *__restrict__ t, int slot
             uint64_t w = __hip_atomic_load(src + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             while (alive && (uint32_t)(w >> 32) != e) {
                 __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t0 > t->timeout_ticks) { *t->err = 0xA11E0000u | (uint32_t)rank; alive = false; }   // bounded: a dead peer must not hang the GPU
+                if (wall_clock64() - t0 > t->timeout_ticks) { if (*t->err == 0) *t->err = 0xA11E0000u | (uint32_t)rank; alive = false; }   // bounded: a dead peer must not hang the GPU
                 w = __hip_atomic_load(src + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             got[r] = __uint_as_float((uint32_t)w);

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(1024) void oneshot_kernel(const float *__restrict__
     __syncthreads();
     __threadfence_system();                       // acquire: the slots are read only after all tp flags were seen
     if (s_bad) {                                  // give up: report, do not touch `out`
-        if (tid == 0) { *err = 0xA11D0000u | (uint32_t)rank; *epoch_ctr = e; }
+        if (tid == 0) { if (*err == 0) *err = 0xA11D0000u | (uint32_t)rank; *epoch_ctr = e; }      // the first report stays
         return;
     }
     const float *mine = tab.inbox[rank] + half;

@@ -195,3 +195,14 @@ def test_all_reduce_fused_into_gemv_epilogue(tmp_path, name, tp, dtype, tune, mo
         assert any("allgather" in n for n in names), names
         gS.close()
     gE.close()
+
+
+@pytest.mark.parametrize("fused", ["2", "0"])
+def test_stalled_peer_is_an_error_not_a_hang(tmp_path, fused):
+    """A rank that never shows up for a decode step: the waiting rank's polls (in the GEMV epilogue, or in the one-shot
+    kernel) give up after FL_AR_TIMEOUT_MS, the step returns FL_ERR_RCCL, and every kernel of the step still drains."""
+    res = run_group(tmp_path, "llama_a", "bf16", 2, env_extra={"TP_WORKER_STALLED_RANK": "1", "FL_AR_TIMEOUT_MS": "300", "FL_TP_FUSED_AR": fused})
+    msg = str(res[0]["error"])
+    assert "gave up waiting for a peer" in msg, msg
+    assert ("0xa11e" in msg) == (fused == "2"), msg                   # which waiter reported: fused epilogue / one-shot kernel
+    assert float(res[0]["waited_s"]) < 30.0

@@ -48,6 +48,22 @@ def main():
     ids = synth.prompt_ids(cfg, T + n_tf, seed=11)
     c = m.new_cache(T + n_tf + n_greedy + 8)
     res = {"prefill": m.forward(c, ids[:T], 0)}
+    stalled = os.environ.get("TP_WORKER_STALLED_RANK", "")
+    if stalled:
+        # rank `stalled` never issues the decode step (but stays mapped: nobody may push into freed memory); the others
+        # must come back with an error after the bounded wait instead of hanging the GPU
+        if rank != int(stalled):
+            t0 = time.time()
+            try:
+                m.decode_greedy(c, 1, T, 1)
+                msg = "no error"
+            except RuntimeError as e:
+                msg = str(e)
+            res["error"] = np.array(msg)
+            res["waited_s"] = np.array(time.time() - t0)
+        np.savez(os.path.join(outdir, "out_%d.npz" % rank), **res)
+        exchange(outdir, rank, world, b"done", "done")
+        return
     step = []
     for i in range(T, T + n_tf):
         step.append(m.forward(c, ids[i:i + 1], i))
