@@ -251,17 +251,259 @@ __global__ __launch_bounds__(1024) void attn_prefill_mfma_kernel(const bf16_t *_
     }
 }
 
+// ------------------------------------------------------------------------------- prefill, 32 query rows per wave
+// The 16-row kernel above re-reads every staged K/V tile from LDS once per 16 query rows and does its softmax
+// bookkeeping per 16 x 32 scores: LDS bandwidth and VALU, not the matrix pipe, set its pace (MfmaUtil 12 %).  Here a
+// wave owns 32 tokens of one query head and both products run "swapped" on v_mfma_f32_32x32x16_bf16 so that a query
+// row lives on a lane (pair) from start to finish:
+//   S^T = K . Q^T     A = K rows from the LDS tile, B = Q^T fragments kept in registers (8 x bf16x8 at d = 128).
+//                     MFMA row m carries key pi(m) = m with bits 2 and 3 swapped, so lane (q, hi) ends up with the
+//                     scores of keys 8*hi + 0..7 (registers 0..7) and 16 + 8*hi + 0..7 (registers 8..15) -- exactly
+//                     the B-operand layout of the second product, no cross-lane traffic.
+//   O^T += V^T . P^T  A = V^T rows (d) straight from the transposed-V tile, B = P^T = the exponentiated scores packed
+//                     to bf16 in place.  O^T keeps q on the lanes: max / sum / rescale are per-lane scalars (one
+//                     xor-32 shuffle joins the two half-rows), the rescale is skipped when no row's max moved.
+// Scores are kept in the exp2 domain (scale * log2 e folded into one FMA per score).  K/V tiles (32 keys) arrive by
+// LDS-DMA into a 3-deep ring, two tiles ahead, behind a counted vmcnt and one raw barrier per tile; tiles that are
+// fully visible to all 32 rows of a wave skip the mask arithmetic.
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef unsigned short ushort4v __attribute__((ext_vector_type(4)));
+
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
+                                                                 const bf16_t *__restrict__ vT, const StepState *__restrict__ st,
+                                                                 bf16_t *__restrict__ out, int T, int H, int Hkv, int seq_alloc,
+                                                                 float scale_log2e, int window, int paired) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // 3 x (K tile | V^T tile)
+    constexpr int TILE = 2 * 32 * D * 2;
+    constexpr int NK = D / 16, NV = D / 16, NI = NK + NV;                  // 1-KiB wave-instructions per tile
+    constexpr int PER = (NI + NW - 1) / NW;                                // issued by every wave (wrapping: duplicates are benign)
+    constexpr int CPR = D / 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m32 = lane & 31, hi = lane >> 5;
+    const int G = H / Hkv, hk = blockIdx.y;
+    const int TB = NW / G;                                                  // 32-token blocks per workgroup
+    const int hq = hk * G + wave % G;
+    const int len = (int)st->len;
+    const int c0 = (int)st->call0;
+    const bf16_t *kb = kc + (size_t)hk * seq_alloc * D;
+    const bf16_t *vb = vT + (size_t)hk * D * seq_alloc;
+    const int krow = (m32 & 19) | ((m32 & 4) << 1) | ((m32 & 8) >> 1);      // pi(m): bits 2 and 3 swapped
+    // Causal: token block b walks ~b+1 key tiles.  paired: a workgroup takes block nb-1-x and then block x, so every
+    // workgroup walks the same number of tiles (one balanced round when nb/2 x Hkv covers the chip); otherwise the
+    // long blocks are dispatched first and the short ones fill the tail.
+    const int nb = (T + 32 * TB - 1) / (32 * TB);
+    for (int pass = 0; pass < (paired ? 2 : 1); pass++) {
+    const int blk = pass == 0 ? nb - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    if (pass == 1 && blk >= nb - 1 - (int)blockIdx.x) break;                // odd count: the middle block was pass 0
+    const int tb0 = blk * TB * 32;
+    const int t0 = tb0 + (wave / G) * 32;
+    const bool wave_on = wave < TB * G;                                     // NW need not be a multiple of G
+    const int t = t0 + m32;
+    const bool col_ok = wave_on && t < T;
+
+    bf16x8 qf[D / 16];
+#pragma unroll
+    for (int dk = 0; dk < D / 16; dk++) {
+        if (col_ok) qf[dk] = ld_bf16x8(q + ((size_t)t * H + hq) * D + dk * 16 + hi * 8);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) qf[dk][j] = (__bf16)0.f;
+        }
+    }
+    int lo = c0;
+    if (window >= 0 && len + t - window > c0) lo = len + t - window;
+    const int lo_q = col_ok ? lo : 0, hi_q = col_ok ? len + t + 1 : 0;
+    const int pre_hi = col_ok ? c0 : 0;
+    int wstart = 0;
+    if (c0 == 0 && window >= 0 && len + t0 - window > 0) wstart = ((len + t0 - window) / 32) * 32;
+    const int wend = (wave_on && t0 < T) ? len + min(T, t0 + 32) : 0;
+    // a tile [kb, kb+32) needs no mask for this wave when all 32 rows exist and see all of it
+    const bool rows_full = wave_on && t0 + 32 <= T;
+    int lo_max = c0;                                                        // largest lower bound among the wave's rows
+    if (window >= 0 && len + t0 + 31 - window > c0) lo_max = len + t0 + 31 - window;
+    const int hi_min = len + t0 + 1;                                        // smallest upper bound
+
+    float mrow = -INFINITY, lrow = 0.f;
+    float16v O[D / 32];
+#pragma unroll
+    for (int db = 0; db < D / 32; db++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) O[db][r] = 0.f;
+
+    int kstart = 0;
+    if (c0 == 0 && window >= 0 && len + tb0 - window > 0) kstart = ((len + tb0 - window) / 32) * 32;
+    const int kend = len + min(T, tb0 + 32 * TB);
+    const int nsteps = (kend - kstart + 31) / 32;
+
+    auto stage = [&](int kbase, unsigned char *buf) {
+        unsigned char *kt = buf, *vt = buf + 32 * D * 2;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            int e = wave + k * NW;
+            if (e >= NI) e -= NI;                                           // PER * NW < 2 * NI
+            if (e < NK) {
+                const int p = e * 64 + lane, row = p / CPR, pc = p % CPR, c = pc ^ (row & (CPR - 1));
+                glds16(kb + (size_t)(kbase + row) * D + c * 8, kt + e * 1024);
+            } else {
+                const int ev = e - NK, p = ev * 64 + lane, row = p >> 2, pc = p & 3, c = pc ^ ((row >> 2) & 3);
+                glds16(vb + (size_t)row * seq_alloc + kbase + c * 8, vt + ev * 1024);
+            }
+        }
+    };
+    stage(kstart, lds);
+    if (nsteps > 1) stage(kstart + 32, lds + TILE);
+
+    for (int sidx = 0; sidx < nsteps; sidx++) {
+        if (sidx + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int kbase = kstart + 32 * sidx;
+        if (sidx + 2 < nsteps) stage(kbase + 64, lds + ((sidx + 2) % 3) * TILE);
+        if (!(kbase + 32 > wstart && kbase < wend)) continue;              // wave-uniform
+        const unsigned char *kt = lds + (sidx % 3) * TILE, *vt = kt + 32 * D * 2;
+
+        // all K fragments are requested before the first MFMA (one register set per fragment: a shared one would
+        // expose the LDS latency D/16 times per tile), the V fragments right behind them
+        bf16x8 kf[D / 16];
+#pragma unroll
+        for (int dk = 0; dk < D / 16; dk++) {
+            const int c = dk * 2 + hi;
+            kf[dk] = *reinterpret_cast<const bf16x8 *>(kt + krow * (D * 2) + ((c ^ (krow & (CPR - 1))) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 vf[2][D / 32];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int db = 0; db < D / 32; db++) {
+                const int row = db * 32 + m32, c = 2 * ks + hi;
+                vf[ks][db] = *reinterpret_cast<const bf16x8 *>(vt + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        float16v S;
+#pragma unroll
+        for (int r = 0; r < 16; r++) S[r] = 0.f;
+#pragma unroll
+        for (int dk = 0; dk < D / 16; dk++) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[dk], qf[dk], S, 0, 0, 0);
+
+        const bool full = rows_full && (kbase + 32 <= c0 || (kbase >= lo_max && kbase + 32 <= hi_min));
+        float alpha;
+        bf16x8 pa[2];
+        if (full) {
+            float mt = S[0];
+#pragma unroll
+            for (int r = 1; r < 16; r++) mt = fmaxf(mt, S[r]);
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;           // scale > 0: max commutes with it
+            const float mn = fmaxf(mrow, mt);
+            alpha = __builtin_amdgcn_exp2f(mrow - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(S[r], scale_log2e, -mn));
+                ps += pv;
+                pa[r >> 3][r & 7] = (__bf16)pv;
+            }
+            lrow = lrow * alpha + ps;
+            mrow = mn;
+        } else {
+            float x[16];
+            float mt = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int key = kbase + (r & 7) + 8 * hi + 16 * (r >> 3);
+                const bool ok = key < pre_hi || (key >= lo_q && key < hi_q);
+                x[r] = ok ? S[r] * scale_log2e : -INFINITY;
+                mt = fmaxf(mt, x[r]);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float mn = fmaxf(mrow, mt);
+            const bool dead = mn == -INFINITY;                              // this row has seen no visible key yet
+            alpha = dead ? 1.0f : __builtin_amdgcn_exp2f(mrow - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float pv = dead ? 0.f : __builtin_amdgcn_exp2f(x[r] - mn);
+                ps += pv;
+                pa[r >> 3][r & 7] = (__bf16)pv;
+            }
+            lrow = lrow * alpha + ps;
+            mrow = mn;
+        }
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {                   // some row's running max moved
+#pragma unroll
+            for (int db = 0; db < D / 32; db++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) O[db][r] *= alpha;
+        }
+#pragma unroll
+        for (int db = 0; db < D / 32; db++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) O[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks][db], pa[ks], O[db], 0, 0, 0);
+    }
+
+    const float ltot = lrow + __shfl_xor(lrow, 32, 64);
+    if (col_ok) {
+        const float inv = 1.0f / ltot;
+        bf16_t *o = out + ((size_t)t * H + hq) * D;
+#pragma unroll
+        for (int db = 0; db < D / 32; db++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int d0 = db * 32 + 8 * rr + 4 * hi;
+                ushort4v pk;
+#pragma unroll
+                for (int j = 0; j < 4; j++) pk[j] = float_to_bf16_bits(O[db][4 * rr + j] * inv);
+                *reinterpret_cast<ushort4v *>(o + d0) = pk;
+            }
+    }
+    __builtin_amdgcn_s_barrier();        // every wave is done with the ring before the next pass refills it
+    }
+}
+
+template <int D, int NW>
+static int launch_pf32(Launcher &L, const void *q, const void *k_cache, const void *v_cache_T, const StepState *st, void *out,
+                       int64_t T, int64_t H, int64_t Hkv, int64_t seq_alloc, float scale, int64_t window, int TB, int paired) {
+    const int64_t nb = (T + 32 * TB - 1) / (32 * TB);
+    dim3 grid((unsigned)(paired ? (nb + 1) / 2 : nb), (unsigned)Hkv);
+    const size_t lds = 3 * (size_t)(2 * 32 * D * 2);
+    const double flops = 2.0 * (double)T * T * H * D;
+    Launcher LL = L; LL.tag = "32row";
+    return LL.launch(KC_ATTN_PREFILL, 0, flops, attn_prefill32_kernel<D, NW>, grid, dim3(NW * 64), lds, (const bf16_t *)q,
+                     (const bf16_t *)k_cache, (const bf16_t *)v_cache_T, st, (bf16_t *)out, (int)T, (int)H, (int)Hkv, (int)seq_alloc,
+                     scale * 1.44269504088896340736f, (int)window, paired);
+}
+
 int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, const void *v_cache_T, const StepState *st,
                              void *out, int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t seq_alloc, float scale,
                              int64_t window) {
     const int G = (int)(H / Hkv);
     if (G > 8) FL_FAIL(FL_ERR_UNSUPPORTED, "mfma prefill attention: at most 8 query heads per kv head");
+    // 32-row waves (attn_prefill32_kernel) once the prompt is long enough to fill the chip with their workgroups
+    static const int pf32_min_t = getenv("FL_ATTN_PF32_MIN_T") ? atoi(getenv("FL_ATTN_PF32_MIN_T")) : 1024;
+    if (T >= pf32_min_t && scale > 0.f) {
+        // waves per workgroup: 8 (G = 1, 2, 4), 6 (G = 3), else G.  Paired (balanced) grids win as soon as they cover
+        // ~3/4 of the chip -- Mistral-7B per layer: T = 3072 134 us paired (192 workgroups) vs 197 unpaired, T = 4096
+        // 177 vs 305, T = 8192 681 vs 693; T = 2048 (128 paired workgroups) 98 vs 85.  4-wave workgroups (half the K/V
+        // reuse, one wave per SIMD) lost everywhere: T = 2048 105 / 180 us, T = 4096 371 / 515.
+        const int NW = G <= 4 ? (8 / G) * G : G, TB = NW / G;
+        const int64_t nb = (T + 32 * TB - 1) / (32 * TB);
+        static const int force_pair = getenv("FL_ATTN_PF32_PAIRED") ? atoi(getenv("FL_ATTN_PF32_PAIRED")) : -1;
+        const int paired = force_pair >= 0 ? force_pair : ((nb + 1) / 2 * Hkv >= 180 ? 1 : 0);
+#define FL_PF32(DD, WW) if (d == DD && NW == WW) return launch_pf32<DD, WW>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired);
+        FL_PF32(128, 8) FL_PF32(128, 7) FL_PF32(128, 6) FL_PF32(128, 5) FL_PF32(64, 8) FL_PF32(64, 7) FL_PF32(64, 6) FL_PF32(64, 5)
+#undef FL_PF32
+    }
     // token sub-tiles per workgroup: every staged K/V tile then serves TT x G x 16 query rows.  Measured: G = 4
     // (Mistral, T = 2048) 4.75 ms with 4 waves, 4.25 with 8, 4.06 with 16; G = 7 (Qwen2, T = 4096) 10.8 ms with 7
     // waves, 12.3 with 14 (126 VGPRs: 16 waves per CU either way, and a longer token block is more lopsided under
     // the causal mask)
+    // ... but only while the grid still covers the chip: at T = 512 (Mistral) 4-wave workgroups (256 of them) take
+    // 26 us per layer against 36 us for 64 16-wave ones; at T = 1024 8 waves 49 us against 57 (4) and 67 (16)
     static const int tt_waves = getenv("FL_ATTN_PF_WAVES") ? atoi(getenv("FL_ATTN_PF_WAVES")) : 0;
-    const int TT = tt_waves > 0 ? std::max(1, std::min(16, tt_waves) / G) : (G <= 4 ? 16 / G : 1);
+    int TT = tt_waves > 0 ? std::max(1, std::min(16, tt_waves) / G) : (G <= 4 ? 16 / G : 1);
+    if (tt_waves <= 0)
+        while (TT > 1 && ((T + 16 * TT - 1) / (16 * TT)) * Hkv < 256) TT >>= 1;
     dim3 grid((unsigned)((T + 16 * TT - 1) / (16 * TT)), (unsigned)Hkv);
     dim3 block((unsigned)(G * TT * 64));
     const size_t lds = 2 * (size_t)(2 * 32 * d * 2);

@@ -200,7 +200,9 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         attr = true;
     }
     const double bytes = ((double)N * K + (double)T * K) * 2.0;
-    Launcher LL = L; LL.tag = "8p";
+    char tag[32];
+    snprintf(tag, sizeof tag, "8p,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");
+    Launcher LL = L; LL.tag = tag;
     return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, gemm_8p_kernel, dim3((unsigned)(tiles_m * tiles_n), (unsigned)ksplit), dim3(512),
                      P_LDS, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit);
 }

@@ -298,7 +298,10 @@ int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bia
                 attr2 = true;
             }
             double bytes2 = ((double)N * K + (double)T * K) * 2.0;
-            return L.launch(KC_GEMM_MFMA, bytes2, 2.0 * T * N * K, gemm_mfma256_kernel, dim3((unsigned)(tm2 * tn2)), dim3(512),
+            char tag2[32];
+            snprintf(tag2, sizeof tag2, "256x128,%lldx%lld", (long long)N, (long long)K);
+            Launcher L2 = L; L2.tag = tag2;
+            return L2.launch(KC_GEMM_MFMA, bytes2, 2.0 * T * N * K, gemm_mfma256_kernel, dim3((unsigned)(tm2 * tn2)), dim3(512),
                             lds2, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tm2, tn2, row_scale);
         }
     }
@@ -312,7 +315,10 @@ int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bia
         attr_set = true;
     }
     double bytes = ((double)N * K + (double)T * K) * 2.0;
-    return L.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, gemm_mfma_kernel, dim3((unsigned)(tiles_m * tiles_n), (unsigned)ksplit),
+    char tag[32];
+    snprintf(tag, sizeof tag, "128x128,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");
+    Launcher LL = L; LL.tag = tag;
+    return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, gemm_mfma_kernel, dim3((unsigned)(tiles_m * tiles_n), (unsigned)ksplit),
                     dim3(256), lds, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi,
                     tiles_m, tiles_n, row_scale, ksplit);
 }

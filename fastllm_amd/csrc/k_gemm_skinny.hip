@@ -148,7 +148,9 @@ static int launch_skinny_t(Launcher &L, const void *W, const void *x, const floa
         attr = true;
     }
     const double bytes = ((double)N * K + (double)T * K) * 2.0;
-    Launcher LL = L; LL.tag = "skinny";
+    char tag[32];
+    snprintf(tag, sizeof tag, "skinny,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");
+    Launcher LL = L; LL.tag = tag;
     return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, dim3((unsigned)((N + BN - 1) / BN), (unsigned)ksplit, (unsigned)((T + BM - 1) / BM)), dim3(NW * 64), lds,
                      (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, row_scale, ksplit);
 }

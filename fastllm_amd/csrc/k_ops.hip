@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(const float *__restrict__ 
                                                       const float *__restrict__ cos_tab, const float *__restrict__ sin_tab,
                                                       int max_pos, CT *__restrict__ q_out, CT *__restrict__ kc,
                                                       CT *__restrict__ vc, int T, int H, int Hkv, int d, int max_seq,
-                                                      int v_transposed) {
+                                                      int v_transposed, int nslab, long long slab_stride) {
     const int half = d >> 1;
     const int nheads = H + 2 * Hkv;
     const int per_t = nheads * half;
@@ -102,7 +102,11 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(const float *__restrict__ 
     const int t = (int)(idx / per_t), rem = (int)(idx % per_t);
     const int hd = rem / half, j = rem % half;
     const float *src = qkv + (size_t)t * nheads * d + (size_t)hd * d;
-    const float a = src[j], b = src[j + half];
+    float a = src[j], b = src[j + half];
+    for (int sl = 1; sl < nslab; sl++) {             // split-K slabs of the projection, summed in slab order
+        a += src[(size_t)sl * slab_stride + j];
+        b += src[(size_t)sl * slab_stride + j + half];
+    }
     const uint32_t pos = st->pos + (uint32_t)t, slot = st->len + (uint32_t)t;
     if (hd < H + Hkv) {
         const uint32_t p = pos < (uint32_t)max_pos ? pos : (uint32_t)max_pos - 1;   // host validates range
@@ -126,7 +130,8 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(const float *__restrict__ 
 
 int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st, const float *cos_tab,
                    const float *sin_tab, int64_t max_pos, void *q_out, void *k_cache, void *v_cache,
-                   int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t max_seq, bool v_transposed) {
+                   int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t max_seq, bool v_transposed, int nslab) {
+    const long long slab_stride = (long long)T * (H + 2 * Hkv) * d;
     const int64_t total = T * (H + 2 * Hkv) * (d / 2);
     const unsigned blocks = (unsigned)((total + 255) / 256);
     const int es = dtype == FL_DTYPE_BF16 ? 2 : 4;
@@ -134,10 +139,10 @@ int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st
     if (dtype == FL_DTYPE_BF16)
         return L.launch(KC_ROPE_KV, bytes, 0, rope_kv_kernel<bf16_t>, dim3(blocks), dim3(256), 0, qkv, st, cos_tab,
                         sin_tab, (int)max_pos, (bf16_t *)q_out, (bf16_t *)k_cache, (bf16_t *)v_cache, (int)T, (int)H,
-                        (int)Hkv, (int)d, (int)max_seq, (int)v_transposed);
+                        (int)Hkv, (int)d, (int)max_seq, (int)v_transposed, nslab, slab_stride);
     return L.launch(KC_ROPE_KV, bytes, 0, rope_kv_kernel<float>, dim3(blocks), dim3(256), 0, qkv, st, cos_tab,
                     sin_tab, (int)max_pos, (float *)q_out, (float *)k_cache, (float *)v_cache, (int)T, (int)H,
-                    (int)Hkv, (int)d, (int)max_seq, (int)v_transposed);
+                    (int)Hkv, (int)d, (int)max_seq, (int)v_transposed, nslab, slab_stride);
 }
 
 // ------------------------------------------------------------------------------- batched variants (row N4)

@@ -327,6 +327,7 @@ static int build_rope(Model *m) {
 }
 
 constexpr int kMaxKSplit = 4;
+constexpr int kMaxQkvSplit = 2;   // QKV projection of a mid-size prompt (its grid leaves CUs idle); rope_kv sums the slabs
 
 // owner: who frees the buffers (default: the shard, i.e. at model destruction)
 static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T, std::vector<void *> *owner = nullptr) {
@@ -342,7 +343,7 @@ static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T, std::vecto
     FL_TRY(dev_alloc(own, (void **)&sc.delta, (size_t)T * D.h * 4 * (T > 1 ? kMaxKSplit : 1), acct));   // split-K slabs
     FL_TRY(dev_alloc(own, &sc.xn, (size_t)T * D.h * es, acct));
     FL_TRY(dev_alloc(own, (void **)&sc.inv_rms, (size_t)T * 4, acct));
-    FL_TRY(dev_alloc(own, (void **)&sc.qkv, (size_t)T * nq * 4, acct));
+    FL_TRY(dev_alloc(own, (void **)&sc.qkv, (size_t)T * nq * 4 * (T > 1 ? kMaxQkvSplit : 1), acct));    // split-K slabs
     FL_TRY(dev_alloc(own, &sc.q, (size_t)T * sh.Hs * D.d * es, acct));
     FL_TRY(dev_alloc(own, &sc.ao, (size_t)T * sh.Hs * D.d * es, acct));
     FL_TRY(dev_alloc(own, &sc.act, (size_t)T * sh.Ip * es, acct));
@@ -1106,9 +1107,11 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             const size_t kv_layer = (size_t)l * sh.Hkvs * c->seq_alloc * D.d * m->esize();
             void *kc = (char *)cs.k + kv_layer, *vc = (char *)cs.v + kv_layer;
             FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, l == 0 ? nullptr : sc.delta, ly.ln1, D.eps, sc.xn, sc.inv_rms, T, D.h, nslab, slab));
-            FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, ly.bqkv, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms));
+            int qkv_slabs = 1;
+            static const int qkv_split = env_int("FL_QKV_SPLIT", kMaxQkvSplit);
+            FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, ly.bqkv, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms, T > 1 ? std::min(qkv_split, kMaxQkvSplit) : 1, &qkv_slabs));
             const int64_t sa = (int64_t)c->seq_alloc;
-            FL_TRY(launch_rope_kv(L, dt, sc.qkv, cs.st, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, kc, vc, T, sh.Hs, sh.Hkvs, D.d, sa, c->v_transposed));
+            FL_TRY(launch_rope_kv(L, dt, sc.qkv, cs.st, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, kc, vc, T, sh.Hs, sh.Hkvs, D.d, sa, c->v_transposed, qkv_slabs));
             if (T == 1) {
                 AttnScratch as{cs.part_m, cs.part_l, cs.part_o, cs.counters, c->nsplit, len_hint + 1};
                 if (c->v_transposed) FL_TRY(launch_attn_decode_mfma(L, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, sa, D.scale));
