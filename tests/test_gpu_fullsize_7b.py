@@ -88,11 +88,21 @@ def test_mistral_7b_full_depth_properties(env, monkeypatch):
     a = gm.decode_greedy(c1, tok, T, 64)
     b = gm.decode_greedy(c2, tok, T, 64)
     assert len(a) == 64
-    same = int(np.argmax(a != b)) if (a != b).any() else 64      # c2 was built by another kernel path: bf16-close, so
-    assert same >= 8, (a[:12], b[:12])                            # the sequences agree until a near-tie
     c3 = gm.new_cache(1024)
     gm.forward(c3, ids, 0)
     np.testing.assert_array_equal(gm.decode_greedy(c3, tok, T, 64), a)     # same path twice: bit-identical
+    # c2 was built by another kernel path (bf16-close, not bit-equal): the two greedy sequences may part, but only
+    # where the two candidates are a near-tie within that closeness -- replay cache 1's sequence up to the fork
+    if (a != b).any():
+        k = int(np.argmax(a != b))
+        c5 = gm.new_cache(1024)
+        lg = gm.forward(c5, ids, 0)
+        seq = np.concatenate([[tok], a[:k]]).astype(np.uint32)
+        for i, t_in in enumerate(seq):
+            lg = gm.forward(c5, seq[i:i + 1], T + i)
+        assert int(np.flatnonzero(lg == lg.max())[-1]) == int(a[k])
+        margin = float(lg[a[k]] - lg[b[k]])
+        assert 0.0 <= margin <= 6e-2 * max(1.0, float(np.abs(lg).max())), "fork at step %d is not a near-tie: margin %g" % (k, margin)
     # library-chunked prefill keeps the single call's mask
     monkeypatch.setenv("FL_PREFILL_CHUNK", "160")
     c4 = gm.new_cache(1024)
