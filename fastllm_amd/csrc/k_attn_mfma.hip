@@ -160,12 +160,29 @@ __device__ inline void glds16(const void *g, unsigned char *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate)
+__device__ inline void wait_vmcnt(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // always safe
+    }
+}
+
+// every wave issues the same number of 1-KiB pieces, per = ceil((NK + NV) / nwv) (wrapping: a duplicate piece writes
+// the same bytes), so that a counted vmcnt can tell which tiles have landed
 template <int D>
 __device__ inline void stage_kv(const bf16_t *__restrict__ kb, const bf16_t *__restrict__ vT, int ldv, int kbase,
-                                unsigned char *buf, int wave, int nwv, int lane) {
+                                unsigned char *buf, int wave, int nwv, int lane, int per) {
     constexpr int CPR = D / 8, NK = CPR / 2, NV = D / 16;          // wave-instructions (1 KiB each) per tile
     unsigned char *kt = buf, *vt = buf + 32 * D * 2;
-    for (int e = wave; e < NK + NV; e += nwv) {
+    for (int k = 0; k < per; k++) {
+        const int e = (wave + k * nwv) % (NK + NV);
         if (e < NK) {
             const int p = e * 64 + lane, row = p / CPR, pc = p % CPR, c = pc ^ (row & (CPR - 1));
             glds16(kb + (size_t)(kbase + row) * D + c * 8, kt + e * 1024);
@@ -180,8 +197,8 @@ template <int D>
 __global__ __launch_bounds__(1024) void attn_prefill_mfma_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
                                                                 const bf16_t *__restrict__ vT, const StepState *__restrict__ st,
                                                                 bf16_t *__restrict__ out, int T, int H, int Hkv, int seq_alloc,
-                                                                float scale, int window, int TT) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // 2 x (K tile | V^T tile)
+                                                                float scale, int window, int TT, int nst) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // nst x (K tile | V^T tile)
     constexpr int TILE = 2 * 32 * D * 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     const int i = lane & 15, g4 = lane >> 4;
@@ -221,14 +238,18 @@ __global__ __launch_bounds__(1024) void attn_prefill_mfma_kernel(const bf16_t *_
     if (c0 == 0 && window >= 0 && len + tb0 - window > 0) kstart = ((len + tb0 - window) / 32) * 32;
     const int kend = len + min(T, tb0 + 16 * TT);
     const int nsteps = (kend - kstart + 31) / 32;
-    stage_kv<D>(kb, vb, seq_alloc, kstart, lds, wave, nwv, lane);
+    // ring of nst tiles, nst - 1 of them in flight
+    constexpr int NI = D / 16 + D / 16;
+    const int per = (NI + nwv - 1) / nwv;
+    for (int a = 0; a < nst - 1 && a < nsteps; a++) stage_kv<D>(kb, vb, seq_alloc, kstart + 32 * a, lds + a * TILE, wave, nwv, lane, per);
     for (int sidx = 0; sidx < nsteps; sidx++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        wait_vmcnt(per * min(nst - 2, nsteps - 1 - sidx));       // tile sidx has landed; the younger ones may still fly
+        __builtin_amdgcn_s_barrier();
         const int kbase = kstart + 32 * sidx;
-        if (sidx + 1 < nsteps) stage_kv<D>(kb, vb, seq_alloc, kbase + 32, lds + ((sidx + 1) & 1) * TILE, wave, nwv, lane);
+        if (sidx + nst - 1 < nsteps)
+            stage_kv<D>(kb, vb, seq_alloc, kbase + 32 * (nst - 1), lds + ((sidx + nst - 1) % nst) * TILE, wave, nwv, lane, per);
         if (kbase + 32 > wstart && kbase < wend) {               // wave-uniform
-            const unsigned char *cur = lds + (sidx & 1) * TILE;
+            const unsigned char *cur = lds + (sidx % nst) * TILE;
             const LdsKV<D> kv{cur, cur + 32 * D * 2, i, g4};
             attn_tile<D>(s, qf, kv, kbase, pre_hi, lo_q, hi_q, scale, lane);
         }
@@ -506,16 +527,21 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
         while (TT > 1 && ((T + 16 * TT - 1) / (16 * TT)) * Hkv < 256) TT >>= 1;
     dim3 grid((unsigned)((T + 16 * TT - 1) / (16 * TT)), (unsigned)Hkv);
     dim3 block((unsigned)(G * TT * 64));
-    const size_t lds = 2 * (size_t)(2 * 32 * d * 2);
+    // LDS tiles in the ring (FL_ATTN_PF_STAGES, 2..4).  Measured: a deeper ring buys nothing -- Mistral T = 512 25 / 26 /
+    // 25 us per layer with 2 / 3 / 4 tiles, T = 768 41 / 40 / 42: with one wave per SIMD a key step is a chain of
+    // dependent LDS read -> MFMA -> shuffle -> exp -> MFMA latencies (~1.5 us), not a wait for the tile
+    static const int pf_stages = getenv("FL_ATTN_PF_STAGES") ? atoi(getenv("FL_ATTN_PF_STAGES")) : 2;
+    const int nst = std::max(2, std::min(4, G * TT <= 8 ? pf_stages : 2));
+    const size_t lds = (size_t)nst * (size_t)(2 * 32 * d * 2);
     double flops = 2.0 * (double)T * T * H * d;
     if (d == 128)
         return L.launch(KC_ATTN_PREFILL, 0, flops, attn_prefill_mfma_kernel<128>, grid, block, lds, (const bf16_t *)q,
                         (const bf16_t *)k_cache, (const bf16_t *)v_cache_T, st, (bf16_t *)out, (int)T, (int)H, (int)Hkv,
-                        (int)seq_alloc, scale, (int)window, TT);
+                        (int)seq_alloc, scale, (int)window, TT, nst);
     if (d == 64)
         return L.launch(KC_ATTN_PREFILL, 0, flops, attn_prefill_mfma_kernel<64>, grid, block, lds, (const bf16_t *)q,
                         (const bf16_t *)k_cache, (const bf16_t *)v_cache_T, st, (bf16_t *)out, (int)T, (int)H, (int)Hkv,
-                        (int)seq_alloc, scale, (int)window, TT);
+                        (int)seq_alloc, scale, (int)window, TT, nst);
     FL_FAIL(FL_ERR_UNSUPPORTED, "mfma attention: head_dim %lld", (long long)d);
 }
 
