@@ -197,15 +197,18 @@ template <int D>
 __global__ __launch_bounds__(1024) void attn_prefill_mfma_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
                                                                 const bf16_t *__restrict__ vT, const StepState *__restrict__ st,
                                                                 bf16_t *__restrict__ out, int T, int H, int Hkv, int seq_alloc,
-                                                                float scale, int window, int TT, int nst) {
+                                                                float scale, int window, int TT, int nst, int ks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // nst x (K tile | V^T tile)
     constexpr int TILE = 2 * 32 * D * 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     const int i = lane & 15, g4 = lane >> 4;
     const int G = H / Hkv, hk = blockIdx.y;
-    const int hq = hk * G + wave % G;
+    // ks == 2 (short prompts): two waves per (head, token sub-tile) take alternate key tiles and merge at the end --
+    // a key step is a chain of dependent latencies, and this puts two such chains on every SIMD
+    const int wq = wave % (G * TT), half = wave / (G * TT);
+    const int hq = hk * G + wq % G;
     const int tb0 = blockIdx.x * TT * 16;                        // first token of the workgroup
-    const int t0 = tb0 + (wave / G) * 16;                        // first token of this wave
+    const int t0 = tb0 + (wq / G) * 16;                          // first token of this wave
     const int len = (int)st->len;
     const int t = t0 + i;                                        // this lane's column
     const bool col_ok = t < T;
@@ -241,6 +244,60 @@ __global__ __launch_bounds__(1024) void attn_prefill_mfma_kernel(const bf16_t *_
     // ring of nst tiles, nst - 1 of them in flight
     constexpr int NI = D / 16 + D / 16;
     const int per = (NI + nwv - 1) / nwv;
+    if (ks == 2) {
+        // super-steps of two tiles (buffers [stage][half]); one barrier per super-step, two LDS stages
+        const int nsuper = (nsteps + 1) / 2;
+        auto stage2 = [&](int ss, int stg) {
+            const int k0 = kstart + 64 * ss;
+            stage_kv<D>(kb, vb, seq_alloc, k0, lds + (stg * 2) * TILE, wave, nwv, lane, per);
+            if (k0 + 32 < kend) stage_kv<D>(kb, vb, seq_alloc, k0 + 32, lds + (stg * 2 + 1) * TILE, wave, nwv, lane, per);
+        };
+        stage2(0, 0);
+        for (int ss = 0; ss < nsuper; ss++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (ss + 1 < nsuper) stage2(ss + 1, (ss + 1) & 1);
+            const int kbase = kstart + 64 * ss + 32 * half;
+            if (kbase < kend && kbase + 32 > wstart && kbase < wend) {               // wave-uniform
+                const unsigned char *cur = lds + ((ss & 1) * 2 + half) * TILE;
+                const LdsKV<D> kv{cur, cur + 32 * D * 2, i, g4};
+                attn_tile<D>(s, qf, kv, kbase, pre_hi, lo_q, hi_q, scale, lane);
+            }
+        }
+        // merge the two key halves through LDS (the tiles are dead after the barrier)
+        __syncthreads();
+        float *slab = reinterpret_cast<float *>(lds) + (size_t)wq * (16 * D + 32);
+        float lt1 = s.l;
+        lt1 += __shfl_xor(lt1, 16, 64);
+        lt1 += __shfl_xor(lt1, 32, 64);
+        if (half == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int db = 0; db < D / 16; db++) slab[(4 * g4 + r) * D + db * 16 + i] = s.O[db][r];
+            if (g4 == 0) { slab[16 * D + i] = s.m; slab[16 * D + 16 + i] = lt1; }
+        }
+        __syncthreads();
+        if (half == 1) return;
+        const float m1 = slab[16 * D + i], l1 = slab[16 * D + 16 + i];
+        const float mm = fmaxf(s.m, m1);
+        const float w0 = s.m == -INFINITY ? 0.f : __expf(s.m - mm), w1 = m1 == -INFINITY ? 0.f : __expf(m1 - mm);
+        const float ltot = lt1 * w0 + l1 * w1;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int qq = 4 * g4 + r;
+            const float lr = __shfl(ltot, qq, 64), a0 = __shfl(w0, qq, 64), a1 = __shfl(w1, qq, 64);
+            const int tt = t0 + qq;
+            if (tt < T) {
+                const float inv = 1.0f / lr;
+                bf16_t *o = out + ((size_t)tt * H + hq) * D;
+#pragma unroll
+                for (int db = 0; db < D / 16; db++)
+                    o[db * 16 + i] = float_to_bf16_bits((s.O[db][r] * a0 + slab[qq * D + db * 16 + i] * a1) * inv);
+            }
+        }
+        return;
+    }
     for (int a = 0; a < nst - 1 && a < nsteps; a++) stage_kv<D>(kb, vb, seq_alloc, kstart + 32 * a, lds + a * TILE, wave, nwv, lane, per);
     for (int sidx = 0; sidx < nsteps; sidx++) {
         wait_vmcnt(per * min(nst - 2, nsteps - 1 - sidx));       // tile sidx has landed; the younger ones may still fly
@@ -531,17 +588,22 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
     // 25 us per layer with 2 / 3 / 4 tiles, T = 768 41 / 40 / 42: with one wave per SIMD a key step is a chain of
     // dependent LDS read -> MFMA -> shuffle -> exp -> MFMA latencies (~1.5 us), not a wait for the tile
     static const int pf_stages = getenv("FL_ATTN_PF_STAGES") ? atoi(getenv("FL_ATTN_PF_STAGES")) : 2;
-    const int nst = std::max(2, std::min(4, G * TT <= 8 ? pf_stages : 2));
-    const size_t lds = (size_t)nst * (size_t)(2 * 32 * d * 2);
+    int nst = std::max(2, std::min(4, G * TT <= 8 ? pf_stages : 2));
+    // key split (two waves per head and token sub-tile) while the workgroup stays within 8 waves: short prompts
+    static const int pf_ksplit = getenv("FL_ATTN_PF_KSPLIT") ? atoi(getenv("FL_ATTN_PF_KSPLIT")) : 2;
+    // (four waves per query tile measured slower than two: Mistral T = 512 23 vs 18 us per layer, T = 768 45 vs 33)
+    const int ks = (pf_ksplit >= 2 && G * TT * 2 <= 16) ? 2 : 1;
+    if (ks == 2) { nst = 2; block = dim3((unsigned)(G * TT * 2 * 64)); }
+    const size_t lds = std::max((size_t)nst * ks * (size_t)(2 * 32 * d * 2), ks == 2 ? (size_t)G * TT * (16 * d + 32) * 4 : (size_t)0);
     double flops = 2.0 * (double)T * T * H * d;
     if (d == 128)
         return L.launch(KC_ATTN_PREFILL, 0, flops, attn_prefill_mfma_kernel<128>, grid, block, lds, (const bf16_t *)q,
                         (const bf16_t *)k_cache, (const bf16_t *)v_cache_T, st, (bf16_t *)out, (int)T, (int)H, (int)Hkv,
-                        (int)seq_alloc, scale, (int)window, TT, nst);
+                        (int)seq_alloc, scale, (int)window, TT, nst, ks);
     if (d == 64)
         return L.launch(KC_ATTN_PREFILL, 0, flops, attn_prefill_mfma_kernel<64>, grid, block, lds, (const bf16_t *)q,
                         (const bf16_t *)k_cache, (const bf16_t *)v_cache_T, st, (bf16_t *)out, (int)T, (int)H, (int)Hkv,
-                        (int)seq_alloc, scale, (int)window, TT, nst);
+                        (int)seq_alloc, scale, (int)window, TT, nst, ks);
     FL_FAIL(FL_ERR_UNSUPPORTED, "mfma attention: head_dim %lld", (long long)d);
 }
 
