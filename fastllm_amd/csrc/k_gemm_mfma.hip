@@ -160,7 +160,7 @@ __device__ inline void stage_rows8(const bf16_t *__restrict__ M, int nrows, int 
 __global__ __launch_bounds__(512) void gemm_mfma256_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
                                                            const float *__restrict__ bias, void *__restrict__ out,
                                                            int T, int N, int K, int epi, int tiles_m, int tiles_n,
-                                                           const float *__restrict__ row_scale) {
+                                                           const float *__restrict__ row_scale, int ksplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [3 stages][X 256x64 | W 128x64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -177,7 +177,11 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(const bf16_t *__restr
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / BK;
+    // split-K: blockIdx.y owns K tiles [kt0, kt0 + nk) and writes its own fp32 slab (summed by the consumer)
+    const int nk_all = K / BK, kz = blockIdx.y;
+    const int kt0 = (int)((long long)nk_all * kz / ksplit), nk = (int)((long long)nk_all * (kz + 1) / ksplit) - kt0;
+    X += (size_t)kt0 * BK; W += (size_t)kt0 * BK;
+    if (ksplit > 1) out = reinterpret_cast<float *>(out) + (size_t)kz * T * N;
     auto stage = [&](int kt, int slot) {                          // 4 + 2 = 6 LDS-DMA instructions per wave
         unsigned char *base = lds + slot * STAGE2;
         stage_rows8<BM2>(X, T, K, m0, kt * BK, base, wave, lane);
@@ -255,6 +259,23 @@ static int gemm_8p_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_spli
     return 0;
 }
 
+// Mid-size prompts (T = 512: 2 row tiles) leave the 256x256 grid far short of the chip and the 128x128 kernel
+// (two stages, vmcnt(0) per K step) at 0.53-0.75 PFLOP/s.  The 256x128 kernel with K slices covers the chip in ONE
+// round of one workgroup per CU: the largest split within the caller's limit whose grid fits 256 workgroups,
+// provided it fills >= 224 of them and every slice keeps >= 8 K steps.  0: not applicable.  Measured in the
+// Mistral-7B pipeline at T = 512 (256 workgroups): down 80 -> 71.5 us, o_proj 30 -> 30; at 192 workgroups it is a
+// wash or worse (T = 512 QKV 48.4 -> 46.0, T = 768 down 113 -> 117, o_proj 41 -> 43), hence the threshold.
+static int gemm_256_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
+    static const int on = getenv("FL_GEMM_256_SPLIT") ? atoi(getenv("FL_GEMM_256_SPLIT")) : 1;
+    if (!on || T < 256 || K % BK) return 0;
+    const int64_t tiles = ((T + BM2 - 1) / BM2) * ((N + BN - 1) / BN);
+    if (tiles > 256) return 0;
+    int best = 0;
+    for (int ks = 1; ks <= (epi == EPI_F32 ? max_split : 1); ks++)
+        if (tiles * ks <= 256 && (K / BK) / ks >= 8) best = ks;
+    return best > 0 && tiles * best >= 224 ? best : 0;
+}
+
 // how many K splits the launcher will use for this shape when the caller allows up to max_split slabs
 int gemm_mfma_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
     {
@@ -263,6 +284,8 @@ int gemm_mfma_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
             const int k8 = gemm_8p_ksplit(T, N, K, epi, max_split);
             if (k8 > 0) return k8;
         }
+        const int k2 = gemm_256_ksplit(T, N, K, epi, max_split);
+        if (k2 > 0) return k2;
     }
     const int64_t tiles = ((T + BM - 1) / BM) * ((N + BN - 1) / BN);
     if (epi != EPI_F32 || max_split <= 1 || tiles >= 256 || K < 2048) return 1;
@@ -285,11 +308,14 @@ int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bia
             return launch_gemm_8p(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
     }
     static const int use256 = getenv("FL_GEMM_256") ? atoi(getenv("FL_GEMM_256")) : 1;
-    if (use256 && ksplit == 1 && T >= 192 && K / BK >= 3) {
+    if (use256 && T >= 192 && K / BK >= 3 && (ksplit == 1 || (!bias && epi == EPI_F32))) {
         const int tm2 = (int)((T + BM2 - 1) / BM2), tn2 = (int)((N + BN - 1) / BN);
         // measured (profiles/r01/gemm_probe.txt): +13 % over the 128x128 kernel at thousands of tiles, -5 % at
-        // ~450 tiles (1.75 rounds of one workgroup per CU): use it only when the tail round does not matter
-        if ((int64_t)tm2 * tn2 >= 1024) {
+        // ~450 tiles (1.75 rounds of one workgroup per CU): use it only when the tail round does not matter --
+        // or when its grid (with K slices) is exactly one round (gemm_256_ksplit)
+        const bool one_round = ksplit == gemm_256_ksplit(T, N, K, epi, ksplit) && ksplit > 0 && (int64_t)tm2 * tn2 * ksplit <= 256 &&
+                               (int64_t)tm2 * tn2 * ksplit >= 224;
+        if ((ksplit == 1 && (int64_t)tm2 * tn2 >= 1024) || one_round) {
             const size_t lds2 = 3 * (size_t)STAGE2;                     // 144 KiB
             static bool attr2 = false;
             if (!attr2) {
@@ -299,10 +325,10 @@ int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bia
             }
             double bytes2 = ((double)N * K + (double)T * K) * 2.0;
             char tag2[32];
-            snprintf(tag2, sizeof tag2, "256x128,%lldx%lld", (long long)N, (long long)K);
+            snprintf(tag2, sizeof tag2, "256x128,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");
             Launcher L2 = L; L2.tag = tag2;
-            return L2.launch(KC_GEMM_MFMA, bytes2, 2.0 * T * N * K, gemm_mfma256_kernel, dim3((unsigned)(tm2 * tn2)), dim3(512),
-                            lds2, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tm2, tn2, row_scale);
+            return L2.launch(KC_GEMM_MFMA, bytes2, 2.0 * T * N * K, gemm_mfma256_kernel, dim3((unsigned)(tm2 * tn2), (unsigned)ksplit), dim3(512),
+                            lds2, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tm2, tn2, row_scale, ksplit);
         }
     }
     const int tiles_m = (int)((T + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
