@@ -301,21 +301,29 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
         }
         // K tail: the remaining 1..U-1 whole 64-lane chunks as ONE straight-line block (K = 3584, 5632,
         // 18944 ... all leave such a remainder), then a generic loop for a ragged last chunk
+        // ... and the tensor-parallel slices (K = 1792, 4736, 896 ...) end in a PARTIAL 64-lane chunk: the lanes past
+        // the end load a clamped (valid) address and contribute zeros, so the block stays straight-line as well
         {
             const int remaining = nchunk - (c0 - lane);          // wave-uniform
-            const int full = remaining >> 6;
-            if (remaining > 0 && (remaining & 63) == 0 && full < U) {
+            const int nblk = (remaining + 63) >> 6;
+            if (remaining > 0 && nblk < U) {
                 auto tail_block = [&](auto TU) {
                     constexpr int NT = decltype(TU)::value;
                     RawChunk<WT> w[R][NT];
 #pragma unroll
-                    for (int u = 0; u < NT; u++)
+                    for (int u = 0; u < NT; u++) {
+                        const int ci = c0 + 64 * u, cc = ci < nchunk ? ci : nchunk - 1;
 #pragma unroll
-                        for (int r = 0; r < R; r++) load_raw_nt(wp[r] + (size_t)(c0 + 64 * u) * 8, w[r][u]);
+                        for (int r = 0; r < R; r++) load_raw_nt(wp[r] + (size_t)cc * 8, w[r][u]);
+                    }
 #pragma unroll
                     for (int u = 0; u < NT; u++) {
+                        const int ci = c0 + 64 * u;
+                        const bool ok = ci < nchunk;
                         float xv[8];
-                        load8(xs + (c0 + 64 * u) * 8, xv);
+                        load8(xs + (ok ? ci : nchunk - 1) * 8, xv);
+#pragma unroll
+                        for (int j = 0; j < 8; j++) xv[j] = ok ? xv[j] : 0.f;
 #pragma unroll
                         for (int r = 0; r < R; r++) {
                             float wv[8];
@@ -326,10 +334,10 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
                     }
                     c0 += 64 * NT;
                 };
-                if (full == 1) tail_block(std::integral_constant<int, 1>{});
-                else if (full == 2) tail_block(std::integral_constant<int, 2>{});
-                else if (full == 3) tail_block(std::integral_constant<int, 3>{});
-                else if (U > 4 && full == 4) tail_block(std::integral_constant<int, 4>{});
+                if (nblk == 1) tail_block(std::integral_constant<int, 1>{});
+                else if (nblk == 2) tail_block(std::integral_constant<int, 2>{});
+                else if (nblk == 3) tail_block(std::integral_constant<int, 3>{});
+                else if (U > 4 && nblk == 4) tail_block(std::integral_constant<int, 4>{});
             }
         }
 #pragma nounroll
