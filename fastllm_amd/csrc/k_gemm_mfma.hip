@@ -247,16 +247,28 @@ bool gemm_mfma_supported(int dtype, int64_t T, int64_t N, int64_t K) {
     return dtype == FL_DTYPE_BF16 && T > 1 && K % BK == 0 && K >= BK && N >= 1;
 }
 
-// K slices that let the 256x256 kernel (one workgroup per CU) cover the chip: 0 if none does
+// Is the 256x256 kernel (one workgroup per CU) worth it with ks K slices?  Returns the fill of its last round in
+// 1/1024 (0 = no).  Measured (gemm_probe, pipeline profiles): 224 tiles +13..29 % over the 128x128 kernel, 2368 tiles
+// +15 %; 288 tiles -6 %, 48..128 tiles -40 %; at exactly 3/4 of a round it still wins when the slices are long
+// (Mistral QKV T = 2048: 152 -> 123 us, T = 1024 with two slices: 78 -> 71 us) and loses when they are 16 K tiles
+// (o_proj T = 768 in four slices: 41 -> 50 us).
+static int gemm_8p_fill(int64_t T, int64_t N, int64_t K, int ks) {
+    if (T < 256 || K % 64 || ks < 1 || (K / 64) / ks < 16) return 0;   // keep the pipeline long enough to pay for its ramp
+    const int64_t t8 = ((T + 255) / 256) * ((N + 255) / 256) * ks, rounds = (t8 + 255) / 256;
+    const int fill = (int)(t8 * 1024 / (rounds * 256));
+    if (t8 < 192) return 0;
+    if (fill >= 820) return fill;                                       // >= 80 %
+    return fill >= 768 && (K / 64) / ks >= 24 ? fill : 0;               // 75 %: long slices only
+}
+
+// K slices that let the 256x256 kernel cover the chip best (ties: fewer slices): 0 if none does
 static int gemm_8p_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
-    if (T < 256 || K % 64) return 0;
-    const int64_t tiles = ((T + 255) / 256) * ((N + 255) / 256);
+    int best = 0, best_fill = 0;
     for (int ks = 1; ks <= (epi == EPI_F32 ? max_split : 1); ks++) {
-        if ((K / 64) / ks < 16) break;                              // keep the pipeline long enough to pay for its ramp
-        const int64_t t8 = tiles * ks, rounds = (t8 + 255) / 256;
-        if (t8 >= 200 && t8 * 10 >= rounds * 256 * 8) return ks;
+        const int f = gemm_8p_fill(T, N, K, ks);
+        if (f > best_fill) { best = ks; best_fill = f; }
     }
-    return 0;
+    return best;
 }
 
 // Mid-size prompts (T = 512: 2 row tiles) leave the 256x256 grid far short of the chip and the 128x128 kernel
@@ -300,11 +312,8 @@ int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bia
     const char *e8 = getenv("FL_GEMM_8P");                      // read per call: tests switch it
     const int use8p = e8 && *e8 ? atoi(e8) : 1;
     if (use8p && K % 64 == 0 && (K / 64) / ksplit >= 2 && (ksplit == 1 || (!bias && epi == EPI_F32))) {
-        // one workgroup per CU: worth it when the last round of tiles is nearly full (measured, gemm_probe: 224 tiles
-        // +13..29 %, 2368 tiles +15 %; 288 tiles -6 %, 48..128 tiles -40 %)
-        const int64_t t8 = ((T + 255) / 256) * ((N + 255) / 256) * ksplit;
-        const int64_t rounds = (t8 + 255) / 256;
-        if (use8p >= 2 || (T >= 256 && t8 >= 200 && t8 * 10 >= rounds * 256 * 8))
+        // one workgroup per CU: worth it when the last round of tiles is nearly full (gemm_8p_fill)
+        if (use8p >= 2 || gemm_8p_fill(T, N, K, ksplit) > 0)
             return launch_gemm_8p(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
     }
     static const int use256 = getenv("FL_GEMM_256") ? atoi(getenv("FL_GEMM_256")) : 1;
