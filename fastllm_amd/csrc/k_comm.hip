@@ -10,7 +10,7 @@
 //
 // Memory: the inbox and the flags live in one hipDeviceMallocUncached allocation per rank (peer
 // stores must not be hidden by the owner's L2), exported with hipIpcGetMemHandle and mapped by the
-// peers (comm.hip).  Two inbox halves alternate by epoch parity: a rank can run at most one
+// peers (comm.hip: comm_ipc_export / comm_connect_impl).  Two inbox halves alternate by epoch parity: a rank can run at most one
 // collective ahead of the slowest peer (it needs that peer's flag to finish), so the half it
 // overwrites is never still being read.  Epochs count collectives and live on the device, so a
 // captured decode graph replays with no argument update.

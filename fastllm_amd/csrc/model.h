@@ -174,6 +174,21 @@ int cache_create(Model *m, size_t max_seq, Cache **out);
 int comm_ipc_export(Model *m, void *handle_out);
 int comm_ipc_connect(Model *m, const void *handles);
 bool fused_all_reduce_ready(const Model *m);   // decode all-reduces ride in the GEMV epilogues (comm_ll.h)
+
+// shared by model.hip and comm.hip
+#define FL_NCCL(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { \
+    ::fl::set_error("RCCL error %s at %s:%d (%s)", ncclGetErrorString(r_), __FILE__, __LINE__, #expr); \
+    return FL_ERR_RCCL; } } while (0)
+int env_int(const char *name, int dflt);
+Launcher make_launcher(Model *m, Shard &sh);
+// comm.hip: inbox / LL region of one shard, its table entries, and the group-level steps
+int comm_alloc(Model *m, Shard &sh);
+void comm_set_entry(PeerComm &pc, int r, void *base);
+int comm_ll_publish(Model *m, Shard &sh);              // every entry is set: hand the fused all-reduce's table to the device
+int comm_bootstrap_over_rccl(Model *m);                // all-gather the handles through RCCL, connect, self-test, vote
+int comm_check(Model *m);                              // a kernel gave up waiting for a peer -> FL_ERR_RCCL
+// n floats in chunks of at most the inbox size; reduce: out = sum over ranks (in == out allowed); gather: out[r * out_stride + i] = in_r[i]
+int oneshot(Model *m, Shard &sh, bool gather, const float *in, float *out, int64_t n, int64_t out_stride, hipStream_t on = nullptr);
 // mode: 0 = logits to host, 1 = argmax token to host
 // device token-selection state for a LogitsProcessor::new(seed, Some(temperature), None); null: ArgMax
 SampleState make_sampler(const fl_sampling *sampling);

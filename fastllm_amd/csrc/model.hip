@@ -30,17 +30,9 @@ void set_error(const char *fmt, ...) {
 }
 const char *last_error() { return g_err; }
 
-#define FL_NCCL(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { \
-    ::fl::set_error("RCCL error %s at %s:%d (%s)", ncclGetErrorString(r_), __FILE__, __LINE__, #expr); \
-    return FL_ERR_RCCL; } } while (0)
 
-static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
-static int comm_alloc(Model *m, Shard &sh);
+int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
 struct PeerComm;
-static void comm_set_entry(PeerComm &pc, int r, void *base);
-static int comm_ll_publish(Model *m, Shard &sh);
-static int comm_bootstrap_over_rccl(Model *m);
-static int comm_check(Model *m);
 
 // ------------------------------------------------------------------------------- config
 int resolve_config(const fl_config *cfg, Dims *o) {
@@ -512,203 +504,6 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
 }
 
 
-// ------------------------------------------------------------------------------- one-shot collectives
-constexpr size_t kCommFlagBytes = 4096;
-static Launcher make_launcher(Model *m, Shard &sh);
-static int comm_connect_impl(Model *m, const void *handles);
-static int comm_export_impl(Shard &sh, void *handle_out);
-
-static int comm_alloc(Model *m, Shard &sh) {
-    PeerComm &pc = sh.pc;
-    FL_HIP(hipSetDevice(sh.device));
-    // a slot holds at least one rank's share of the logits, so the per-step gather is always a one-shot collective
-    pc.nmax = (std::max<int64_t>(std::max<int64_t>(env_int("FL_AR_INBOX_FLOATS", 65536), sh.Vs), 4) + 3) / 4 * 4;
-    pc.ll_off = (kCommFlagBytes + (size_t)2 * m->tp * pc.nmax * 4 + 255) & ~(size_t)255;
-    pc.bytes = pc.ll_off + (size_t)2 * m->tp * m->D.h * 8;
-    FL_HIP(hipExtMallocWithFlags(&pc.local, pc.bytes, hipDeviceMallocUncached));
-    FL_HIP(hipMemset(pc.local, 0, pc.bytes));
-    FL_HIP(hipMalloc((void **)&pc.epoch, 64));
-    FL_HIP(hipMemset(pc.epoch, 0, 64));
-    FL_HIP(hipMalloc((void **)&pc.ll_dev, sizeof(LLTable)));
-    FL_HIP(hipHostMalloc((void **)&pc.err, 64, hipHostMallocDefault));
-    *pc.err = 0;
-    pc.timeout_ticks = (long long)env_int("FL_AR_TIMEOUT_MS", 20000) * 100000LL;       // 100 MHz wall clock
-    FL_HIP(hipDeviceSynchronize());
-    m->hbm_bytes += (int64_t)pc.bytes;
-    return FL_OK;
-}
-
-static void comm_set_entry(PeerComm &pc, int r, void *base) {
-    pc.tab.flags[r] = (uint32_t *)base;
-    pc.tab.inbox[r] = (float *)((char *)base + kCommFlagBytes);
-    pc.ll.peer[r] = (uint64_t *)((char *)base + pc.ll_off);
-}
-
-// every entry of the table is set: hand the fused all-reduce's view of the group to the device
-static int comm_ll_publish(Model *m, Shard &sh) {
-    PeerComm &pc = sh.pc;
-    FL_HIP(hipSetDevice(sh.device));
-    pc.ll.epoch_ctr = pc.epoch; pc.ll.err = pc.err; pc.ll.timeout_ticks = pc.timeout_ticks;
-    pc.ll.rank = sh.rank; pc.ll.tp = m->tp; pc.ll.n = (int)m->D.h; pc.ll.slots = (int)(2 * m->D.L);
-    FL_HIP(hipMemcpy(pc.ll_dev, &pc.ll, sizeof(LLTable), hipMemcpyHostToDevice));
-    pc.ll_ok = true;
-    return FL_OK;
-}
-
-int comm_ipc_export(Model *m, void *handle_out) {
-    if (!m || !handle_out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
-    if (m->tp_mode != FL_TP_MULTI_PROCESS || m->tp < 2) FL_FAIL(FL_ERR_BAD_ARGUMENT, "peer inboxes exist in FL_TP_MULTI_PROCESS mode only");
-    return comm_export_impl(m->shards[0], handle_out);
-}
-
-static int comm_export_impl(Shard &sh, void *handle_out) {
-    FL_HIP(hipSetDevice(sh.device));
-    static_assert(sizeof(hipIpcMemHandle_t) <= FL_IPC_HANDLE_BYTES, "handle size");
-    hipIpcMemHandle_t h;
-    FL_HIP(hipIpcGetMemHandle(&h, sh.pc.local));
-    memset(handle_out, 0, FL_IPC_HANDLE_BYTES);
-    memcpy(handle_out, &h, sizeof h);
-    return FL_OK;
-}
-
-int comm_ipc_connect(Model *m, const void *handles) {
-    if (!m || !handles) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
-    if (m->tp_mode != FL_TP_MULTI_PROCESS || m->tp < 2) FL_FAIL(FL_ERR_BAD_ARGUMENT, "peer inboxes exist in FL_TP_MULTI_PROCESS mode only");
-    std::lock_guard<std::mutex> lock(m->mu);
-    return comm_connect_impl(m, handles);
-}
-
-static int comm_connect_impl(Model *m, const void *handles) {
-    Shard &sh = m->shards[0];
-    PeerComm &pc = sh.pc;
-    if (pc.connected) FL_FAIL(FL_ERR_BAD_ARGUMENT, "peer inboxes are already connected");
-    FL_HIP(hipSetDevice(sh.device));
-    for (int r = 0; r < m->tp; r++) {
-        if (r == sh.rank) { comm_set_entry(pc, r, pc.local); continue; }
-        hipIpcMemHandle_t h;
-        memcpy(&h, (const char *)handles + (size_t)r * FL_IPC_HANDLE_BYTES, sizeof h);
-        void *p = nullptr;
-        hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            for (void *&mp : pc.mapped) if (mp) { (void)hipIpcCloseMemHandle(mp); mp = nullptr; }
-            FL_FAIL(FL_ERR_HIP, "hipIpcOpenMemHandle of rank %d's inbox failed: %s", r, hipGetErrorString(e));
-        }
-        pc.mapped[r] = p;
-        comm_set_entry(pc, r, p);
-        hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, p) == hipSuccess) pc.shares_device = pc.shares_device || at.device == sh.device;
-        else (void)hipGetLastError();
-    }
-    pc.connected = true;
-    return comm_ll_publish(m, sh);
-}
-
-// n floats in chunks of at most nmax; reduce: out = sum over ranks (in == out allowed);
-// gather: out[r * out_stride + i] = in_r[i]
-static int oneshot(Model *m, Shard &sh, bool gather, const float *in, float *out, int64_t n, int64_t out_stride, hipStream_t on = nullptr) {
-    PeerComm &pc = sh.pc;
-    Launcher L = make_launcher(m, sh);
-    if (on) L.stream = on;
-    for (int64_t off = 0; off < n; off += pc.nmax) {
-        const int64_t c = std::min(pc.nmax, n - off);
-        FL_TRY(launch_oneshot(L, gather, in + off, out + off, pc.tab, sh.rank, m->tp, c, pc.nmax, out_stride, pc.epoch, pc.err, pc.timeout_ticks));
-    }
-    return FL_OK;
-}
-
-// Self-contained bootstrap when an RCCL communicator exists: all-gather the IPC handles through it,
-// map the peers, then prove the path on integer-valued data against ncclAllReduce.  Every decision
-// is agreed by all ranks (min over ranks), so either all use the one-shot path or none does.
-static int comm_bootstrap_over_rccl(Model *m) {
-    Shard &sh = m->shards[0];
-    PeerComm &pc = sh.pc;
-    const int tp = m->tp;
-    const bool verbose = env_int("FL_VERBOSE", 0) != 0;
-    FL_HIP(hipSetDevice(sh.device));
-    char *dbuf = nullptr;
-    const size_t test_n = 4096;
-    FL_HIP(hipMalloc((void **)&dbuf, (size_t)tp * FL_IPC_HANDLE_BYTES + 64 + 2 * test_n * 4));
-    std::vector<char> hbuf((size_t)tp * FL_IPC_HANDLE_BYTES);
-    int ok = comm_export_impl(sh, hbuf.data() + (size_t)sh.rank * FL_IPC_HANDLE_BYTES) == FL_OK;
-    auto agree = [&](int mine, int *all) -> int {
-        int *d = (int *)(dbuf + (size_t)tp * FL_IPC_HANDLE_BYTES);
-        FL_HIP(hipMemcpyAsync(d, &mine, 4, hipMemcpyHostToDevice, sh.stream));
-        FL_NCCL(ncclAllReduce(d, d, 1, ncclInt, ncclMin, sh.comm, sh.stream));
-        FL_HIP(hipMemcpyAsync(all, d, 4, hipMemcpyDeviceToHost, sh.stream));
-        FL_HIP(hipStreamSynchronize(sh.stream));
-        return FL_OK;
-    };
-    auto finish = [&](int rc) { (void)hipFree(dbuf); return rc; };
-    int all = 0;
-    if (agree(ok, &all) != FL_OK) return finish(FL_ERR_RCCL);
-    if (!all) return finish(FL_OK);
-    FL_HIP(hipMemcpyAsync(dbuf + (size_t)sh.rank * FL_IPC_HANDLE_BYTES, hbuf.data() + (size_t)sh.rank * FL_IPC_HANDLE_BYTES,
-                          FL_IPC_HANDLE_BYTES, hipMemcpyHostToDevice, sh.stream));
-    FL_NCCL(ncclAllGather(dbuf + (size_t)sh.rank * FL_IPC_HANDLE_BYTES, dbuf, FL_IPC_HANDLE_BYTES, ncclChar, sh.comm, sh.stream));
-    FL_HIP(hipMemcpyAsync(hbuf.data(), dbuf, hbuf.size(), hipMemcpyDeviceToHost, sh.stream));
-    FL_HIP(hipStreamSynchronize(sh.stream));
-    ok = comm_connect_impl(m, hbuf.data()) == FL_OK;
-    if (!ok && verbose) fprintf(stderr, "[fastllm_mi355x] rank %d: %s\n", sh.rank, last_error());
-    if (agree(ok, &all) != FL_OK) return finish(FL_ERR_RCCL);
-    if (all) {
-        // proof run: x_r[i] = (i % 251) + 1000 r  (exact in fp32 whatever the summation order)
-        float *a = (float *)(dbuf + (size_t)tp * FL_IPC_HANDLE_BYTES + 64), *b = a + test_n;
-        std::vector<float> x(test_n), ya(test_n), yb(test_n);
-        for (size_t i = 0; i < test_n; i++) x[i] = (float)(i % 251) + 1000.f * sh.rank;
-        FL_HIP(hipMemcpyAsync(a, x.data(), test_n * 4, hipMemcpyHostToDevice, sh.stream));
-        FL_HIP(hipMemcpyAsync(b, x.data(), test_n * 4, hipMemcpyHostToDevice, sh.stream));
-        const long long keep = pc.timeout_ticks;
-        pc.timeout_ticks = 200000000LL;              // 2 s: a path that does not work must fail fast here
-        // the exchange fused into the GEMV epilogues first (epoch counter still 0: it uses epoch 1, never seen again)
-        {
-            const size_t ll_n = std::min<size_t>(test_n, (size_t)m->D.h);
-            int ll_good = comm_ll_publish(m, sh) == FL_OK;
-            if (ll_good) {
-                Launcher L = make_launcher(m, sh);
-                ll_good = launch_ll_allreduce(L, pc.ll_dev, 1, a, a, (int64_t)ll_n) == FL_OK;
-                FL_HIP(hipMemcpyAsync(ya.data(), a, ll_n * 4, hipMemcpyDeviceToHost, sh.stream));
-                FL_HIP(hipStreamSynchronize(sh.stream));
-                ll_good = ll_good && *pc.err == 0;
-                for (size_t i = 0; i < ll_n && ll_good; i++) ll_good = ya[i] == (float)tp * (float)(i % 251) + 1000.f * (float)(tp * (tp - 1) / 2);
-                FL_HIP(hipMemcpyAsync(a, x.data(), test_n * 4, hipMemcpyHostToDevice, sh.stream));
-            }
-            int ll_all = 0;
-            if (agree(ll_good, &ll_all) != FL_OK) return finish(FL_ERR_RCCL);
-            if (!ll_good && verbose) fprintf(stderr, "[fastllm_mi355x] rank %d: fused all-reduce self-test failed (err 0x%x)\n", sh.rank, *pc.err);
-            *pc.err = 0;
-            pc.timeout_ticks = keep;
-            if (ll_all) { if (comm_ll_publish(m, sh) != FL_OK) return finish(FL_ERR_HIP); }    // with the real timeout
-            pc.ll_ok = ll_all != 0;
-            pc.timeout_ticks = 200000000LL;
-        }
-        int rc = oneshot(m, sh, false, a, a, (int64_t)test_n, 0);
-        pc.timeout_ticks = keep;
-        if (rc != FL_OK) return finish(rc);
-        FL_NCCL(ncclAllReduce(b, b, test_n, ncclFloat, ncclSum, sh.comm, sh.stream));
-        FL_HIP(hipMemcpyAsync(ya.data(), a, test_n * 4, hipMemcpyDeviceToHost, sh.stream));
-        FL_HIP(hipMemcpyAsync(yb.data(), b, test_n * 4, hipMemcpyDeviceToHost, sh.stream));
-        FL_HIP(hipStreamSynchronize(sh.stream));
-        ok = *pc.err == 0 && memcmp(ya.data(), yb.data(), test_n * 4) == 0;
-        if (!ok && verbose) fprintf(stderr, "[fastllm_mi355x] rank %d: one-shot all-reduce self-test failed (err 0x%x)\n", sh.rank, *pc.err);
-        if (agree(ok, &all) != FL_OK) return finish(FL_ERR_RCCL);
-    }
-    if (!all) {                                      // stay on RCCL; the epoch counters may differ now, so the path is closed for good
-        pc.connected = false;
-        pc.ll_ok = false;
-        *pc.err = 0;
-    }
-    if (verbose && sh.rank == 0)
-        fprintf(stderr, "[fastllm_mi355x] small collectives: %s%s\n", all ? "one-shot over peer-mapped HBM" : "RCCL", all && pc.ll_ok ? ", all-reduce fused into the GEMV epilogues" : "");
-    return finish(FL_OK);
-}
-
-static int comm_check(Model *m) {
-    for (auto &sh : m->shards)
-        if (sh.pc.err && *sh.pc.err) FL_FAIL(FL_ERR_RCCL, "one-shot collective gave up waiting for a peer (code 0x%x): the tensor-parallel group is broken", *sh.pc.err);
-    return FL_OK;
-}
-
 // ------------------------------------------------------------------------------- cache
 int cache_create(Model *m, size_t max_seq, Cache **out) {
     if (!m || !out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
@@ -799,7 +594,7 @@ SampleState make_sampler(const fl_sampling *sp) {
     return s;
 }
 
-static Launcher make_launcher(Model *m, Shard &sh) {
+Launcher make_launcher(Model *m, Shard &sh) {
     Launcher L; L.stream = sh.stream; L.prof = m->profiling ? &m->prof : nullptr; return L;
 }
 
@@ -878,28 +673,6 @@ static int gather_logits(Model *m) {
     return FL_OK;
 }
 
-// Decode step with the fused kernels: 5 launches per layer instead of 10.
-//   K1 gemv[norm1(+residual add, or embedding) -> qkv -> RoPE -> q buffer / KV cache slot]
-//   K2 attn_decode (+ in-launch split-S combine)      K3 gemv[o_proj] -> delta   (all-reduce)
-//   K4 gemv[norm2(+add) -> gate/up -> silu*up]        K5 gemv[down]   -> delta   (all-reduce)
-// and finally gemv[final norm -> lm_head].  The residual ping-pongs x_res <-> x_res2 because the
-// norm prologue of every workgroup reads x_in while workgroup 0 writes the updated residual.
-// In a tensor-parallel group whose LL regions are connected, K3 and K5 carry their all-reduce in the epilogue
-// (comm_ll.h): the layer stays at 5 launches.
-bool fused_all_reduce_ready(const Model *m) {
-    // 0: never; 1: when every rank has a GPU of its own (two full-chip GEMV grids that wait for each other's rows
-    // cannot both be resident on one card -- the same-device rehearsals); 2: regardless (tests with small grids)
-    const int allow = env_int("FL_TP_FUSED_AR", 1);
-    if (!allow || !m->fused_decode) return false;
-    if (allow < 2) for (auto &sh : m->shards) if (sh.pc.shares_device) return false;
-    const bool group_of_one = m->tp == 1 && m->shards[0].pc.connected;          // FL_DEBUG_RCCL_SELF: the bootstrap rehearsal
-    if (m->tp_mode != FL_TP_MULTI_PROCESS && m->tp_mode != FL_TP_SINGLE_PROCESS && !group_of_one) return false;   // emulated shards share one stream
-    for (auto &sh : m->shards) {
-        if (!sh.pc.connected || !sh.pc.ll_ok || sh.Vs > sh.pc.nmax) return false;   // the per-step logits gather must move the epoch counter
-        if (!gemv_supported(m->dtype, m->D.h, sh.Hs * m->D.d) || !gemv_supported(m->dtype, m->D.h, sh.Ip)) return false;
-    }
-    return true;
-}
 static bool fused_all_reduce(Model *m, Cache *c) { return !c->fuse_oproj && fused_all_reduce_ready(m); }
 
 static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
