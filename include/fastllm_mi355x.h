@@ -139,7 +139,9 @@ int fl_model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n_ten
  * are one-shot pushes into inboxes that every rank maps from every peer's HBM over xGMI (new
  * capability; the reference is single-device, README.md:149).  A model created with a unique_id
  * wires them itself over RCCL.  Otherwise: every rank exports its inbox handle, the host all-gathers
- * the tp handles out of band (rank order) and every rank connects before its first forward. */
+ * the tp handles out of band (rank order) and every rank connects before its first forward.
+ * Connected groups with one GPU per rank exchange the all-reduces inside the o_proj / down_proj GEMV epilogues
+ * (fl_model_info.fused_all_reduce); waits for a peer are bounded (FL_AR_TIMEOUT_MS) and end in FL_ERR_RCCL. */
 #define FL_IPC_HANDLE_BYTES 64
 int fl_comm_ipc_export(fl_model *m, void *handle_out /* FL_IPC_HANDLE_BYTES */);
 int fl_comm_ipc_connect(fl_model *m, const void *handles /* tp_size * FL_IPC_HANDLE_BYTES */);
