@@ -592,9 +592,11 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
     // key split (two waves per head and token sub-tile) while the workgroup stays within 8 waves: short prompts
     static const int pf_ksplit = getenv("FL_ATTN_PF_KSPLIT") ? atoi(getenv("FL_ATTN_PF_KSPLIT")) : 2;
     // (four waves per query tile measured slower than two: Mistral T = 512 23 vs 18 us per layer, T = 768 45 vs 33)
-    const int ks = (pf_ksplit >= 2 && G * TT * 2 <= 16) ? 2 : 1;
+    // ... while the workgroup stays within 16 waves and its merge slabs within the 64 KB of LDS a launch gets by default
+    const size_t slabs = (size_t)G * TT * (16 * d + 32) * 4;
+    const int ks = (pf_ksplit >= 2 && G * TT * 2 <= 16 && slabs <= 64 * 1024) ? 2 : 1;
     if (ks == 2) { nst = 2; block = dim3((unsigned)(G * TT * 2 * 64)); }
-    const size_t lds = std::max((size_t)nst * ks * (size_t)(2 * 32 * d * 2), ks == 2 ? (size_t)G * TT * (16 * d + 32) * 4 : (size_t)0);
+    const size_t lds = std::max((size_t)nst * ks * (size_t)(2 * 32 * d * 2), ks == 2 ? slabs : (size_t)0);
     double flops = 2.0 * (double)T * T * H * d;
     if (d == 128)
         return L.launch(KC_ATTN_PREFILL, 0, flops, attn_prefill_mfma_kernel<128>, grid, block, lds, (const bf16_t *)q,
