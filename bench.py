@@ -232,6 +232,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, t_prefill = float(tt[0]), float(tt[1])
     assert len(toks) == K
+    # every rank of a tensor-parallel group must have produced the same tokens (the sums run in rank order everywhere)
+    my_crc = zlib.crc32(np.asarray(toks, dtype=np.uint32).tobytes())
+    ranks_agree = True
+    if world > 1:
+        crcs = [None] * world
+        dist.all_gather_object(crcs, my_crc)
+        ranks_agree = all(c == crcs[0] for c in crcs)
+        if not ranks_agree:
+            log("WARNING: ranks disagree on the generated tokens:", crcs)
 
     # ---- the reference's loop shape for comparison: one fl_forward per token, V fp32 logits copied to the host
     #      and argmax there (mod.rs:421-452): PCIe-inclusive, never the headline value ----
@@ -314,7 +323,7 @@ def main():
             "cpu_baseline": cpu,
             "e2e_hbm": {"bytes_per_token": b_tok, "achieved_GBps": round(tok_s * b_tok / world / 1e9, 1),
                         "frac_of_8TBps_per_gpu": round(tok_s * b_tok / world / 8e12, 4)},
-            "tokens_crc32": zlib.crc32(np.asarray(toks, dtype=np.uint32).tobytes()),
+            "tokens_crc32": my_crc, "ranks_agree": ranks_agree,
             "batched_decode": batch8,
             "host_loop": {"tokens_per_sec": round(1.0 / t_host_loop, 2),
                           "note": "fl_forward per token: logits (V fp32) to the host + host argmax, PCIe-inclusive"},
