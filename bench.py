@@ -163,23 +163,66 @@ def main():
     torch.cuda.synchronize()
     log("synthetic weights in HBM: %.1f GB in %.1fs" % (sum(v.numel() for v in wts.values()) * 2 / 1e9, time.perf_counter() - t0))
 
-    uid = None
-    if world > 1 and not same_device:
-        box = [fa.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        uid = box[0]
-    t0 = time.perf_counter()
-    model = fa.Model(cfg, as_fl_tensors(wts, local_rank), dtype="bf16",
-                     tp_mode=binding.TP_MULTI_PROCESS if world > 1 else binding.TP_NONE, tp_size=world, tp_rank=rank,
-                     device_ids=[local_rank], unique_id=uid)
+    def build_model():
+        uid = None
+        if world > 1 and not same_device:
+            box = [fa.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
+        mdl = fa.Model(cfg, as_fl_tensors(wts, local_rank), dtype="bf16",
+                       tp_mode=binding.TP_MULTI_PROCESS if world > 1 else binding.TP_NONE, tp_size=world, tp_rank=rank,
+                       device_ids=[local_rank], unique_id=uid)
+        if same_device:
+            hs = [None] * world
+            dist.all_gather_object(hs, mdl.ipc_export())
+            mdl.ipc_connect(hs)
+        return mdl
+
     if same_device and os.environ.get("FL_BENCH_SAME_DEVICE_FUSED", "0") == "1":      # (FL_TP_FUSED_AR=0 on top: same grids, kernel form)
         fa.tune("gemv_blocks", 192 // world)
         fa.tune("gemv_waves", 4)
-    if same_device:
-        hs = [None] * world
-        dist.all_gather_object(hs, model.ipc_export())
-        model.ipc_connect(hs)
-    log("model built in %.1fs" % (time.perf_counter() - t0))
+    t0 = time.perf_counter()
+    # A tensor-parallel group is checked before it is measured: one overlapped prefill and a few decode steps; if any
+    # rank fails (a bounded wait gave up, an RCCL error) ALL ranks rebuild the model one level more conservative:
+    #   0 as configured;  1 all-reduces as kernels of their own, prefill all-reduces on the compute stream;  2 RCCL only.
+    # The level that ran is reported in the JSON line (config.tp_fallback_level).
+    os.environ.setdefault("FL_AR_TIMEOUT_MS", "5000")
+    fallback_level, model = 0, None
+    for level in range(3):
+        if level >= 1:
+            os.environ["FL_TP_FUSED_AR"] = "0"
+            os.environ["FL_TP_OVERLAP"] = "0"
+        if level >= 2:
+            os.environ["FL_ONESHOT"] = "0"
+        model = build_model()
+        if world == 1:
+            break
+        failed, hc = 0, None
+        try:
+            hp = np.random.RandomState(7).randint(0, cfg["vocab_size"], size=max(T, 8)).astype(np.uint32)
+            hc = model.new_cache(len(hp) + 16)
+            hf = model.forward_argmax(hc, hp, 0)
+            model.decode_greedy(hc, hf, len(hp), 4)
+            model.synchronize()
+        except Exception as e:                                                # noqa: the point is to survive it
+            failed = 1
+            log("rank %d: tensor-parallel health check failed at level %d: %r" % (rank, level, e))
+        finally:
+            if hc is not None:
+                hc.close()
+        ft = torch.tensor([failed], dtype=torch.int32)
+        dist.all_reduce(ft, op=dist.ReduceOp.MAX)
+        if int(ft[0]) == 0:
+            fallback_level = level
+            break
+        if level == 2:
+            raise SystemExit("tensor-parallel group does not work even on the most conservative path")
+        try:
+            model.close()
+        except Exception as e:
+            log("rank %d: closing the failed model: %r" % (rank, e))
+        model = None
+    log("model built in %.1fs (tensor-parallel fallback level %d)" % (time.perf_counter() - t0, fallback_level))
     info = model.info()
     collectives = {0: None, 1: "rccl", 2: "one-shot peer inboxes (k_comm.hip) + rccl for prefill", 3: "local"}[info.small_collectives]
     if same_device:
@@ -318,7 +361,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "%s bf16 greedy decode, %d-token prompt, %d generated tokens, batch 1, TP=%d"
                                    % (args.model, T, K, world), "kv_len": "%d..%d" % (T, T + K),
-                       "parallelism": "tp%d" % world, "collectives": collectives},
+                       "parallelism": "tp%d" % world, "collectives": collectives, "tp_fallback_level": fallback_level},
             "roofline": roof,
             "cpu_baseline": cpu,
             "e2e_hbm": {"bytes_per_token": b_tok, "achieved_GBps": round(tok_s * b_tok / world / 1e9, 1),

@@ -47,7 +47,7 @@ void comm_set_entry(PeerComm &pc, int r, void *base) {
 int comm_ll_publish(Model *m, Shard &sh) {
     PeerComm &pc = sh.pc;
     FL_HIP(hipSetDevice(sh.device));
-    pc.ll.epoch_ctr = pc.epoch; pc.ll.err = pc.err; pc.ll.timeout_ticks = pc.timeout_ticks;
+    pc.ll.epoch_ctr = pc.epoch; pc.ll.err = pc.err; pc.ll.abort_flag = pc.epoch + 8; pc.ll.timeout_ticks = pc.timeout_ticks;
     pc.ll.rank = sh.rank; pc.ll.tp = m->tp; pc.ll.n = (int)m->D.h; pc.ll.slots = (int)(2 * m->D.L);
     FL_HIP(hipMemcpy(pc.ll_dev, &pc.ll, sizeof(LLTable), hipMemcpyHostToDevice));
     pc.ll_ok = true;
@@ -111,7 +111,7 @@ int oneshot(Model *m, Shard &sh, bool gather, const float *in, float *out, int64
     if (on) L.stream = on;
     for (int64_t off = 0; off < n; off += pc.nmax) {
         const int64_t c = std::min(pc.nmax, n - off);
-        FL_TRY(launch_oneshot(L, gather, in + off, out + off, pc.tab, sh.rank, m->tp, c, pc.nmax, out_stride, pc.epoch, pc.err, pc.timeout_ticks));
+        FL_TRY(launch_oneshot(L, gather, in + off, out + off, pc.tab, sh.rank, m->tp, c, pc.nmax, out_stride, pc.epoch, pc.err, pc.timeout_ticks, pc.epoch + 8));
     }
     return FL_OK;
 }
@@ -176,6 +176,8 @@ int comm_bootstrap_over_rccl(Model *m) {
             if (agree(ll_good, &ll_all) != FL_OK) return finish(FL_ERR_RCCL);
             if (!ll_good && verbose) fprintf(stderr, "[fastllm_mi355x] rank %d: fused all-reduce self-test failed (err 0x%x)\n", sh.rank, *pc.err);
             *pc.err = 0;
+            FL_HIP(hipMemsetAsync(pc.epoch + 8, 0, 4, sh.stream));           // the abort word a failed wait left behind
+            FL_HIP(hipStreamSynchronize(sh.stream));
             pc.timeout_ticks = keep;
             if (ll_all) { if (comm_ll_publish(m, sh) != FL_OK) return finish(FL_ERR_HIP); }    // with the real timeout
             pc.ll_ok = ll_all != 0;
@@ -196,6 +198,8 @@ int comm_bootstrap_over_rccl(Model *m) {
         pc.connected = false;
         pc.ll_ok = false;
         *pc.err = 0;
+        FL_HIP(hipMemsetAsync(pc.epoch + 8, 0, 4, sh.stream));
+        FL_HIP(hipStreamSynchronize(sh.stream));
     }
     if (verbose && sh.rank == 0)
         fprintf(stderr, "[fastllm_mi355x] small collectives: %s%s\n", all ? "one-shot over peer-mapped HBM" : "RCCL", all && pc.ll_ok ? ", all-reduce fused into the GEMV epilogues" : "");

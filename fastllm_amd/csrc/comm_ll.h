@@ -40,7 +40,14 @@ __device__ inline void ll_allreduce_rows(const LLTable *__restrict__ t, int slot
             uint64_t w = __hip_atomic_load(src + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             while (alive && (uint32_t)(w >> 32) != e) {
                 __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t0 > t->timeout_ticks) { if (*t->err == 0) *t->err = 0xA11E0000u | (uint32_t)rank; alive = false; }   // bounded: a dead peer must not hang the GPU
+                const long long waited = wall_clock64() - t0;
+                // bounded: a dead peer must not hang the GPU; once one wait of this rank has given up, the others of the
+                // broken step follow after 1 ms instead of the full bound each
+                if (waited > t->timeout_ticks || (waited > 100000 && *t->abort_flag)) {
+                    if (*t->err == 0) *t->err = 0xA11E0000u | (uint32_t)rank;
+                    *t->abort_flag = 1;
+                    alive = false;
+                }
                 w = __hip_atomic_load(src + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             got[r] = __uint_as_float((uint32_t)w);

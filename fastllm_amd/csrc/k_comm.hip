@@ -22,7 +22,7 @@ namespace fl {
 template <bool GATHER>
 __global__ __launch_bounds__(1024) void oneshot_kernel(const float *__restrict__ in, float *__restrict__ out, CommTable tab,
                                                        int rank, int tp, int n, int nmax, long long out_stride, uint32_t *__restrict__ epoch_ctr,
-                                                       uint32_t *__restrict__ err, long long timeout_ticks) {
+                                                       uint32_t *__restrict__ err, long long timeout_ticks, uint32_t *__restrict__ abort_flag) {
     __shared__ uint32_t s_bad;
     const int tid = threadIdx.x;
     const uint32_t e = *epoch_ctr + 1;
@@ -51,13 +51,14 @@ __global__ __launch_bounds__(1024) void oneshot_kernel(const float *__restrict__
         const long long t0 = wall_clock64();
         while ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
             __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t0 > timeout_ticks) { s_bad = 1; break; }
+            const long long waited = wall_clock64() - t0;
+            if (waited > timeout_ticks || (waited > 100000 && abort_flag && *abort_flag)) { s_bad = 1; break; }   // (1 ms once a wait has given up)
         }
     }
     __syncthreads();
     __threadfence_system();                       // acquire: the slots are read only after all tp flags were seen
     if (s_bad) {                                  // give up: report, do not touch `out`
-        if (tid == 0) { if (*err == 0) *err = 0xA11D0000u | (uint32_t)rank; *epoch_ctr = e; }      // the first report stays
+        if (tid == 0) { if (*err == 0) *err = 0xA11D0000u | (uint32_t)rank; if (abort_flag) *abort_flag = 1; *epoch_ctr = e; }      // the first report stays
         return;
     }
     const float *mine = tab.inbox[rank] + half;
@@ -91,15 +92,16 @@ __global__ __launch_bounds__(1024) void oneshot_kernel(const float *__restrict__
 // thread reads its elements of `in` before any write of `out`, and writes only its own elements).
 // all-gather: out[r*out_stride + i] = in_r[i].
 int launch_oneshot(Launcher &L, bool gather, const float *in, float *out, const CommTable &tab, int rank, int tp,
-                   int64_t n, int64_t nmax, int64_t out_stride, uint32_t *epoch_ctr, uint32_t *err, long long timeout_ticks) {
+                   int64_t n, int64_t nmax, int64_t out_stride, uint32_t *epoch_ctr, uint32_t *err, long long timeout_ticks,
+                   uint32_t *abort_flag) {
     if (n <= 0 || n > nmax || tp < 1 || tp > FL_MAX_TP) FL_FAIL(FL_ERR_BAD_ARGUMENT, "one-shot collective: bad size %lld (max %lld), tp %d", (long long)n, (long long)nmax, tp);
     const double bytes = (double)n * 4 * (2.0 * tp + 1);
     L.tag = gather ? "allgather" : "allreduce";
     int rc;
     if (gather)
-        rc = L.launch(KC_COMM, bytes, 0, oneshot_kernel<true>, dim3(1), dim3(1024), 0, in, out, tab, rank, tp, (int)n, (int)nmax, (long long)out_stride, epoch_ctr, err, timeout_ticks);
+        rc = L.launch(KC_COMM, bytes, 0, oneshot_kernel<true>, dim3(1), dim3(1024), 0, in, out, tab, rank, tp, (int)n, (int)nmax, (long long)out_stride, epoch_ctr, err, timeout_ticks, abort_flag);
     else
-        rc = L.launch(KC_COMM, bytes, 0, oneshot_kernel<false>, dim3(1), dim3(1024), 0, in, out, tab, rank, tp, (int)n, (int)nmax, (long long)out_stride, epoch_ctr, err, timeout_ticks);
+        rc = L.launch(KC_COMM, bytes, 0, oneshot_kernel<false>, dim3(1), dim3(1024), 0, in, out, tab, rank, tp, (int)n, (int)nmax, (long long)out_stride, epoch_ctr, err, timeout_ticks, abort_flag);
     L.tag = "";
     return rc;
 }

@@ -167,7 +167,8 @@ constexpr int FL_MAX_TP = 8;
 // (own allocation for r == rank, hipIpcOpenMemHandle / peer pointer otherwise).
 struct CommTable { float *inbox[FL_MAX_TP]; uint32_t *flags[FL_MAX_TP]; };
 int launch_oneshot(Launcher &L, bool gather, const float *in, float *out, const CommTable &tab, int rank, int tp,
-                   int64_t n, int64_t nmax, int64_t out_stride, uint32_t *epoch_ctr, uint32_t *err, long long timeout_ticks);
+                   int64_t n, int64_t nmax, int64_t out_stride, uint32_t *epoch_ctr, uint32_t *err, long long timeout_ticks,
+                   uint32_t *abort_flag = nullptr);
 
 // All-reduce fused into the epilogue of a row-parallel decode GEMV ("LL" protocol: a value and the epoch that
 // validates it travel in ONE 8-byte store, so there is no fence, no flag round and no separate kernel).  Every
@@ -179,6 +180,7 @@ struct LLTable {
     uint64_t *peer[FL_MAX_TP];      // rank r's LL region as mapped here
     const uint32_t *epoch_ctr;      // the one-shot collectives' device counter
     uint32_t *err;                  // pinned host word
+    uint32_t *abort_flag;           // device word, set with err: later waits of a broken step give up after ~1 ms
     long long timeout_ticks;
     int rank, tp, n, slots;
 };

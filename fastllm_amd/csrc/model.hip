@@ -852,8 +852,7 @@ static int enqueue_prefill_tp_overlap(Model *m, Cache *c, int64_t T) {
 // cache must already be set on the device.  ids_dev == null: the single token comes from the state.
 static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_scratch, int64_t len_hint) {
     if (T == 1 && !pre && !ids_in_scratch && m->fused_decode) return enqueue_decode_fused(m, c, len_hint);
-    static const int tp_overlap = env_int("FL_TP_OVERLAP", 1);
-    if (pre && ids_in_scratch && tp_overlap && m->tp > 1 && T >= env_int("FL_TP_OVERLAP_MIN_T", 512) && !m->profiling &&
+    if (pre && ids_in_scratch && m->tp > 1 && env_int("FL_TP_OVERLAP", 1) && T >= env_int("FL_TP_OVERLAP_MIN_T", 512) && !m->profiling &&
         (m->tp_mode == FL_TP_MULTI_PROCESS || m->tp_mode == FL_TP_SINGLE_PROCESS))
         return enqueue_prefill_tp_overlap(m, c, T);
     const Dims &D = m->D;
