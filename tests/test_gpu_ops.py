@@ -33,7 +33,12 @@ def _ref(x, w, bias, epi):
 SHAPES = [(1, 512, 256), (1, 6144, 4096), (1, 300, 384), (1, 4096, 14336), (1, 2, 8), (1, 33, 1032),
           (5, 512, 256), (128, 256, 512), (130, 384, 448), (257, 1000, 1024), (7, 96, 40), (512, 512, 4096), (300, 1024, 2048), (512, 4096, 4096), (129, 2048, 5632),
           (1030, 26000, 256), (520, 44000, 192), (2050, 16400, 128),   # 256x128 three-stage kernel (>= 1024 tiles)
-          (64, 136, 72)]
+          (64, 136, 72),
+          # decode GEMV with a partial last 64-lane chunk after 0..3 full ones (tensor-parallel K slices: Mistral down_proj
+          # at tp 8, Qwen2 down_proj / o_proj at tp 4) and K below one chunk row
+          (1, 4096, 1792), (1, 3584, 4736), (1, 3584, 896), (1, 256, 2568), (1, 64, 520), (1, 40, 24),
+          # two row tiles whose 256x128 grid with K slices is exactly one round of the chip (op_linear allows 4 slabs)
+          (512, 4096, 14336), (500, 4096, 4096)]
 
 
 @pytest.mark.parametrize("T,N,K", SHAPES)
