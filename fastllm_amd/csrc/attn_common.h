@@ -7,9 +7,29 @@
 
 namespace fl {
 
+// agent-scope write-through stores (global_store_dword / dwordx2 ... sc1): visible to every XCD once the storing wave's
+// vmcnt has drained, no L2 write-back fence
+__device__ inline void st_sc1(float *p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void st_sc1_x4(float *p, float4v v) {                       // p 16-byte aligned (one fabric write, not two)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ inline void st_sc1_pair(float *p, float a, float b) {              // p 8-byte aligned
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// floats of LDS a decode-attention workgroup needs: its NW wave slabs, or -- in the workgroup that combines the splits --
+// the (m, l) of up to 64 splits plus one 5-float partial per thread
+template <int D, int GMAX, int NW>
+constexpr int decode_lds_floats() {
+    return NW * GMAX * (D + 2) > 2 * GMAX * 64 + 5 * NW * 64 ? NW * GMAX * (D + 2) : 2 * GMAX * 64 + 5 * NW * 64;
+}
+
 // combine the NW wave slabs in LDS for (head g, 4 d-elements at j4): returns M, L and O[4] (unnormalised)
 template <int D, int GMAX, int NW>
-__device__ inline void combine_lds(const float *lds, int g, int j4, float &M, float &L, float (&O)[4]) {
+__device__ __forceinline__ void combine_lds(const float *lds, int g, int j4, float &M, float &L, float (&O)[4]) {
     constexpr int STR = D + 2;
     M = -INFINITY;
 #pragma unroll
@@ -34,7 +54,7 @@ __device__ inline void combine_lds(const float *lds, int g, int j4, float &M, fl
 // arriver, so a captured graph replays without a memset node.
 // Returns true in the workgroup that wrote the final output of its heads.
 template <typename CT, int D, int GMAX, int NW>
-__device__ inline bool decode_tail(float *lds, int *is_last, int G, int hq0, int ticket_idx, int split, int nsplit,
+__device__ __forceinline__ bool decode_tail(float *lds, int *is_last, int G, int hq0, int ticket_idx, int split, int nsplit,
                                    float *__restrict__ part_m, float *__restrict__ part_l, float *__restrict__ part_o,
                                    unsigned *__restrict__ counters, CT *__restrict__ out) {
     if (nsplit == 1) {
@@ -48,19 +68,30 @@ __device__ inline bool decode_tail(float *lds, int *is_last, int G, int hq0, int
         }
         return true;
     }
+    const bool few = nsplit <= 8;
     for (int e = threadIdx.x; e < G * (D / 4); e += NW * 64) {
         const int g = e / (D / 4), j4 = (e % (D / 4)) * 4;
         float M, L, O[4];
         combine_lds<D, GMAX, NW>(lds, g, j4, M, L, O);
         const size_t idx = (size_t)(hq0 + g) * nsplit + split;
-        *reinterpret_cast<float4v *>(part_o + idx * D + j4) = float4v{O[0], O[1], O[2], O[3]};
-        if (j4 == 0) { part_m[idx] = M; part_l[idx] = L; }
+        // write-through (sc1) stores: no release fence is needed before the ticket (cdna guide Guideline 16, R1 store
+        // forms).  The fence is a write-back of the XCD's whole L2; one per split workgroup made a long context's
+        // attention (512 workgroups at S = 16 384) wait on 512 of them.
+        if (few) {                                   // a handful of splits: plain stores + one release fence is the cheaper form
+            *reinterpret_cast<float4v *>(part_o + idx * D + j4) = float4v{O[0], O[1], O[2], O[3]};
+            if (j4 == 0) { part_m[idx] = M; part_l[idx] = L; }
+        } else {
+            st_sc1_x4(part_o + idx * D + j4, float4v{O[0], O[1], O[2], O[3]});
+            if (j4 == 0) { st_sc1(part_m + idx, M); st_sc1(part_l + idx, L); }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (few) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         unsigned *cnt = counters + ticket_idx;
         const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = t == (unsigned)nsplit - 1;
@@ -81,14 +112,25 @@ __device__ inline bool decode_tail(float *lds, int *is_last, int G, int hq0, int
         lm[g * nsplit + sp] = part_m[idx]; ll[g * nsplit + sp] = part_l[idx];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < G * (D / 4); e += NW * 64) {
-        const int g = e / (D / 4), j4 = (e % (D / 4)) * 4;
-        const size_t hb = (size_t)(hq0 + g) * nsplit;
-        float M = -INFINITY;
+    // Long contexts have up to 64 splits and every partial o row is one dependent trip to L2: a thread that walks
+    // them four at a time spends ~0.5 us per split (S = 16 384: 43 us per layer, three quarters of it here).  So the
+    // (head, 4-d) slots are spread over ALL threads -- `parts` threads per slot take the splits round-robin, eight
+    // loads in flight each -- and the parts meet in LDS.  Fixed order (part 0, 1, ...), so results stay reproducible.
+    const int slots = G * (D / 4), nthr = NW * 64;
+    int parts = 1;
+    while (parts * 2 * slots <= nthr && parts * 2 * 8 <= nsplit) parts *= 2;      // (a handful of splits: one pass, no LDS round)
+    float *red = ll + GMAX * nsplit;                                  // [parts][slots][5] floats behind lm / ll
+    const int slot = threadIdx.x % slots, part = threadIdx.x / slots;
+    const bool active = threadIdx.x < parts * slots;
+    const int g = slot / (D / 4), j4 = (slot % (D / 4)) * 4;
+    float M = -INFINITY;
+    if (active)
         for (int sp = 0; sp < nsplit; sp++) M = fmaxf(M, lm[g * nsplit + sp]);
+    if (active) {
+        const size_t hb = (size_t)(hq0 + g) * nsplit;
         float L = 0.f, O[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int sp = 0; sp < nsplit; sp++) {
+#pragma unroll 8
+        for (int sp = part; sp < nsplit; sp += parts) {
             const float mm = lm[g * nsplit + sp];
             const float w = mm == -INFINITY ? 0.f : __expf(mm - M);
             L += ll[g * nsplit + sp] * w;
@@ -96,9 +138,27 @@ __device__ inline bool decode_tail(float *lds, int *is_last, int G, int hq0, int
 #pragma unroll
             for (int j = 0; j < 4; j++) O[j] += o4[j] * w;
         }
-        const float inv = 1.0f / L;
+        if (parts > 1) {
+            float *r = red + ((size_t)part * slots + slot) * 5;
+            r[0] = L; r[1] = O[0]; r[2] = O[1]; r[3] = O[2]; r[4] = O[3];
+        } else {
+            const float inv = 1.0f / L;
 #pragma unroll
-        for (int j = 0; j < 4; j++) elem<CT>::st(out + (size_t)(hq0 + g) * D + j4 + j, O[j] * inv);
+            for (int j = 0; j < 4; j++) elem<CT>::st(out + (size_t)(hq0 + g) * D + j4 + j, O[j] * inv);
+        }
+    }
+    if (parts > 1) {
+        __syncthreads();
+        if (threadIdx.x < slots) {
+            float L = 0.f, O[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int pt = 0; pt < parts; pt++) {
+                const float *r = red + ((size_t)pt * slots + slot) * 5;
+                L += r[0]; O[0] += r[1]; O[1] += r[2]; O[2] += r[3]; O[3] += r[4];
+            }
+            const float inv = 1.0f / L;
+#pragma unroll
+            for (int j = 0; j < 4; j++) elem<CT>::st(out + (size_t)(hq0 + g) * D + j4 + j, O[j] * inv);
+        }
     }
     return true;
 }

@@ -50,7 +50,7 @@ struct LdsKV {
 
 // One 32-key step.  Column q sees key k iff  k < pre_hi  ||  (lo_q <= k && k < hi_q).
 template <int D, typename KV>
-__device__ inline void attn_tile(MfmaAttnState<D> &s, const bf16x8 (&qf)[D / 32], const KV &kv, int kbase, int pre_hi,
+__device__ __forceinline__ void attn_tile(MfmaAttnState<D> &s, const bf16x8 (&qf)[D / 32], const KV &kv, int kbase, int pre_hi,
                                  int lo_q, int hi_q, float scale, int lane) {
     const int g4 = lane >> 4;
     float4v s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
@@ -118,7 +118,7 @@ struct RegKV {
 
 // wave slab -> LDS in the shared format [wave][head][o[D], m, l] (attn_common.h)
 template <int D, int GMAX>
-__device__ inline void mfma_state_to_lds(const MfmaAttnState<D> &s, float *lds, int wave, int G, int lane) {
+__device__ __forceinline__ void mfma_state_to_lds(const MfmaAttnState<D> &s, float *lds, int wave, int G, int lane) {
     const int i = lane & 15, g4 = lane >> 4;
     float lt = s.l;
     lt += __shfl_xor(lt, 16, 64);

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const CT *__restri
                                                               float *__restrict__ part_o, unsigned *__restrict__ counters,
                                                               CT *__restrict__ out, int H, int Hkv, int max_seq,
                                                               float scale, int nsplit) {
-    __shared__ float lds[NW * GMAX * (D + 2)];
+    __shared__ float lds[decode_lds_floats<D, GMAX, NW>()];
     __shared__ int is_last;
     constexpr int LPK = D / 8, KPI = 64 / LPK, UNR = 2;
     const int hk = blockIdx.x, split = blockIdx.y;

@@ -29,7 +29,7 @@ namespace fl {
 
 // ------------------------------------------------------------------------------- decode
 template <int D, int GMAX, int NW>
-__device__ inline void attn_decode_mfma_body(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
+__device__ __forceinline__ void attn_decode_mfma_body(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
                                              const bf16_t *__restrict__ vT, const StepState *__restrict__ st,
                                              float *__restrict__ part_m, float *__restrict__ part_l,
                                              float *__restrict__ part_o, unsigned *__restrict__ counters,
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const bf16_t 
                                                                float *__restrict__ part_o, unsigned *__restrict__ counters,
                                                                bf16_t *__restrict__ out, int H, int Hkv, int seq_alloc,
                                                                float scale, int nsplit) {
-    __shared__ float lds[NW * GMAX * (D + 2)];
+    __shared__ float lds[decode_lds_floats<D, GMAX, NW>()];
     __shared__ int is_last;
     attn_decode_mfma_body<D, GMAX, NW>(q, kc, vT, st, part_m, part_l, part_o, counters, out, H, Hkv, seq_alloc, scale, nsplit, lds, &is_last);
 }
@@ -84,7 +84,7 @@ template <int D, int GMAX, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_batch_kernel(const bf16_t *__restrict__ q, const SeqRef *__restrict__ seqs,
                                                                      size_t kv_layer_off, bf16_t *__restrict__ out, int H, int Hkv,
                                                                      float scale, int nsplit_cap) {
-    __shared__ float lds[NW * GMAX * (D + 2)];
+    __shared__ float lds[decode_lds_floats<D, GMAX, NW>()];
     __shared__ int is_last;
     SeqRef sq = seqs[blockIdx.z];
     sq.nsplit = min(sq.nsplit, nsplit_cap);                         // a batch already fills the chip: fewer, longer splits
