@@ -576,7 +576,7 @@ __device__ inline int sample_all(const float *__restrict__ logits, int V, Sample
     return min(*count, V - 1);
 }
 
-__device__ inline void select_advance_body(const float *__restrict__ logits, int V, StepState *__restrict__ st,
+__device__ __forceinline__ void select_advance_body(const float *__restrict__ logits, int V, StepState *__restrict__ st,
                                            SampleState *__restrict__ ss, float *__restrict__ scratch,
                                            uint32_t *__restrict__ out_tokens, int advance, unsigned char *lds) {
     __shared__ float bv[16], bcast[2];
