@@ -48,10 +48,12 @@ __device__ __forceinline__ void combine_lds(const float *lds, int g, int j4, flo
 // Tail of a decode-attention workgroup once its NW wave slabs are in LDS (and a barrier has passed).
 // nsplit == 1: normalise and write the output.  Otherwise publish this split's (m, l, o) slab and
 // let the workgroup that draws the last ticket of its (kv head, q-group) combine all splits:
-//   plain stores -> per-wave vmcnt(0) -> barrier -> agent-scope release -> vmcnt(0) -> ticket;
-//   last arriver: agent-scope acquire -> barrier -> plain loads
-// (cdna guide Guideline 16, counter form; placement-independent).  The ticket word is reset by the last
-// arriver, so a captured graph replays without a memset node.
+//   up to 8 splits:  plain stores -> per-wave vmcnt(0) -> barrier -> agent-scope release -> vmcnt(0) -> ticket;
+//   more splits:     write-through (sc1) stores -> per-wave vmcnt(0) -> barrier -> ticket   (no release: that fence
+//                    writes back the XCD's whole L2, and hundreds of split workgroups each paid for one);
+//   last arriver:    agent-scope acquire -> barrier -> plain loads, splits spread over all threads
+// (cdna guide Guideline 16, counter form and R1 store forms; placement-independent).  The ticket word is reset by
+// the last arriver, so a captured graph replays without a memset node.
 // Returns true in the workgroup that wrote the final output of its heads.
 template <typename CT, int D, int GMAX, int NW>
 __device__ __forceinline__ bool decode_tail(float *lds, int *is_last, int G, int hq0, int ticket_idx, int split, int nsplit,
