@@ -56,9 +56,36 @@ __device__ __forceinline__ void attn_decode_mfma_body(const bf16_t *__restrict__
     MfmaAttnState<D> s; s.init();
     const bf16_t *kb = kc + (size_t)hk * seq_alloc * D;
     const bf16_t *vb = vT + (size_t)hk * D * seq_alloc;
-    for (int kbase = lo + 32 * wave; kbase < hi; kbase += 32 * NW) {
-        const GlobalKV<D> kv{kb, vb, seq_alloc, kbase, i, g4};
-        attn_tile<D>(s, qf, kv, kbase, 0, lo, hi, scale, lane);
+    // A wave's tiles are 32 * NW keys apart and every fragment is one trip to HBM.  The next tile's K fragments are
+    // requested before the current tile is computed (its V fragments are requested inside the step, behind the K.Q^T
+    // MFMAs, and land under the softmax); both sets of V would not fit the register budget of three waves per SIMD.
+    constexpr int STEP = 32 * NW;
+    struct KregVglobal {
+        bf16x8 k[2][D / 32];
+        const bf16_t *vT; int ldv, kbase, i, g4;
+        __device__ void load_k(const bf16_t *kb_, int kbase_, int i_, int g4_) {
+#pragma unroll
+            for (int dk = 0; dk < D / 32; dk++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) k[t][dk] = ld_bf16x8(kb_ + (size_t)(kbase_ + 8 * (i_ >> 2) + (i_ & 3) + 4 * t) * D + dk * 32 + g4_ * 8);
+        }
+        __device__ bf16x8 k_frag(int tile, int dk) const { return k[tile][dk]; }
+        __device__ bf16x8 v_frag(int db) const { return ld_bf16x8(vT + (size_t)(db * 16 + i) * ldv + kbase + 8 * g4); }
+    };
+    KregVglobal ra, rb;
+    ra.vT = rb.vT = vb; ra.ldv = rb.ldv = seq_alloc; ra.i = rb.i = i; ra.g4 = rb.g4 = g4;
+    int kbase = lo + 32 * wave;
+    if (kbase < hi) ra.load_k(kb, kbase, i, g4);
+    while (kbase < hi) {
+        if (kbase + STEP < hi) rb.load_k(kb, kbase + STEP, i, g4);
+        ra.kbase = kbase;
+        attn_tile<D>(s, qf, ra, kbase, 0, lo, hi, scale, lane);
+        kbase += STEP;
+        if (kbase >= hi) break;
+        if (kbase + STEP < hi) ra.load_k(kb, kbase + STEP, i, g4);
+        rb.kbase = kbase;
+        attn_tile<D>(s, qf, rb, kbase, 0, lo, hi, scale, lane);
+        kbase += STEP;
     }
 
     mfma_state_to_lds<D, GMAX>(s, lds, wave, G, lane);

@@ -523,7 +523,7 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
     // small (<= 96 KB per head): then one wide workgroup per head with no cross-workgroup combine wins.
     int64_t ns = (int64_t)((max_seq + (c->v_transposed ? 127 : 63)) / (c->v_transposed ? 128 : 64));
     if (c->v_transposed && max_seq * (size_t)D.d * 4 <= 96 * 1024) ns = 1;
-    c->nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(ns, 64));
+    c->nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(ns, c->v_transposed ? 48 : 64));   // (measured at S = 8192 / 16384: 32..48 splits 17.4 / 24.0 us, 64: 18.7 / 25.4)
     c->nsplit = env_int("FL_ATTN_NSPLIT", c->nsplit);
     {   // decode attention + o_proj in one launch when W_o's per-CU slice fits in LDS next to the attention state
         hipDeviceProp_t prop;
