@@ -48,7 +48,7 @@ __device__ __forceinline__ void combine_lds(const float *lds, int g, int j4, flo
 // Tail of a decode-attention workgroup once its NW wave slabs are in LDS (and a barrier has passed).
 // nsplit == 1: normalise and write the output.  Otherwise publish this split's (m, l, o) slab and
 // let the workgroup that draws the last ticket of its (kv head, q-group) combine all splits:
-//   up to 8 splits:  plain stores -> per-wave vmcnt(0) -> barrier -> agent-scope release -> vmcnt(0) -> ticket;
+//   up to 8 splits in a launch of at most 64 workgroups:  plain stores -> per-wave vmcnt(0) -> barrier -> agent-scope release -> vmcnt(0) -> ticket;
 //   more splits:     write-through (sc1) stores -> per-wave vmcnt(0) -> barrier -> ticket   (no release: that fence
 //                    writes back the XCD's whole L2, and hundreds of split workgroups each paid for one);
 //   last arriver:    agent-scope acquire -> barrier -> plain loads, splits spread over all threads
@@ -70,7 +70,7 @@ __device__ __forceinline__ bool decode_tail(float *lds, int *is_last, int G, int
         }
         return true;
     }
-    const bool few = nsplit <= 8;
+    const bool few = nsplit <= 8 && gridDim.x * gridDim.y * gridDim.z <= 64;      // (a batch launch has many publishers even with few splits each)
     for (int e = threadIdx.x; e < G * (D / 4); e += NW * 64) {
         const int g = e / (D / 4), j4 = (e % (D / 4)) * 4;
         float M, L, O[4];

@@ -162,8 +162,10 @@ int launch_attn_decode_mfma_batch(Launcher &L, const void *q, const SeqRef *seqs
                                   void *out, int64_t H, int64_t Hkv, int64_t d, float scale, double kv_bytes_hint) {
     const int G = (int)(H / Hkv);
     if (max_nsplit > 64 || max_nsplit < 1) FL_FAIL(FL_ERR_BAD_ARGUMENT, "attention: 1..64 splits");
-    // measured (Mistral-7B, 8 sequences at S ~ 600): 128 workgroups (2 splits) 15.3 us, 448 (7 splits) 24.3 us
-    const int cap = (int)std::max<int64_t>(1, 128 / (Hkv * B));
+    // measured (Mistral-7B, 8 sequences at S ~ 600), with a release fence per split workgroup: 128 workgroups (2 splits)
+    // 15.3 us, 448 (7 splits) 24.3 us; with write-through publication (attn_common.h): 128 -> 11.4 us, 256 -> 10.9, 512 -> 12.2
+    static const int wg_cap = getenv("FL_ATTN_BATCH_WGS") ? atoi(getenv("FL_ATTN_BATCH_WGS")) : 256;
+    const int cap = (int)std::max<int64_t>(1, wg_cap / (Hkv * B));
     max_nsplit = std::min(max_nsplit, cap);
     dim3 grid((unsigned)Hkv, (unsigned)max_nsplit, (unsigned)B);
 #define FL_GOB(DD, GM)                                                                                                          \
