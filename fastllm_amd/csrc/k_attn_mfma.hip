@@ -72,6 +72,12 @@ __device__ __forceinline__ void attn_decode_mfma_body(const bf16_t *__restrict__
         __device__ bf16x8 k_frag(int tile, int dk) const { return k[tile][dk]; }
         __device__ bf16x8 v_frag(int db) const { return ld_bf16x8(vT + (size_t)(db * 16 + i) * ldv + kbase + 8 * g4); }
     };
+    if constexpr (NW > 8) {               // 16-wave workgroups have 128 VGPRs per lane: no room for a second K set
+        for (int kbase = lo + 32 * wave; kbase < hi; kbase += STEP) {
+            const GlobalKV<D> kv{kb, vb, seq_alloc, kbase, i, g4};
+            attn_tile<D>(s, qf, kv, kbase, 0, lo, hi, scale, lane);
+        }
+    } else {
     KregVglobal ra, rb;
     ra.vT = rb.vT = vb; ra.ldv = rb.ldv = seq_alloc; ra.i = rb.i = i; ra.g4 = rb.g4 = g4;
     int kbase = lo + 32 * wave;
@@ -86,6 +92,7 @@ __device__ __forceinline__ void attn_decode_mfma_body(const bf16_t *__restrict__
         rb.kbase = kbase;
         attn_tile<D>(s, qf, rb, kbase, 0, lo, hi, scale, lane);
         kbase += STEP;
+    }
     }
 
     mfma_state_to_lds<D, GMAX>(s, lds, wave, G, lane);
