@@ -57,13 +57,14 @@ __device__ inline void unpack_raw(const RawChunk<float> &r, float (&o)[8]) {
 // SMALL: every wave owns at most ONE row group and K <= 2 blocks of U chunks (host-checked): the whole
 // weight share of the wave (2*U*R KiB) is requested before x is staged -- one HBM round trip instead of
 // two for the short QKV / o_proj launches, where ramp-up is most of the kernel.
-template <typename WT, typename XT, int R, int U, int PRO, int MAXT, bool SMALL>
+template <typename WT, typename XT, int R, int U, int PRO, int MAXT, bool SMALL, int EPI>
 __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float red[kGemvMaxThreads / 64];
     XT *xs = reinterpret_cast<XT *>(lds_raw);
     const WT *__restrict__ W = reinterpret_cast<const WT *>(a.W);
-    const int N = a.N, K = a.K, epi = a.epi;
+    const int N = a.N, K = a.K;
+    constexpr int epi = EPI;                         // compile-time: the epilogue's operands do not occupy registers of the others
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthr = blockDim.x, nwv = nthr >> 6;
     const int nchunk = K >> 3;                       // 8-element chunks; K % 8 == 0
@@ -413,9 +414,9 @@ static void pick_geometry(int64_t ngroups, size_t lds_bytes, int *blocks_out, in
     *blocks_out = bb; *waves_out = bw;
 }
 
-template <typename WT, typename XT, int R, int U, int PRO, int MAXT, bool SMALL>
-static int launch_gemv_k(Launcher &L, const GemvArgs &a, int blocks, int waves, size_t lds) {
-    auto kern = gemv_kernel<WT, XT, R, U, PRO, MAXT, SMALL>;
+template <typename WT, typename XT, int R, int U, int PRO, int MAXT, bool SMALL, int EPI>
+static int launch_gemv_ke(Launcher &L, const GemvArgs &a, int blocks, int waves, size_t lds) {
+    auto kern = gemv_kernel<WT, XT, R, U, PRO, MAXT, SMALL, EPI>;
     if (lds > 64 * 1024) {
         static std::atomic<size_t> raised{0};      // per instantiation, process-wide
         if (raised.load() < lds) {
@@ -428,6 +429,13 @@ static int launch_gemv_k(Launcher &L, const GemvArgs &a, int blocks, int waves, 
     snprintf(tag, sizeof tag, "%dx%d%s%s", a.N, a.K, PRO == PRO_NORM ? ",norm" : "", a.epi == EPI_GATEUP ? ",glu" : (a.epi == EPI_QKV_ROPE ? ",rope" : ""));
     Launcher LL = L; LL.tag = tag;
     return LL.launch(KC_GEMV, bytes, 2.0 * a.N * a.K, kern, dim3((unsigned)blocks), dim3((unsigned)waves * 64), lds, a);
+}
+
+template <typename WT, typename XT, int R, int U, int PRO, int MAXT, bool SMALL>
+static int launch_gemv_k(Launcher &L, const GemvArgs &a, int blocks, int waves, size_t lds) {
+    if (a.epi == EPI_GATEUP) return launch_gemv_ke<WT, XT, R, U, PRO, MAXT, SMALL, EPI_GATEUP>(L, a, blocks, waves, lds);
+    if (a.epi == EPI_QKV_ROPE) return launch_gemv_ke<WT, XT, R, U, PRO, MAXT, SMALL, EPI_QKV_ROPE>(L, a, blocks, waves, lds);
+    return launch_gemv_ke<WT, XT, R, U, PRO, MAXT, SMALL, EPI_F32>(L, a, blocks, waves, lds);
 }
 
 template <typename WT, typename XT, int R, int U, int PRO>
