@@ -29,13 +29,14 @@ namespace fl {
 
 constexpr int kBR = 2, kBU = 4, kBThreads = 512;
 
-template <int NB, int PRO>
+template <int NB, int PRO, int EPI>
 __global__ __launch_bounds__(kBThreads) void gemv_batch_kernel(const GemvBatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float red[kBThreads / 64][NB];
     bf16_t *xs = reinterpret_cast<bf16_t *>(lds_raw);                 // [NB][Ks]
     const bf16_t *__restrict__ W = reinterpret_cast<const bf16_t *>(a.W);
-    const int N = a.N, K = a.K, epi = a.epi, B = a.B;
+    const int N = a.N, K = a.K, B = a.B;
+    constexpr int epi = EPI;                          // compile-time, like gemv_kernel's: the other epilogues' operands cost no registers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int nthr = kBThreads, nwv = kBThreads / 64;
     const int ks = blockIdx.y;
@@ -281,14 +282,15 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 // MODE 0: per-unit loop; 1: pipelined across units (PIPE); 2: PIPE + per-wave LDS transpose (STAGED).
 // Tried and dropped (profiles/r01/README.md): K steps dealt round-robin to the waves (3.5 vs 4.05 TB/s), and
 // workgroup-cooperative 32-row x 512-k stages with 1 KiB-per-row loads and a barrier per stage (3.3 TB/s).
-template <int PRO, int MU, int MODE>
+template <int PRO, int MU, int MODE, int EPI>
 __global__ __launch_bounds__(kBThreads) void gemv_batch_mfma_kernel(const GemvBatchArgs a) {
     constexpr bool PIPE = MODE == 1 || MODE == 2, STAGED = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float red[kBThreads / 64][8];
     __shared__ float inv_lds[8];
     const bf16_t *__restrict__ W = reinterpret_cast<const bf16_t *>(a.W);
-    const int N = a.N, K = a.K, epi = a.epi, B = a.B;
+    const int N = a.N, K = a.K, B = a.B;
+    constexpr int epi = EPI;                          // compile-time, like gemv_kernel's: the other epilogues' operands cost no registers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int nthr = kBThreads, nwv = kBThreads / 64;
     const int ks = blockIdx.y;
@@ -576,9 +578,9 @@ int gemv_batch_ksplit(int B, int64_t K, int64_t N, int epi) {
     return nks;
 }
 
-template <int NB, int PRO>
-static int launch_gemv_batch_t(Launcher &L, const GemvBatchArgs &a) {
-    auto kern = gemv_batch_kernel<NB, PRO>;
+template <int NB, int PRO, int EPI>
+static int launch_gemv_batch_e(Launcher &L, const GemvBatchArgs &a) {
+    auto kern = gemv_batch_kernel<NB, PRO, EPI>;
     const int64_t per = (((a.K / 8) + a.nks - 1) / a.nks + 63) & ~(int64_t)63;
     const size_t lds = (size_t)NB * per * 8 * 2;
     if (lds > 64 * 1024) {
@@ -597,9 +599,16 @@ static int launch_gemv_batch_t(Launcher &L, const GemvBatchArgs &a) {
     return LL.launch(KC_GEMV, (double)a.N * a.K * 2, 2.0 * a.N * a.K * a.B, kern, dim3((unsigned)blocks, (unsigned)a.nks), dim3(kBThreads), lds, a);
 }
 
-template <int PRO, int MU, int MODE>
-static int launch_gemv_batch_mfma_k(Launcher &L, const GemvBatchArgs &a) {
-    auto kern = gemv_batch_mfma_kernel<PRO, MU, MODE>;
+template <int NB, int PRO>
+static int launch_gemv_batch_t(Launcher &L, const GemvBatchArgs &a) {
+    if (a.epi == EPI_GATEUP) return launch_gemv_batch_e<NB, PRO, EPI_GATEUP>(L, a);
+    if (a.epi == EPI_QKV_ROPE) return launch_gemv_batch_e<NB, PRO, EPI_QKV_ROPE>(L, a);
+    return launch_gemv_batch_e<NB, PRO, EPI_F32>(L, a);
+}
+
+template <int PRO, int MU, int MODE, int EPI>
+static int launch_gemv_batch_mfma_e(Launcher &L, const GemvBatchArgs &a) {
+    auto kern = gemv_batch_mfma_kernel<PRO, MU, MODE, EPI>;
     const int64_t per = (((a.K / 8) + a.nks - 1) / a.nks + 63) & ~(int64_t)63;
     const size_t lds = (size_t)8 * (per * 8 + 8) * 2 + (size_t)(8 * 2 * 256 + 2 * 256) * 4 + (MODE >= 2 ? 8 * 8192 : 0);
     if (lds > 64 * 1024) {
@@ -615,6 +624,13 @@ static int launch_gemv_batch_mfma_k(Launcher &L, const GemvBatchArgs &a) {
     snprintf(tag, sizeof tag, "b%dm:%dx%d%s%s", a.B, a.N, a.K, PRO == PRO_NORM ? ",norm" : "", a.epi == EPI_GATEUP ? ",glu" : (a.epi == EPI_QKV_ROPE ? ",rope" : ""));
     Launcher LL = L; LL.tag = tag;
     return LL.launch(KC_GEMV, (double)a.N * a.K * 2, 2.0 * a.N * a.K * a.B, kern, dim3((unsigned)blocks, (unsigned)a.nks), dim3(kBThreads), lds, a);
+}
+
+template <int PRO, int MU, int MODE>
+static int launch_gemv_batch_mfma_k(Launcher &L, const GemvBatchArgs &a) {
+    if (a.epi == EPI_GATEUP) return launch_gemv_batch_mfma_e<PRO, MU, MODE, EPI_GATEUP>(L, a);
+    if (a.epi == EPI_QKV_ROPE) return launch_gemv_batch_mfma_e<PRO, MU, MODE, EPI_QKV_ROPE>(L, a);
+    return launch_gemv_batch_mfma_e<PRO, MU, MODE, EPI_F32>(L, a);
 }
 
 template <int PRO>
