@@ -57,7 +57,7 @@ __device__ inline void unpack_raw(const RawChunk<float> &r, float (&o)[8]) {
 // SMALL: every wave owns at most ONE row group and K <= 2 blocks of U chunks (host-checked): the whole
 // weight share of the wave (2*U*R KiB) is requested before x is staged -- one HBM round trip instead of
 // two for the short QKV / o_proj launches, where ramp-up is most of the kernel.
-template <typename WT, typename XT, int R, int U, int PRO, int MAXT, bool SMALL, int EPI>
+template <typename WT, typename XT, int R, int U, int PRO, int MAXT, bool SMALL, int EPI, bool FUSE_AR>
 __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float red[kGemvMaxThreads / 64];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
         float sum[R];
 #pragma unroll
         for (int r = 0; r < R; r++) { sum[r] = wave_sum(acc[r]) * inv_m; acc[r] = 0.f; }
-        if (a.ll) {                                   // row-parallel projection of a tensor-parallel group (EPI_F32, no bias: host-checked)
+        if constexpr (FUSE_AR) {                           // row-parallel projection of a tensor-parallel group (EPI_F32, no bias: host-checked)
             ll_allreduce_rows<R>(a.ll, a.ll_slot, g * R, N, sum, reinterpret_cast<float *>(a.out), lane);
             return;
         }
@@ -414,9 +414,9 @@ static void pick_geometry(int64_t ngroups, size_t lds_bytes, int *blocks_out, in
     *blocks_out = bb; *waves_out = bw;
 }
 
-template <typename WT, typename XT, int R, int U, int PRO, int MAXT, bool SMALL, int EPI>
+template <typename WT, typename XT, int R, int U, int PRO, int MAXT, bool SMALL, int EPI, bool FUSE_AR = false>
 static int launch_gemv_ke(Launcher &L, const GemvArgs &a, int blocks, int waves, size_t lds) {
-    auto kern = gemv_kernel<WT, XT, R, U, PRO, MAXT, SMALL, EPI>;
+    auto kern = gemv_kernel<WT, XT, R, U, PRO, MAXT, SMALL, EPI, FUSE_AR>;
     if (lds > 64 * 1024) {
         static std::atomic<size_t> raised{0};      // per instantiation, process-wide
         if (raised.load() < lds) {
@@ -435,6 +435,7 @@ template <typename WT, typename XT, int R, int U, int PRO, int MAXT, bool SMALL>
 static int launch_gemv_k(Launcher &L, const GemvArgs &a, int blocks, int waves, size_t lds) {
     if (a.epi == EPI_GATEUP) return launch_gemv_ke<WT, XT, R, U, PRO, MAXT, SMALL, EPI_GATEUP>(L, a, blocks, waves, lds);
     if (a.epi == EPI_QKV_ROPE) return launch_gemv_ke<WT, XT, R, U, PRO, MAXT, SMALL, EPI_QKV_ROPE>(L, a, blocks, waves, lds);
+    if (a.ll) return launch_gemv_ke<WT, XT, R, U, PRO, MAXT, SMALL, EPI_F32, true>(L, a, blocks, waves, lds);
     return launch_gemv_ke<WT, XT, R, U, PRO, MAXT, SMALL, EPI_F32>(L, a, blocks, waves, lds);
 }
 
