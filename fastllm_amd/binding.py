@@ -44,7 +44,8 @@ class FlParallel(C.Structure):
 class FlModelInfo(C.Structure):
     _fields_ = [("cfg", FlConfig), ("head_dim", C.c_int64), ("compute_dtype", C.c_int32), ("tp_size", C.c_int32),
                 ("weight_bytes_per_token", C.c_int64), ("kv_bytes_per_position", C.c_int64),
-                ("hbm_bytes_allocated", C.c_int64), ("small_collectives", C.c_int32), ("fused_all_reduce", C.c_int32)]
+                ("hbm_bytes_allocated", C.c_int64), ("small_collectives", C.c_int32), ("fused_all_reduce", C.c_int32),
+                ("rccl_ranks", C.c_int32), ("_reserved", C.c_int32)]
 
 
 class FlSampling(C.Structure):

@@ -1,5 +1,12 @@
 // api.hip -- the extern "C" surface declared in include/fastllm_mi355x.h.
+//
+// Every entry point is an exception barrier: the host of this library is Rust (or ctypes), and a C++
+// exception that crosses the C ABI is undefined behaviour there.  The reference surfaces failures as
+// anyhow::Error (mod.rs:402-405,446-451); here std::bad_alloc becomes FL_ERR_OOM and anything else
+// FL_ERR_HIP, both with fl_last_error() set.
+#include <exception>
 #include <memory>
+#include <new>
 
 #include "model.h"
 
@@ -12,291 +19,379 @@ static const Model *M(const fl_model *m) { return reinterpret_cast<const Model *
 static Cache *C(fl_cache *c) { return reinterpret_cast<Cache *>(c); }
 static const Cache *C(const fl_cache *c) { return reinterpret_cast<const Cache *>(c); }
 
+template <typename F> static int guarded(F &&body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        set_error("out of host memory (std::bad_alloc)");
+        return FL_ERR_OOM;
+    } catch (const std::exception &e) {
+        set_error("internal error: %s", e.what());
+        return FL_ERR_HIP;
+    } catch (...) {
+        set_error("internal error: unknown C++ exception");
+        return FL_ERR_HIP;
+    }
+}
+template <typename F> static void guarded_void(F &&body) noexcept {
+    (void)guarded([&]() -> int { body(); return FL_OK; });
+}
+
 extern "C" {
 
 int fl_abi_version(void) { return FL_ABI_VERSION; }
 const char *fl_last_error(void) { return last_error(); }
 
 int fl_device_count(int *count) {
-    if (!count) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null count");
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
-    *count = n;
-    return FL_OK;
+    return guarded([&]() -> int {
+        if (!count) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null count");
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+        *count = n;
+        return FL_OK;
+    });
 }
 
 int fl_comm_unique_id(void *out) {
-    if (!out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null out");
-    static_assert(sizeof(ncclUniqueId) <= FL_UNIQUE_ID_BYTES, "unique id size");
-    ncclUniqueId id;
-    ncclResult_t r = ncclGetUniqueId(&id);
-    if (r != ncclSuccess) FL_FAIL(FL_ERR_RCCL, "ncclGetUniqueId: %s", ncclGetErrorString(r));
-    memset(out, 0, FL_UNIQUE_ID_BYTES);
-    memcpy(out, &id, sizeof id);
-    return FL_OK;
+    return guarded([&]() -> int {
+        if (!out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null out");
+        static_assert(sizeof(ncclUniqueId) <= FL_UNIQUE_ID_BYTES, "unique id size");
+        ncclUniqueId id;
+        ncclResult_t r = ncclGetUniqueId(&id);
+        if (r != ncclSuccess) FL_FAIL(FL_ERR_RCCL, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+        memset(out, 0, FL_UNIQUE_ID_BYTES);
+        memcpy(out, &id, sizeof id);
+        return FL_OK;
+    });
 }
 
-int fl_comm_ipc_export(fl_model *m, void *handle_out) { return comm_ipc_export(M(m), handle_out); }
-int fl_comm_ipc_connect(fl_model *m, const void *handles) { return comm_ipc_connect(M(m), handles); }
+int fl_comm_ipc_export(fl_model *m, void *handle_out) {
+    return guarded([&]() -> int {
+        return comm_ipc_export(M(m), handle_out);
+    });
+}
+int fl_comm_ipc_connect(fl_model *m, const void *handles) {
+    return guarded([&]() -> int {
+        return comm_ipc_connect(M(m), handles);
+    });
+}
 
 int fl_model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n_tensors, int32_t compute_dtype,
                     const fl_parallel *par, fl_model **out) {
-    Model *m = nullptr;
-    int rc = model_create(cfg, tensors, n_tensors, compute_dtype, par, &m);
-    if (rc == FL_OK) *out = reinterpret_cast<fl_model *>(m);
-    return rc;
+    return guarded([&]() -> int {
+        if (!out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "fl_model_create: null out");
+        *out = nullptr;
+        Model *m = nullptr;
+        int rc = model_create(cfg, tensors, n_tensors, compute_dtype, par, &m);
+        if (rc == FL_OK) *out = reinterpret_cast<fl_model *>(m);
+        return rc;
+    });
 }
 
-void fl_model_retain(fl_model *m) { if (m) M(m)->refs.fetch_add(1); }
+void fl_model_retain(fl_model *m) {
+    guarded_void([&]() {
+        if (m) M(m)->refs.fetch_add(1);
+    });
+}
 void fl_model_release(fl_model *m) {
-    if (m && M(m)->refs.fetch_sub(1) == 1) delete M(m);
+    guarded_void([&]() {
+        if (m && M(m)->refs.fetch_sub(1) == 1) delete M(m);
+    });
 }
 
 int fl_model_get_info(const fl_model *m, fl_model_info *out) {
-    if (!m || !out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
-    const Model *mm = M(m);
-    const Dims &D = mm->D;
-    memset(out, 0, sizeof *out);
-    out->cfg = mm->cfg_resolved;
-    out->head_dim = D.d;
-    out->compute_dtype = mm->dtype;
-    out->tp_size = mm->tp;
-    const int64_t es = (int64_t)mm->esize();
-    // weights read once per decoded token (one embedding row, norms, biases
-    // included; the rest of the embedding table excluded)
-    int64_t per_layer = 2 * D.h * D.h + 2 * D.Hkv * D.d * D.h + 3 * D.h * D.inter;
-    int64_t small = 2 * D.h + (D.qkv_bias ? D.h + 2 * D.Hkv * D.d : 0);
-    out->weight_bytes_per_token = es * (D.L * (per_layer + small) + D.h + D.V * D.h);
-    out->kv_bytes_per_position = es * D.L * D.Hkv * D.d * 2;
-    out->hbm_bytes_allocated = mm->hbm_bytes;
-    out->small_collectives = mm->shards[0].pc.connected ? 2 : mm->tp == 1 ? 0 : mm->tp_mode == FL_TP_EMULATED ? 3 : 1;
-    out->fused_all_reduce = fused_all_reduce_ready(mm) ? 1 : 0;
-    return FL_OK;
+    return guarded([&]() -> int {
+        if (!m || !out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+        const Model *mm = M(m);
+        const Dims &D = mm->D;
+        memset(out, 0, sizeof *out);
+        out->cfg = mm->cfg_resolved;
+        out->head_dim = D.d;
+        out->compute_dtype = mm->dtype;
+        out->tp_size = mm->tp;
+        const int64_t es = (int64_t)mm->esize();
+        // weights read once per decoded token (one embedding row, norms, biases
+        // included; the rest of the embedding table excluded)
+        int64_t per_layer = 2 * D.h * D.h + 2 * D.Hkv * D.d * D.h + 3 * D.h * D.inter;
+        int64_t small = 2 * D.h + (D.qkv_bias ? D.h + 2 * D.Hkv * D.d : 0);
+        out->weight_bytes_per_token = es * (D.L * (per_layer + small) + D.h + D.V * D.h);
+        out->kv_bytes_per_position = es * D.L * D.Hkv * D.d * 2;
+        out->hbm_bytes_allocated = mm->hbm_bytes;
+        out->small_collectives = mm->shards[0].pc.connected ? 2 : mm->tp == 1 ? 0 : mm->tp_mode == FL_TP_EMULATED ? 3 : 1;
+        out->fused_all_reduce = fused_all_reduce_ready(mm) ? 1 : 0;
+        if (mm->shards[0].comm) {
+            int n = 0;
+            if (ncclCommCount(mm->shards[0].comm, &n) == ncclSuccess) out->rccl_ranks = n;
+        }
+        return FL_OK;
+    });
 }
 
 int fl_cache_create(fl_model *m, size_t max_seq, fl_cache **out) {
-    Cache *c = nullptr;
-    int rc = cache_create(M(m), max_seq, &c);
-    if (rc == FL_OK) *out = reinterpret_cast<fl_cache *>(c);
-    return rc;
+    return guarded([&]() -> int {
+        if (!out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "fl_cache_create: null out");
+        *out = nullptr;
+        Cache *c = nullptr;
+        int rc = cache_create(M(m), max_seq, &c);
+        if (rc == FL_OK) *out = reinterpret_cast<fl_cache *>(c);
+        return rc;
+    });
 }
-void fl_cache_reset(fl_cache *c) { if (c) C(c)->len = 0; }
+void fl_cache_reset(fl_cache *c) {
+    guarded_void([&]() {
+        if (c) C(c)->len = 0;
+    });
+}
 size_t fl_cache_len(const fl_cache *c) { return c ? C(c)->len : 0; }
 size_t fl_cache_capacity(const fl_cache *c) { return c ? C(c)->max_seq : 0; }
 void fl_cache_destroy(fl_cache *c) {
-    if (!c) return;
-    Model *m = C(c)->m;
-    delete C(c);
-    if (m && m->refs.fetch_sub(1) == 1) delete m;
+    guarded_void([&]() {
+        if (!c) return;
+        Model *m = C(c)->m;
+        delete C(c);
+        if (m && m->refs.fetch_sub(1) == 1) delete m;
+    });
 }
 
 int fl_forward(fl_model *m, fl_cache *c, const uint32_t *ids, size_t T, size_t pos, float *logits_out) {
-    if (!logits_out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null logits_out");
-    return forward(M(m), C(c), ids, T, pos, logits_out, nullptr);
+    return guarded([&]() -> int {
+        if (!logits_out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null logits_out");
+        return forward(M(m), C(c), ids, T, pos, logits_out, nullptr);
+    });
 }
 
 int fl_forward_argmax(fl_model *m, fl_cache *c, const uint32_t *ids, size_t T, size_t pos, uint32_t *token_out) {
-    if (!token_out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null token_out");
-    return forward(M(m), C(c), ids, T, pos, nullptr, token_out);
+    return guarded([&]() -> int {
+        if (!token_out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null token_out");
+        return forward(M(m), C(c), ids, T, pos, nullptr, token_out);
+    });
 }
 
 int fl_decode_greedy(fl_model *m, fl_cache *c, uint32_t first_token, size_t pos, size_t n_steps, int64_t eos,
                      uint32_t *tokens_out, size_t *n_out) {
-    return decode_greedy(M(m), C(c), first_token, pos, n_steps, eos, tokens_out, n_out);
+    return guarded([&]() -> int {
+        return decode_greedy(M(m), C(c), first_token, pos, n_steps, eos, tokens_out, n_out);
+    });
 }
 
 int fl_forward_sample(fl_model *m, fl_cache *c, const uint32_t *ids, size_t T, size_t pos, const fl_sampling *sampling,
                       uint32_t *token_out) {
-    if (!token_out || !sampling) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
-    return forward(M(m), C(c), ids, T, pos, nullptr, token_out, sampling);
+    return guarded([&]() -> int {
+        if (!token_out || !sampling) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+        return forward(M(m), C(c), ids, T, pos, nullptr, token_out, sampling);
+    });
 }
 
 int fl_decode_sample(fl_model *m, fl_cache *c, uint32_t first_token, size_t pos, size_t n_steps, int64_t eos,
                      const fl_sampling *sampling, uint32_t *tokens_out, size_t *n_out) {
-    if (!sampling) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null sampling");
-    return decode_greedy(M(m), C(c), first_token, pos, n_steps, eos, tokens_out, n_out, sampling);
+    return guarded([&]() -> int {
+        if (!sampling) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null sampling");
+        return decode_greedy(M(m), C(c), first_token, pos, n_steps, eos, tokens_out, n_out, sampling);
+    });
 }
 
 int fl_batch_create(fl_model *m, fl_cache *const *caches, size_t n, fl_batch **out) {
-    if (!out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null out");
-    Batch *b = nullptr;
-    FL_TRY(batch_create(M(m), reinterpret_cast<Cache *const *>(caches), n, &b));
-    *out = reinterpret_cast<fl_batch *>(b);
-    return FL_OK;
+    return guarded([&]() -> int {
+        if (!out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null out");
+        Batch *b = nullptr;
+        FL_TRY(batch_create(M(m), reinterpret_cast<Cache *const *>(caches), n, &b));
+        *out = reinterpret_cast<fl_batch *>(b);
+        return FL_OK;
+    });
 }
 void fl_batch_destroy(fl_batch *b) {
-    if (!b) return;
-    Batch *bb = reinterpret_cast<Batch *>(b);
-    Model *m = bb->m;
-    delete bb;
-    if (m && m->refs.fetch_sub(1) == 1) delete m;
+    guarded_void([&]() {
+        if (!b) return;
+        Batch *bb = reinterpret_cast<Batch *>(b);
+        Model *m = bb->m;
+        delete bb;
+        if (m && m->refs.fetch_sub(1) == 1) delete m;
+    });
 }
 int fl_batch_forward(fl_batch *b, const uint32_t *tokens, const size_t *pos, float *logits_out, uint32_t *argmax_out) {
-    return batch_forward(reinterpret_cast<Batch *>(b), tokens, pos, logits_out, argmax_out);
+    return guarded([&]() -> int {
+        return batch_forward(reinterpret_cast<Batch *>(b), tokens, pos, logits_out, argmax_out);
+    });
 }
 int fl_batch_decode(fl_batch *b, const uint32_t *first_tokens, const size_t *pos, size_t n_steps, int64_t eos,
                     const fl_sampling *sampling, uint32_t *tokens_out, size_t *n_out) {
-    return batch_decode(reinterpret_cast<Batch *>(b), first_tokens, pos, n_steps, eos, sampling, tokens_out, n_out);
+    return guarded([&]() -> int {
+        return batch_decode(reinterpret_cast<Batch *>(b), first_tokens, pos, n_steps, eos, sampling, tokens_out, n_out);
+    });
 }
 
 int fl_synchronize(fl_model *m) {
-    if (!m) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null model");
-    for (auto &sh : M(m)->shards) { FL_HIP(hipSetDevice(sh.device)); FL_HIP(hipStreamSynchronize(sh.stream)); }
-    return FL_OK;
+    return guarded([&]() -> int {
+        if (!m) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null model");
+        for (auto &sh : M(m)->shards) { FL_HIP(hipSetDevice(sh.device)); FL_HIP(hipStreamSynchronize(sh.stream)); }
+        return FL_OK;
+    });
 }
 
 int fl_tp_slice(const fl_config *cfg, const char *tensor_name, int32_t tp_rank, int32_t tp_size, int64_t out[4]) {
-    if (!tensor_name || !out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
-    Dims D;
-    FL_TRY(resolve_config(cfg, &D));
-    return tp_slice(D, tensor_name, tp_rank, tp_size, out);
+    return guarded([&]() -> int {
+        if (!tensor_name || !out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+        Dims D;
+        FL_TRY(resolve_config(cfg, &D));
+        return tp_slice(D, tensor_name, tp_rank, tp_size, out);
+    });
 }
 
 int fl_profile_begin(fl_model *m) {
-    if (!m) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null model");
-    std::lock_guard<std::mutex> lock(M(m)->mu);
-    for (auto &r : M(m)->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
-    M(m)->prof.clear();
-    M(m)->profiling = true;
-    return FL_OK;
+    return guarded([&]() -> int {
+        if (!m) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null model");
+        std::lock_guard<std::mutex> lock(M(m)->mu);
+        for (auto &r : M(m)->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+        M(m)->prof.clear();
+        M(m)->profiling = true;
+        return FL_OK;
+    });
 }
 
 int fl_profile_end(fl_model *m, fl_kernel_stat *stats, size_t cap, size_t *n_stats) {
-    if (!m || !n_stats) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
-    Model *mm = M(m);
-    std::lock_guard<std::mutex> lock(mm->mu);
-    mm->profiling = false;
-    for (auto &sh : mm->shards) { FL_HIP(hipSetDevice(sh.device)); FL_HIP(hipStreamSynchronize(sh.stream)); }
-    std::vector<fl_kernel_stat> acc;
-    for (auto &r : mm->prof) {
-        float ms = 0.f;
-        FL_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
-        char name[48];
-        if (r.tag[0]) snprintf(name, sizeof name, "%s[%s]", kernel_class_name(r.kc), r.tag);
-        else snprintf(name, sizeof name, "%s", kernel_class_name(r.kc));
-        fl_kernel_stat *st = nullptr;
-        for (auto &e : acc) if (!strcmp(e.name, name)) { st = &e; break; }
-        if (!st) { fl_kernel_stat e; memset(&e, 0, sizeof e); snprintf(e.name, sizeof e.name, "%s", name); acc.push_back(e); st = &acc.back(); }
-        st->launches++; st->total_ms += ms; st->bytes += r.bytes; st->flops += r.flops;
-    }
-    for (auto &r : mm->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
-    mm->prof.clear();
-    size_t n = 0;
-    for (auto &e : acc) {
-        if (stats && n < cap) stats[n] = e;
-        n++;
-    }
-    *n_stats = n;
-    return FL_OK;
+    return guarded([&]() -> int {
+        if (!m || !n_stats) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+        Model *mm = M(m);
+        std::lock_guard<std::mutex> lock(mm->mu);
+        mm->profiling = false;
+        for (auto &sh : mm->shards) { FL_HIP(hipSetDevice(sh.device)); FL_HIP(hipStreamSynchronize(sh.stream)); }
+        std::vector<fl_kernel_stat> acc;
+        for (auto &r : mm->prof) {
+            float ms = 0.f;
+            FL_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+            char name[48];
+            if (r.tag[0]) snprintf(name, sizeof name, "%s[%s]", kernel_class_name(r.kc), r.tag);
+            else snprintf(name, sizeof name, "%s", kernel_class_name(r.kc));
+            fl_kernel_stat *st = nullptr;
+            for (auto &e : acc) if (!strcmp(e.name, name)) { st = &e; break; }
+            if (!st) { fl_kernel_stat e; memset(&e, 0, sizeof e); snprintf(e.name, sizeof e.name, "%s", name); acc.push_back(e); st = &acc.back(); }
+            st->launches++; st->total_ms += ms; st->bytes += r.bytes; st->flops += r.flops;
+        }
+        for (auto &r : mm->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+        mm->prof.clear();
+        size_t n = 0;
+        for (auto &e : acc) {
+            if (stats && n < cap) stats[n] = e;
+            n++;
+        }
+        *n_stats = n;
+        return FL_OK;
+    });
 }
 
 int fl_tune(const char *key, int value) {
-    if (!key || value < 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "bad tuning key/value");
-    if (!strcmp(key, "gemv_r")) gemv_set_tuning(value, 0, -1, -1);
-    else if (!strcmp(key, "gemv_u")) gemv_set_tuning(0, value, -1, -1);
-    else if (!strcmp(key, "gemv_blocks")) gemv_set_tuning(0, 0, value, -1);        // 0 = automatic
-    else if (!strcmp(key, "gemv_waves")) gemv_set_tuning(0, 0, -1, value);          // 0 = automatic
-    else FL_FAIL(FL_ERR_BAD_ARGUMENT, "unknown tuning key %s", key);
-    return FL_OK;
+    return guarded([&]() -> int {
+        if (!key || value < 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "bad tuning key/value");
+        if (!strcmp(key, "gemv_r")) gemv_set_tuning(value, 0, -1, -1);
+        else if (!strcmp(key, "gemv_u")) gemv_set_tuning(0, value, -1, -1);
+        else if (!strcmp(key, "gemv_blocks")) gemv_set_tuning(0, 0, value, -1);        // 0 = automatic
+        else if (!strcmp(key, "gemv_waves")) gemv_set_tuning(0, 0, -1, value);          // 0 = automatic
+        else FL_FAIL(FL_ERR_BAD_ARGUMENT, "unknown tuning key %s", key);
+        return FL_OK;
+    });
 }
 
 int fl_op_sample(const float *logits, int64_t V, const fl_sampling *sampling, int64_t n_draws, uint32_t *tokens_out) {
-    if (!logits || !sampling || !tokens_out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
-    if (V <= 0 || V > (1 << 24) || n_draws <= 0 || n_draws > (1 << 20)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "bad size");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FL_FAIL(FL_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU path");
-    FL_HIP(hipSetDevice(0));
-    struct Bufs { float *lg = 0, *sc = 0; StepState *st = 0; SampleState *ss = 0; uint32_t *out = 0; hipStream_t s = 0;
-                  ~Bufs() { (void)hipFree(lg); (void)hipFree(sc); (void)hipFree(st); (void)hipFree(ss); (void)hipFree(out); if (s) (void)hipStreamDestroy(s); } } B;
-    FL_HIP(hipStreamCreate(&B.s));
-    FL_HIP(hipMalloc((void **)&B.lg, (size_t)V * 4));
-    FL_HIP(hipMalloc((void **)&B.sc, (size_t)V * 4));
-    FL_HIP(hipMalloc((void **)&B.st, sizeof(StepState)));
-    FL_HIP(hipMalloc((void **)&B.ss, sizeof(SampleState)));
-    FL_HIP(hipMalloc((void **)&B.out, (size_t)n_draws * 4));
-    StepState st{}; st.eos = -1;
-    const SampleState ss = make_sampler(sampling);
-    FL_HIP(hipMemcpy(B.lg, logits, (size_t)V * 4, hipMemcpyHostToDevice));
-    FL_HIP(hipMemcpy(B.st, &st, sizeof st, hipMemcpyHostToDevice));
-    FL_HIP(hipMemcpy(B.ss, &ss, sizeof ss, hipMemcpyHostToDevice));
-    Launcher L; L.stream = B.s;
-    for (int64_t i = 0; i < n_draws; i++) FL_TRY(launch_select_advance(L, B.lg, V, B.st, B.ss, B.sc, B.out, 1));
-    FL_HIP(hipStreamSynchronize(B.s));
-    FL_HIP(hipMemcpy(tokens_out, B.out, (size_t)n_draws * 4, hipMemcpyDeviceToHost));
-    return FL_OK;
+    return guarded([&]() -> int {
+        if (!logits || !sampling || !tokens_out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+        if (V <= 0 || V > (1 << 24) || n_draws <= 0 || n_draws > (1 << 20)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "bad size");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FL_FAIL(FL_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU path");
+        FL_HIP(hipSetDevice(0));
+        struct Bufs { float *lg = 0, *sc = 0; StepState *st = 0; SampleState *ss = 0; uint32_t *out = 0; hipStream_t s = 0;
+                      ~Bufs() { (void)hipFree(lg); (void)hipFree(sc); (void)hipFree(st); (void)hipFree(ss); (void)hipFree(out); if (s) (void)hipStreamDestroy(s); } } B;
+        FL_HIP(hipStreamCreate(&B.s));
+        FL_HIP(hipMalloc((void **)&B.lg, (size_t)V * 4));
+        FL_HIP(hipMalloc((void **)&B.sc, (size_t)V * 4));
+        FL_HIP(hipMalloc((void **)&B.st, sizeof(StepState)));
+        FL_HIP(hipMalloc((void **)&B.ss, sizeof(SampleState)));
+        FL_HIP(hipMalloc((void **)&B.out, (size_t)n_draws * 4));
+        StepState st{}; st.eos = -1;
+        const SampleState ss = make_sampler(sampling);
+        FL_HIP(hipMemcpy(B.lg, logits, (size_t)V * 4, hipMemcpyHostToDevice));
+        FL_HIP(hipMemcpy(B.st, &st, sizeof st, hipMemcpyHostToDevice));
+        FL_HIP(hipMemcpy(B.ss, &ss, sizeof ss, hipMemcpyHostToDevice));
+        Launcher L; L.stream = B.s;
+        for (int64_t i = 0; i < n_draws; i++) FL_TRY(launch_select_advance(L, B.lg, V, B.st, B.ss, B.sc, B.out, 1));
+        FL_HIP(hipStreamSynchronize(B.s));
+        FL_HIP(hipMemcpy(tokens_out, B.out, (size_t)n_draws * 4, hipMemcpyDeviceToHost));
+        return FL_OK;
+    });
 }
 
 int fl_op_linear(const void *x, const void *w, const float *bias, int64_t T, int64_t N, int64_t K, int32_t dtype,
                  int32_t epilogue, float *y, int32_t iters, double *ms_out) {
-    if (!x || !w || !y) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
-    if (dtype != FL_DTYPE_BF16 && dtype != FL_DTYPE_F32) FL_FAIL(FL_ERR_UNSUPPORTED, "dtype must be bf16 or f32");
-    if (T <= 0 || N <= 0 || K <= 0 || K % 8) FL_FAIL(FL_ERR_BAD_ARGUMENT, "bad shape (K must be a multiple of 8)");
-    if (epilogue == EPI_GATEUP && (N % 2)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gate/up needs an even row count");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FL_FAIL(FL_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU path");
-    FL_HIP(hipSetDevice(0));
-    const size_t es = dtype == FL_DTYPE_BF16 ? 2 : 4;
-    const int64_t I = N / 2, Ip = (I + 15) / 16 * 16;
-    const int64_t Nw = epilogue == EPI_GATEUP ? 2 * Ip : N;          // rows of the device matrix
-    const int64_t Ny = epilogue == EPI_GATEUP ? Ip : N;              // columns of the device output
-    struct Bufs { void *x = 0, *w = 0, *ws = 0, *y = 0; float *b = 0; hipStream_t s = 0; hipEvent_t e0 = 0, e1 = 0;
-                  ~Bufs() { (void)hipFree(x); (void)hipFree(w); (void)hipFree(ws); (void)hipFree(y); (void)hipFree(b);
-                            if (s) (void)hipStreamDestroy(s);
-                            if (e0) (void)hipEventDestroy(e0);
-                            if (e1) (void)hipEventDestroy(e1); } } B;
-    FL_HIP(hipStreamCreate(&B.s));
-    FL_HIP(hipMalloc(&B.x, (size_t)T * K * es));
-    FL_HIP(hipMalloc(&B.w, (size_t)Nw * K * es));
-    const size_t ybytes = (size_t)T * Ny * (epilogue == EPI_GATEUP ? es : 4);
-    const int max_split = (epilogue == EPI_F32 && !bias) ? 4 : 1;      // exercise split-K where the model would
-    int nsplit = 1;
-    FL_HIP(hipMalloc(&B.y, ybytes * max_split));
-    FL_HIP(hipMemcpy(B.x, x, (size_t)T * K * es, hipMemcpyHostToDevice));
-    Launcher L; L.stream = B.s;
-    if (epilogue == EPI_GATEUP) {
-        FL_HIP(hipMalloc(&B.ws, (size_t)N * K * es));
-        FL_HIP(hipMemcpy(B.ws, w, (size_t)N * K * es, hipMemcpyHostToDevice));
-        FL_HIP(hipMemsetAsync(B.w, 0, (size_t)Nw * K * es, B.s));
-        FL_TRY(launch_convert_slice(L, dtype, B.ws, K, 0, 0, I, K, dtype, B.w, K, 0, 1));
-        FL_TRY(launch_convert_slice(L, dtype, B.ws, K, I, 0, I, K, dtype, B.w, K, 0, 2));
-    } else {
-        FL_HIP(hipMemcpy(B.w, w, (size_t)N * K * es, hipMemcpyHostToDevice));
-        if (bias) {
-            FL_HIP(hipMalloc((void **)&B.b, (size_t)N * 4));
-            FL_HIP(hipMemcpy(B.b, bias, (size_t)N * 4, hipMemcpyHostToDevice));
-        }
-    }
-    FL_TRY(launch_linear(L, dtype, B.w, B.x, B.b, B.y, T, Nw, K, epilogue, nullptr, max_split, &nsplit));
-    FL_HIP(hipStreamSynchronize(B.s));
-    if (iters > 0 && ms_out) {
-        FL_HIP(hipEventCreate(&B.e0)); FL_HIP(hipEventCreate(&B.e1));
-        FL_HIP(hipEventRecord(B.e0, B.s));
-        for (int i = 0; i < iters; i++) FL_TRY(launch_linear(L, dtype, B.w, B.x, B.b, B.y, T, Nw, K, epilogue, nullptr, max_split, &nsplit));
-        FL_HIP(hipEventRecord(B.e1, B.s));
-        FL_HIP(hipEventSynchronize(B.e1));
-        float ms = 0.f; FL_HIP(hipEventElapsedTime(&ms, B.e0, B.e1));
-        *ms_out = ms / iters;
-    }
-    if (epilogue == EPI_GATEUP) {
-        std::unique_ptr<unsigned char[]> tmp(new unsigned char[ybytes]);
-        FL_HIP(hipMemcpy(tmp.get(), B.y, ybytes, hipMemcpyDeviceToHost));
-        for (int64_t t = 0; t < T; t++)
-            for (int64_t j = 0; j < I; j++) {
-                const size_t idx = (size_t)t * Ip + j;
-                y[(size_t)t * I + j] = es == 2 ? bf16_bits_to_float(reinterpret_cast<bf16_t *>(tmp.get())[idx])
-                                               : reinterpret_cast<float *>(tmp.get())[idx];
-            }
-    } else {
-        FL_HIP(hipMemcpy(y, B.y, ybytes, hipMemcpyDeviceToHost));
-        if (nsplit > 1) {                                   // sum the split-K slabs in slab order, like rmsnorm_add does
-            std::unique_ptr<float[]> tmp(new float[(size_t)T * Ny]);
-            for (int sl = 1; sl < nsplit; sl++) {
-                FL_HIP(hipMemcpy(tmp.get(), (char *)B.y + (size_t)sl * ybytes, ybytes, hipMemcpyDeviceToHost));
-                for (size_t i = 0; i < (size_t)T * Ny; i++) y[i] += tmp[i];
+    return guarded([&]() -> int {
+        if (!x || !w || !y) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+        if (dtype != FL_DTYPE_BF16 && dtype != FL_DTYPE_F32) FL_FAIL(FL_ERR_UNSUPPORTED, "dtype must be bf16 or f32");
+        if (T <= 0 || N <= 0 || K <= 0 || K % 8) FL_FAIL(FL_ERR_BAD_ARGUMENT, "bad shape (K must be a multiple of 8)");
+        if (epilogue == EPI_GATEUP && (N % 2)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gate/up needs an even row count");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FL_FAIL(FL_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU path");
+        FL_HIP(hipSetDevice(0));
+        const size_t es = dtype == FL_DTYPE_BF16 ? 2 : 4;
+        const int64_t I = N / 2, Ip = (I + 15) / 16 * 16;
+        const int64_t Nw = epilogue == EPI_GATEUP ? 2 * Ip : N;          // rows of the device matrix
+        const int64_t Ny = epilogue == EPI_GATEUP ? Ip : N;              // columns of the device output
+        struct Bufs { void *x = 0, *w = 0, *ws = 0, *y = 0; float *b = 0; hipStream_t s = 0; hipEvent_t e0 = 0, e1 = 0;
+                      ~Bufs() { (void)hipFree(x); (void)hipFree(w); (void)hipFree(ws); (void)hipFree(y); (void)hipFree(b);
+                                if (s) (void)hipStreamDestroy(s);
+                                if (e0) (void)hipEventDestroy(e0);
+                                if (e1) (void)hipEventDestroy(e1); } } B;
+        FL_HIP(hipStreamCreate(&B.s));
+        FL_HIP(hipMalloc(&B.x, (size_t)T * K * es));
+        FL_HIP(hipMalloc(&B.w, (size_t)Nw * K * es));
+        const size_t ybytes = (size_t)T * Ny * (epilogue == EPI_GATEUP ? es : 4);
+        const int max_split = (epilogue == EPI_F32 && !bias) ? 4 : 1;      // exercise split-K where the model would
+        int nsplit = 1;
+        FL_HIP(hipMalloc(&B.y, ybytes * max_split));
+        FL_HIP(hipMemcpy(B.x, x, (size_t)T * K * es, hipMemcpyHostToDevice));
+        Launcher L; L.stream = B.s;
+        if (epilogue == EPI_GATEUP) {
+            FL_HIP(hipMalloc(&B.ws, (size_t)N * K * es));
+            FL_HIP(hipMemcpy(B.ws, w, (size_t)N * K * es, hipMemcpyHostToDevice));
+            FL_HIP(hipMemsetAsync(B.w, 0, (size_t)Nw * K * es, B.s));
+            FL_TRY(launch_convert_slice(L, dtype, B.ws, K, 0, 0, I, K, dtype, B.w, K, 0, 1));
+            FL_TRY(launch_convert_slice(L, dtype, B.ws, K, I, 0, I, K, dtype, B.w, K, 0, 2));
+        } else {
+            FL_HIP(hipMemcpy(B.w, w, (size_t)N * K * es, hipMemcpyHostToDevice));
+            if (bias) {
+                FL_HIP(hipMalloc((void **)&B.b, (size_t)N * 4));
+                FL_HIP(hipMemcpy(B.b, bias, (size_t)N * 4, hipMemcpyHostToDevice));
             }
         }
-    }
-    return FL_OK;
+        FL_TRY(launch_linear(L, dtype, B.w, B.x, B.b, B.y, T, Nw, K, epilogue, nullptr, max_split, &nsplit));
+        FL_HIP(hipStreamSynchronize(B.s));
+        if (iters > 0 && ms_out) {
+            FL_HIP(hipEventCreate(&B.e0)); FL_HIP(hipEventCreate(&B.e1));
+            FL_HIP(hipEventRecord(B.e0, B.s));
+            for (int i = 0; i < iters; i++) FL_TRY(launch_linear(L, dtype, B.w, B.x, B.b, B.y, T, Nw, K, epilogue, nullptr, max_split, &nsplit));
+            FL_HIP(hipEventRecord(B.e1, B.s));
+            FL_HIP(hipEventSynchronize(B.e1));
+            float ms = 0.f; FL_HIP(hipEventElapsedTime(&ms, B.e0, B.e1));
+            *ms_out = ms / iters;
+        }
+        if (epilogue == EPI_GATEUP) {
+            std::unique_ptr<unsigned char[]> tmp(new unsigned char[ybytes]);
+            FL_HIP(hipMemcpy(tmp.get(), B.y, ybytes, hipMemcpyDeviceToHost));
+            for (int64_t t = 0; t < T; t++)
+                for (int64_t j = 0; j < I; j++) {
+                    const size_t idx = (size_t)t * Ip + j;
+                    y[(size_t)t * I + j] = es == 2 ? bf16_bits_to_float(reinterpret_cast<bf16_t *>(tmp.get())[idx])
+                                                   : reinterpret_cast<float *>(tmp.get())[idx];
+                }
+        } else {
+            FL_HIP(hipMemcpy(y, B.y, ybytes, hipMemcpyDeviceToHost));
+            if (nsplit > 1) {                                   // sum the split-K slabs in slab order, like rmsnorm_add does
+                std::unique_ptr<float[]> tmp(new float[(size_t)T * Ny]);
+                for (int sl = 1; sl < nsplit; sl++) {
+                    FL_HIP(hipMemcpy(tmp.get(), (char *)B.y + (size_t)sl * ybytes, ybytes, hipMemcpyDeviceToHost));
+                    for (size_t i = 0; i < (size_t)T * Ny; i++) y[i] += tmp[i];
+                }
+            }
+        }
+        return FL_OK;
+    });
 }
 
 }  // extern "C"

@@ -20,6 +20,11 @@ const char *last_error();
     return (e_ == hipErrorOutOfMemory) ? FL_ERR_OOM : FL_ERR_HIP; } } while (0)
 #define FL_TRY(expr) do { int rc_ = (expr); if (rc_ != FL_OK) return rc_; } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to (function, device): raise it for `fn` on the CURRENT device when
+// a launch needs more than the 64 KiB default (remembered per pair; a single-process tensor-parallel group launches
+// the same instantiation on every GPU of the group).
+int raise_dynamic_lds(const void *fn, size_t lds_bytes);
+
 // ---- element types ------------------------------------------------------------------------
 typedef uint16_t bf16_t;   // raw bf16 bits in memory
 

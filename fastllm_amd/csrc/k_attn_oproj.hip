@@ -199,11 +199,7 @@ int launch_attn_oproj(Launcher &L, const void *q, const void *k_cache, const voi
     const double bytes = (double)h * H * d * 2 + 2.0 * (double)sc.kv_len_hint * Hkv * d * 2;
     const double flops = 2.0 * h * H * d + 4.0 * (double)sc.kv_len_hint * H * d;
     auto go = [&](auto kern) -> int {
-        static std::atomic<size_t> raised{0};
-        if (lds > 64 * 1024 && raised.load() < lds) {
-            FL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            raised.store(lds);
-        }
+        FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
         return L.launch(KC_ATTN_OPROJ, bytes, flops, kern, dim3((unsigned)nb), dim3(512), lds, a);
     };
     if (d == 128) return G <= 4 ? go(attn_oproj_kernel<128, 4>) : go(attn_oproj_kernel<128, 8>);

@@ -194,11 +194,7 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
     const int tiles_m = (int)((T + P_BM - 1) / P_BM), tiles_n = (int)((N + P_BN - 1) / P_BN);
     if (K % P_BK || K / P_BK / ksplit < 2) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: K must give at least two 64-wide tiles per slice");
     if (ksplit > 1 && (bias || epi != EPI_F32)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "split-K GEMM: fp32 epilogue without bias only");
-    static bool attr = false;
-    if (!attr) {
-        FL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_8p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
-        attr = true;
-    }
+    FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(gemm_8p_kernel), P_LDS));
     const double bytes = ((double)N * K + (double)T * K) * 2.0;
     char tag[32];
     snprintf(tag, sizeof tag, "8p,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");

@@ -326,12 +326,7 @@ int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bia
                                (int64_t)tm2 * tn2 * ksplit >= 224;
         if ((ksplit == 1 && (int64_t)tm2 * tn2 >= 1024) || one_round) {
             const size_t lds2 = 3 * (size_t)STAGE2;                     // 144 KiB
-            static bool attr2 = false;
-            if (!attr2) {
-                FL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_mfma256_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-                attr2 = true;
-            }
+            FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(gemm_mfma256_kernel), lds2));
             double bytes2 = ((double)N * K + (double)T * K) * 2.0;
             char tag2[32];
             snprintf(tag2, sizeof tag2, "256x128,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");
@@ -343,12 +338,7 @@ int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bia
     const int tiles_m = (int)((T + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
     if (ksplit > 1 && bias) FL_FAIL(FL_ERR_BAD_ARGUMENT, "split-K GEMM cannot add a bias");
     const size_t lds = 4 * TILE_BYTES;     // 64 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-        FL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_mfma_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(gemm_mfma_kernel), lds));
     double bytes = ((double)N * K + (double)T * K) * 2.0;
     char tag[32];
     snprintf(tag, sizeof tag, "128x128,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");

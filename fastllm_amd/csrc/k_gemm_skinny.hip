@@ -142,11 +142,7 @@ static int launch_skinny_t(Launcher &L, const void *W, const void *x, const floa
     constexpr int BN = NW * 16 * NT;
     constexpr size_t lds = (size_t)S_NSTG * (BM * 128 + BN * 128);
     auto kern = gemm_skinny_kernel<BM, NT, NW>;
-    static bool attr = false;
-    if (!attr && lds > 64 * 1024) {
-        FL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+    FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
     const double bytes = ((double)N * K + (double)T * K) * 2.0;
     char tag[32];
     snprintf(tag, sizeof tag, "skinny,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");

@@ -37,6 +37,7 @@
 namespace fl {
 
 constexpr int kGemvMaxThreads = 768;     // 12 waves: 170 VGPRs per lane available
+constexpr int kMaxDevices = 64;
 
 template <typename WT> struct RawChunk { uint4v v[sizeof(WT) == 2 ? 1 : 2]; };
 
@@ -377,12 +378,16 @@ bool gemv_supported(int dtype, int64_t N, int64_t K) {
 // smallest workgroup is 256 threads
 bool gemv_norm_supported(int dtype, int64_t N, int64_t K) { return gemv_supported(dtype, N, K) && K <= 6144; }
 
-static int cu_count() {
-    static int n = 0;
+static int cu_count() {                      // of the current device (the shards of a group may sit on different ones)
+    static std::atomic<int> cached[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+    int n = cached[dev].load();
     if (!n) {
-        int dev = 0; hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
         if (n <= 0) n = 256;
+        cached[dev].store(n);
     }
     return n;
 }
@@ -417,13 +422,7 @@ static void pick_geometry(int64_t ngroups, size_t lds_bytes, int *blocks_out, in
 template <typename WT, typename XT, int R, int U, int PRO, int MAXT, bool SMALL, int EPI, bool FUSE_AR = false>
 static int launch_gemv_ke(Launcher &L, const GemvArgs &a, int blocks, int waves, size_t lds) {
     auto kern = gemv_kernel<WT, XT, R, U, PRO, MAXT, SMALL, EPI, FUSE_AR>;
-    if (lds > 64 * 1024) {
-        static std::atomic<size_t> raised{0};      // per instantiation, process-wide
-        if (raised.load() < lds) {
-            FL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            raised.store(lds);
-        }
-    }
+    FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
     double bytes = (double)a.N * a.K * sizeof(WT);
     char tag[32];
     snprintf(tag, sizeof tag, "%dx%d%s%s", a.N, a.K, PRO == PRO_NORM ? ",norm" : "", a.epi == EPI_GATEUP ? ",glu" : (a.epi == EPI_QKV_ROPE ? ",rope" : ""));

@@ -583,13 +583,7 @@ static int launch_gemv_batch_e(Launcher &L, const GemvBatchArgs &a) {
     auto kern = gemv_batch_kernel<NB, PRO, EPI>;
     const int64_t per = (((a.K / 8) + a.nks - 1) / a.nks + 63) & ~(int64_t)63;
     const size_t lds = (size_t)NB * per * 8 * 2;
-    if (lds > 64 * 1024) {
-        static std::atomic<size_t> raised{0};
-        if (raised.load() < lds) {
-            FL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            raised.store(lds);
-        }
-    }
+    FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
     const int64_t ngroups = (a.N + kBR - 1) / kBR;
     const int nwv = kBThreads / 64;
     int blocks = (int)std::min<int64_t>((ngroups + nwv - 1) / nwv, std::max(1, cu_count_b() / a.nks));
@@ -611,13 +605,7 @@ static int launch_gemv_batch_mfma_e(Launcher &L, const GemvBatchArgs &a) {
     auto kern = gemv_batch_mfma_kernel<PRO, MU, MODE, EPI>;
     const int64_t per = (((a.K / 8) + a.nks - 1) / a.nks + 63) & ~(int64_t)63;
     const size_t lds = (size_t)8 * (per * 8 + 8) * 2 + (size_t)(8 * 2 * 256 + 2 * 256) * 4 + (MODE >= 2 ? 8 * 8192 : 0);
-    if (lds > 64 * 1024) {
-        static std::atomic<size_t> raised{0};
-        if (raised.load() < lds) {
-            FL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            raised.store(lds);
-        }
-    }
+    FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
     const int64_t nunits = (a.N + 31) / 32;
     const int blocks = (int)std::min<int64_t>(nunits, std::max(1, cu_count_b() / a.nks));
     char tag[32];

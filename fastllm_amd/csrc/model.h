@@ -80,6 +80,8 @@ struct Shard {
     float *logits_local = nullptr;   // [Vs]
     float *logits_full = nullptr;    // [V]
     std::vector<void *> allocs;
+    std::vector<void *> pre_allocs;  // the prefill scratch set: replaced (and freed) when a longer prompt arrives
+    int64_t pre_bytes = 0;
     ncclComm_t comm = nullptr;
     PeerComm pc;
 };
@@ -180,6 +182,7 @@ bool fused_all_reduce_ready(const Model *m);   // decode all-reduces ride in the
     ::fl::set_error("RCCL error %s at %s:%d (%s)", ncclGetErrorString(r_), __FILE__, __LINE__, #expr); \
     return FL_ERR_RCCL; } } while (0)
 int env_int(const char *name, int dflt);
+void debug_inject(const char *site);     // FL_DEBUG_THROW fault injection (tests of the ABI exception barrier)
 Launcher make_launcher(Model *m, Shard &sh);
 // comm.hip: inbox / LL region of one shard, its table entries, and the group-level steps
 int comm_alloc(Model *m, Shard &sh);

@@ -20,6 +20,8 @@
 
 #include <algorithm>
 #include <memory>
+#include <new>
+#include <stdexcept>
 
 namespace fl {
 
@@ -32,6 +34,33 @@ const char *last_error() { return g_err; }
 
 
 int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
+
+int raise_dynamic_lds(const void *fn, size_t lds) {
+    if (lds < 64 * 1024) return FL_OK;
+    static std::mutex mu;
+    static std::unordered_map<uint64_t, size_t> raised;           // (function, device) -> bytes granted
+    int dev = 0;
+    FL_HIP(hipGetDevice(&dev));
+    const uint64_t key = (uint64_t)(uintptr_t)fn * 64 + (uint64_t)(dev & 63);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = raised.find(key);
+    if (it != raised.end() && it->second >= lds) return FL_OK;
+    FL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    raised[key] = lds;
+    return FL_OK;
+}
+
+// Fault injection for the tests of the ABI's exception barrier: FL_DEBUG_THROW="<site>=<bad_alloc|runtime|int>"
+// makes the named site throw, as a failed `new` / std::vector growth would.
+void debug_inject(const char *site) {
+    const char *s = getenv("FL_DEBUG_THROW");
+    if (!s || !*s) return;
+    const size_t n = strlen(site);
+    if (strncmp(s, site, n) || s[n] != '=') return;
+    if (!strcmp(s + n + 1, "bad_alloc")) throw std::bad_alloc();
+    if (!strcmp(s + n + 1, "runtime")) throw std::runtime_error("injected failure");
+    throw 42;
+}
 struct PeerComm;
 
 // ------------------------------------------------------------------------------- config
@@ -96,7 +125,9 @@ int tp_slice(const Dims &D, const char *name_c, int rank, int tp, int64_t out[4]
 // ------------------------------------------------------------------------------- allocation
 static int dev_alloc(std::vector<void *> &owner, void **p, size_t bytes, int64_t *acct) {
     if (bytes == 0) bytes = 16;
-    FL_HIP(hipMalloc(p, bytes));
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); FL_FAIL(FL_ERR_OOM, "out of HBM: hipMalloc of %zu bytes failed", bytes); }
+    FL_HIP(e);
     owner.push_back(*p);
     if (acct) *acct += (int64_t)bytes;
     return FL_OK;
@@ -116,6 +147,7 @@ Model::~Model() {
         if (s.pc.ll_dev) (void)hipFree(s.pc.ll_dev);
         if (s.pc.err) (void)hipHostFree(s.pc.err);
         for (void *p : s.allocs) (void)hipFree(p);
+        for (void *p : s.pre_allocs) (void)hipFree(p);
         if (s.stream && std::find(closed.begin(), closed.end(), s.stream) == closed.end()) {
             closed.push_back(s.stream);
             (void)hipStreamDestroy(s.stream);
@@ -324,11 +356,10 @@ constexpr int kMaxQkvSplit = 2;   // QKV projection of a mid-size prompt (its gr
 // owner: who frees the buffers (default: the shard, i.e. at model destruction)
 static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T, std::vector<void *> *owner = nullptr) {
     std::vector<void *> &own = owner ? *owner : sh.allocs;
-    int64_t *acct = owner ? nullptr : &m->hbm_bytes;
+    int64_t *acct = (owner && owner != &sh.pre_allocs) ? nullptr : &m->hbm_bytes;
     const Dims &D = m->D;
     const size_t es = m->esize();
     const int64_t nq = (sh.Hs + 2 * sh.Hkvs) * D.d;
-    // grow-only; the previous buffers stay owned by the shard until the model dies (rare path)
     sc.cap_T = T;
     FL_TRY(dev_alloc(own, (void **)&sc.x_res, (size_t)T * D.h * 4, acct));
     if (T == 1) FL_TRY(dev_alloc(own, (void **)&sc.x_res2, (size_t)D.h * 4, acct));
@@ -343,6 +374,30 @@ static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T, std::vecto
     return FL_OK;
 }
 
+// The prefill scratch of a shard grows geometrically and the set it replaces is freed: every forward() ends with a
+// stream synchronisation, so under the model mutex the old buffers are idle (a long-running server that sees longer
+// and longer prompts would otherwise pile up one dead set per new maximum, ~180 KB per token for Mistral-7B).
+static int grow_prefill_scratch(Model *m, Shard &sh, int64_t T) {
+    const int64_t chunk_max = env_int("FL_PREFILL_CHUNK", 8192);
+    int64_t cap = std::max<int64_t>(T, std::min<int64_t>(chunk_max, sh.pre.cap_T + sh.pre.cap_T / 2));
+    cap = std::min<int64_t>(std::max<int64_t>(T, chunk_max), (cap + 127) / 128 * 128);
+    FL_HIP(hipStreamSynchronize(sh.stream));
+    if (sh.comm_stream) FL_HIP(hipStreamSynchronize(sh.comm_stream));
+    for (void *p : sh.pre_allocs) (void)hipFree(p);
+    sh.pre_allocs.clear();
+    m->hbm_bytes -= sh.pre_bytes;
+    sh.pre = Scratch{};
+    const int64_t before = m->hbm_bytes;
+    int rc = alloc_scratch(m, sh, sh.pre, cap, &sh.pre_allocs);
+    if (rc != FL_OK) {                                   // leave the shard without a prefill scratch rather than with half of one
+        for (void *p : sh.pre_allocs) (void)hipFree(p);
+        sh.pre_allocs.clear(); sh.pre = Scratch{}; sh.pre_bytes = 0; m->hbm_bytes = before;
+        return rc;
+    }
+    sh.pre_bytes = m->hbm_bytes - before;
+    return FL_OK;
+}
+
 int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int compute_dtype,
                  const fl_parallel *par, Model **out) {
     if (!out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null out pointer");
@@ -354,6 +409,7 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
     if (D.h % 8) FL_FAIL(FL_ERR_UNSUPPORTED, "hidden_size must be a multiple of 8 (16-byte rows)");
     if (D.d != 64 && D.d != 128) FL_FAIL(FL_ERR_UNSUPPORTED, "head_dim %lld not supported (64 or 128)", (long long)D.d);
     if (D.max_pos > (1 << 20)) D.max_pos = 1 << 20;
+    debug_inject("model_create");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -508,6 +564,7 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
 int cache_create(Model *m, size_t max_seq, Cache **out) {
     if (!m || !out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
     if (max_seq == 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "max_seq must be > 0");
+    debug_inject("cache_create");
     const Dims &D = m->D;
     std::unique_ptr<Cache> c(new Cache());
     c->m = m; c->max_seq = max_seq; c->len = 0;
@@ -1024,6 +1081,7 @@ static int check_call(Model *m, Cache *c, size_t T, size_t pos) {
 int forward(Model *m, Cache *c, const uint32_t *ids, size_t T, size_t pos, float *logits_out, uint32_t *token_out,
             const fl_sampling *sampling) {
     FL_TRY(check_call(m, c, T, pos));
+    debug_inject("forward");
     const SampleState sampler = make_sampler(sampling);
     if (!ids) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null ids");
     for (size_t t = 0; t < T; t++)
@@ -1043,7 +1101,7 @@ int forward(Model *m, Cache *c, const uint32_t *ids, size_t T, size_t pos, float
             if (T - done - (size_t)Tc == 1 && Tc > 2) Tc -= 1;      // never leave a 1-token tail (it would take the decode mask)
             for (auto &sh : m->shards) {
                 FL_HIP(hipSetDevice(sh.device));
-                if (sh.pre.cap_T < Tc) FL_TRY(alloc_scratch(m, sh, sh.pre, Tc));
+                if (sh.pre.cap_T < Tc) FL_TRY(grow_prefill_scratch(m, sh, Tc));
                 FL_HIP(hipMemcpyAsync(sh.pre.ids, ids + done, (size_t)Tc * 4, hipMemcpyHostToDevice, sh.stream));
             }
             FL_TRY(set_state(m, c, ids[done], pos + done, c->len, 0, -1, call0, &sampler));
@@ -1083,8 +1141,13 @@ int decode_greedy(Model *m, Cache *c, uint32_t first, size_t pos, size_t n_steps
     Shard &s0 = m->shards[0];
     size_t done = 0;
     uint32_t tok = first;
+    // With an EOS id the host looks at the tokens between chunks of 16, 32, ... 256 steps: the reference's loop breaks at
+    // the first EOS (mod.rs:431-436), and a request that ends after 20 tokens must not pay for n_steps forwards.  Without
+    // one, a chunk is as long as the token buffer allows (one sync per 4096 steps).
+    size_t chunk = eos >= 0 ? 16 : kOutTokensCap;
     while (done < n_steps) {
-        const size_t nb = std::min(n_steps - done, kOutTokensCap);
+        const size_t nb = std::min(n_steps - done, chunk);
+        if (eos >= 0) chunk = std::min<size_t>(chunk * 2, 256);
         FL_TRY(set_state(m, c, tok, pos + done, c->len, 0, eos, (size_t)-1, done == 0 ? &sampler : nullptr));
         for (size_t i = 0; i < nb; i++) FL_TRY(decode_step(m, c, (int64_t)(c->len + i)));
         FL_HIP(hipSetDevice(s0.device));

@@ -14,7 +14,8 @@
  *
  * Conventions
  *   - every entry returns an fl_status (0 = OK, negative = error); fl_last_error() gives a
- *     thread-local message (anyhow::Error analogue).  Nothing aborts or throws across the ABI.
+ *     thread-local message (anyhow::Error analogue).  Nothing aborts or throws across the ABI: every
+ *     entry is an exception barrier (std::bad_alloc -> FL_ERR_OOM, anything else -> FL_ERR_HIP).
  *   - plain pointers and sizes only; opaque handles for model and cache.
  *   - thread-safe: any number of threads may call fl_forward on ONE model with DISTINCT caches
  *     (the reference's streaming path does that, mod.rs:137-238); submission is serialised
@@ -32,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FL_ABI_VERSION 1
+#define FL_ABI_VERSION 2
 
 typedef enum fl_status {
     FL_OK = 0,
@@ -159,6 +160,8 @@ typedef struct fl_model_info {
     int64_t hbm_bytes_allocated;    /* this process, all shards */
     int32_t small_collectives;      /* decode collectives: 0 none (tp 1), 1 RCCL, 2 one-shot peer inboxes, 3 local (emulated) */
     int32_t fused_all_reduce;       /* 1: decode all-reduces ride in the o_proj / down_proj GEMV epilogues (no kernel of their own) */
+    int32_t rccl_ranks;             /* ncclCommCount of this rank's RCCL communicator; 0: no communicator (tp 1, emulated, IPC-only groups) */
+    int32_t _reserved;
 } fl_model_info;
 int fl_model_get_info(const fl_model *m, fl_model_info *out);
 

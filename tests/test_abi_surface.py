@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported(fa):
     out = subprocess.check_output(["nm", "-D", "--defined-only", fa.binding.LIB_PATH], text=True)
     exported = set(re.findall(r" T (fl_[a-z_0-9]+)", out))
     assert set(names) <= exported
-    assert fa.abi_version() == 1
+    assert fa.abi_version() == 2
 
 
 def test_library_contains_gfx950_code_objects(fa):
@@ -113,3 +113,30 @@ def test_algorithmic_bytes_formula(fa):
     assert decode_bytes_per_token(MODEL_CONFIGS["mistral-7b"], 1) - decode_bytes_per_token(MODEL_CONFIGS["mistral-7b"], 0) == 131072
     assert abs(prefill_flops(MODEL_CONFIGS["mistral-7b"], 512) / 1e12 - 7.216) < 0.01
     assert abs(prefill_flops(MODEL_CONFIGS["qwen2-7b"], 4096) / 1e12 - 56.82) < 0.05
+
+
+def test_exception_barrier_at_the_abi(fa, monkeypatch):
+    """Nothing throws across the C ABI (the host is Rust: an unwinding C++ exception there is UB; the reference
+    surfaces failures as anyhow::Error, mod.rs:402-405).  FL_DEBUG_THROW makes model_create throw where a failed
+    `new` / container growth would: bad_alloc -> FL_ERR_OOM, anything else -> FL_ERR_HIP, message set, process alive."""
+    cfg = synth.CONFIGS["llama_a"]
+    for kind, code, text in (("bad_alloc", -4, "bad_alloc"), ("runtime", -5, "injected failure"), ("int", -5, "unknown C++ exception")):
+        monkeypatch.setenv("FL_DEBUG_THROW", "model_create=" + kind)
+        with pytest.raises(fa.FastLLMError) as e:
+            fa.Model(cfg, {})
+        assert e.value.code == code and text in str(e.value), (kind, str(e.value))
+    monkeypatch.setenv("FL_DEBUG_THROW", "cache_create=bad_alloc")     # another site's name: model_create is unaffected
+    with pytest.raises(fa.FastLLMError) as e:
+        fa.Model(cfg, {})
+    assert e.value.code in (-9, -2)                                     # no device here / no tensors on a GPU box
+    monkeypatch.delenv("FL_DEBUG_THROW")
+
+
+def test_null_out_pointers_are_rejected(fa):
+    L = fa.lib()
+    b = fa.binding
+    c = b.FlConfig()
+    assert L.fl_model_create(C.byref(c), None, 0, 1, None, None) == -8      # FL_ERR_BAD_ARGUMENT, not a segfault
+    assert b"null out" in L.fl_last_error()
+    assert L.fl_cache_create(None, 16, None) == -8
+    assert L.fl_device_count(None) == -8
