@@ -276,6 +276,8 @@ def main():
         try:
             hp = np.random.RandomState(7).randint(0, cfg["vocab_size"], size=max(T, 8)).astype(np.uint32)
             hc = model.new_cache(len(hp) + 16)
+            if level == 0 and rank == world - 1 and os.environ.get("FL_BENCH_INJECT_LEVEL0_FAILURE") == "1":
+                raise RuntimeError("injected health-check failure (test of the fallback path)")
             hf = model.forward_argmax(hc, hp, 0)
             model.decode_greedy(hc, hf, len(hp), 4)
             model.synchronize()

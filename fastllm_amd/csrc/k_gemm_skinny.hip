@@ -19,13 +19,18 @@
 namespace fl {
 
 typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
-constexpr int S_BK = 64, S_NSTG = 4;
+constexpr int S_BK = 64;
 // (BM = 256 with three stages was tried for 128 < T <= 256: 9.6 ms vs 8.9 ms for the 128x128 kernel on the
 // Mistral-7B prefill -- the X tile, re-read by every workgroup, then costs more than the stream gains.)
 
 __device__ inline void glds16s(const void *g, unsigned char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+// non-temporal form for the weight strip: every byte is read once by one CU (cdna guide, nt-weights)
+__device__ inline void glds16s_nt(const void *g, unsigned char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 2);
 }
 __device__ inline bf16x8s frag_s(const unsigned char *tile, int row, int chunk) {
     return *reinterpret_cast<const bf16x8s *>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
@@ -35,21 +40,34 @@ __device__ inline bf16x8s frag_s(const unsigned char *tile, int row, int chunk) 
 // limit), but the 128x128 kernel is then faster: Mistral-7B prefill T = 256 9.8 vs 9.2 ms, T = 512 18.3 vs 11.7 ms
 static const int kSkinnyMaxT = getenv("FL_GEMM_SKINNY_MAXT") ? atoi(getenv("FL_GEMM_SKINNY_MAXT")) : 128;
 
-template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ inline void wait_vmcnt() {
+    static_assert(N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// the last tiles of a K loop: `younger` (0 .. MAXY) tiles of PW loads each may stay outstanding
+template <int MAXY, int PW> __device__ inline void wait_tail(int younger) {
+    if constexpr (MAXY <= 0) { wait_vmcnt<0>(); }
+    else { if (younger >= MAXY) wait_vmcnt<MAXY * PW>(); else wait_tail<MAXY - 1, PW>(younger); }
+}
 
-// BM tokens x (NW * 16 * NT) weight rows per workgroup of NW waves; NT n-tiles of 16 rows per wave
-template <int BM, int NT, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
+// BM tokens x (NW * 16 * NT) weight rows per workgroup of NWM x NW waves; NT n-tiles of 16 rows per wave column; with
+// NWM = 2 the token tiles are split over two wave rows (8 waves, two per SIMD): an LDS-DMA instruction costs its wave
+// ~100 cycles of issue, so at BM = 128 (32 KB per K tile = 8 instructions per wave of a 4-wave workgroup) staging, not
+// the MFMAs or HBM, set the pace; eight waves halve it and let one wave's MFMAs run under its SIMD partner's issue.
+template <int BM, int NT, int NW, int S_NSTG, bool WNT, int NWM>
+__global__ __launch_bounds__(NW * NWM * 64) void gemm_skinny_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
                                                           const float *__restrict__ bias, void *__restrict__ out,
                                                           int T, int N, int K, int epi, const float *__restrict__ row_scale,
                                                           int ksplit) {
-    constexpr int BN = NW * 16 * NT, MT = BM / 16;
+    constexpr int BN = NW * 16 * NT, MT = BM / 16 / NWM;         // MT: token tiles per wave
     constexpr int XB = BM * 128, STG = XB + BN * 128;             // bytes per stage
     constexpr int NI = (BM + BN) / 8;                              // 1 KiB DMA instructions per stage
-    constexpr int PW = NI / NW;                                    // ... per wave
-    static_assert(NI % NW == 0, "stage instructions must divide evenly over the waves");
+    constexpr int PW = NI / (NW * NWM);                            // ... per wave
+    static_assert(NI % (NW * NWM) == 0, "stage instructions must divide evenly over the waves");
+    static_assert(BM % (16 * NWM) == 0, "token tiles must divide over the wave rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
+    const int wave = wave_all % NW, wm = wave_all / NW;          // wave column (W rows) / wave row (token tiles)
     const int m16 = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.z * BM;       // blockIdx.z: token block (T > BM: W strips are re-read through L2)
     const int nk_all = K / S_BK, kz = blockIdx.y;
@@ -67,14 +85,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t *__re
         unsigned char *base = lds + (kt % S_NSTG) * STG;
 #pragma unroll
         for (int s = 0; s < PW; s++) {
-            const int q = wave * PW + s;                           // instruction index: 8 rows each
+            const int q = wave_all * PW + s;                       // instruction index: 8 rows each
             const int rb = q * 8, r = rb + (lane >> 3), pc = lane & 7, c = pc ^ ((r >> 1) & 7);
             if (rb < BM) {                                         // X rows (uniform per instruction)
                 int gr = m0 + r; if (gr > T - 1) gr = T - 1;
                 glds16s(X + (size_t)gr * K + kt * S_BK + c * 8, base + rb * 128);
             } else {
                 int gr = n0 + r - BM; if (gr > N - 1) gr = N - 1;
-                glds16s(W + (size_t)gr * K + kt * S_BK + c * 8, base + rb * 128);
+                if constexpr (WNT) glds16s_nt(W + (size_t)gr * K + kt * S_BK + c * 8, base + rb * 128);
+                else glds16s(W + (size_t)gr * K + kt * S_BK + c * 8, base + rb * 128);
             }
         }
     };
@@ -83,10 +102,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t *__re
     for (int p = 0; p < S_NSTG - 1; p++)
         if (p < nk) stage(p);
     for (int kt = 0; kt < nk; kt++) {
-        // tile kt has landed for this wave when at most the two younger tiles' loads are outstanding
-        if (kt + 2 < nk) wait_vmcnt<2 * PW>();
-        else if (kt + 1 < nk) wait_vmcnt<PW>();
-        else wait_vmcnt<0>();
+        // tile kt has landed for this wave when at most the S_NSTG - 2 younger tiles' loads are outstanding
+        {
+            const int younger = nk - 1 - kt;                     // tiles staged after kt (wave-uniform)
+            if (younger >= S_NSTG - 2) wait_vmcnt<(S_NSTG - 2) * PW>();
+            else wait_tail<S_NSTG - 3, PW>(younger);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // everyone's tile kt landed; slot (kt+3)%4 is free
         if (kt + S_NSTG - 1 < nk) stage(kt + S_NSTG - 1);
@@ -99,7 +120,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t *__re
             for (int j = 0; j < NT; j++) b[j] = frag_s(wt, wave * 16 * NT + j * 16 + m16, chunk);
 #pragma unroll
             for (int i = 0; i < MT; i++) {
-                const bf16x8s a = frag_s(xt, i * 16 + m16, chunk);
+                const bf16x8s a = frag_s(xt, (wm * MT + i) * 16 + m16, chunk);
 #pragma unroll
                 for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
             }
@@ -112,7 +133,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t *__re
     for (int i = 0; i < MT; i++) {
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
-            const int m = m0 + i * 16 + rm + rg;
+            const int m = m0 + (wm * MT + i) * 16 + rm + rg;
             if (m >= T) continue;
             const float rs = row_scale ? row_scale[m] : 1.0f;
             if (epi == EPI_GATEUP) {
@@ -136,19 +157,50 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t *__re
     }
 }
 
-template <int BM, int NT, int NW>
-static int launch_skinny_t(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
+template <int BM, int NT, int NW, int NSTG, bool WNT, int NWM>
+static int launch_skinny_s(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
                            int epi, const float *row_scale, int ksplit) {
     constexpr int BN = NW * 16 * NT;
-    constexpr size_t lds = (size_t)S_NSTG * (BM * 128 + BN * 128);
-    auto kern = gemm_skinny_kernel<BM, NT, NW>;
+    constexpr size_t lds = (size_t)NSTG * (BM * 128 + BN * 128);
+    static_assert(lds <= 160 * 1024, "LDS ring exceeds the CU");
+    static_assert((NSTG - 2) * ((BM + BN) / 8 / (NW * NWM)) < 64, "vmcnt field");
+    auto kern = gemm_skinny_kernel<BM, NT, NW, NSTG, WNT, NWM>;
     FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
     const double bytes = ((double)N * K + (double)T * K) * 2.0;
     char tag[32];
     snprintf(tag, sizeof tag, "skinny,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");
     Launcher LL = L; LL.tag = tag;
-    return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, dim3((unsigned)((N + BN - 1) / BN), (unsigned)ksplit, (unsigned)((T + BM - 1) / BM)), dim3(NW * 64), lds,
+    return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, dim3((unsigned)((N + BN - 1) / BN), (unsigned)ksplit, (unsigned)((T + BM - 1) / BM)), dim3(NW * NWM * 64), lds,
                      (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, row_scale, ksplit);
+}
+
+// ring depth: FL_SKINNY_STAGES (default 4; deeper rings measured SLOWER: profiles/r02/README.md); FL_SKINNY_NT: non-temporal
+// weight loads for T <= 32 (-5..10 % there, +3..8 % at T = 128); FL_SKINNY_WM: two wave rows for BM >= 64
+static const int kSkinnyStages = getenv("FL_SKINNY_STAGES") ? atoi(getenv("FL_SKINNY_STAGES")) : 4;
+static const int kSkinnyNt = getenv("FL_SKINNY_NT") ? atoi(getenv("FL_SKINNY_NT")) : 1;
+static const int kSkinnyWm = getenv("FL_SKINNY_WM") ? atoi(getenv("FL_SKINNY_WM")) : 1;
+
+template <int BM, int NT, int NW>
+static int launch_skinny_t(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
+                           int epi, const float *row_scale, int ksplit) {
+    constexpr int BN = NW * 16 * NT, STG = (BM + BN) * 128, PW = (BM + BN) / 8 / NW;
+    // deepest ring: LDS (<= 152 KB) and the 6-bit vmcnt field
+    constexpr int kFit = 152 * 1024 / STG, kCnt = 63 / PW + 2;
+    constexpr int kDeep = kFit < kCnt ? (kFit < 12 ? kFit : 12) : (kCnt < 12 ? kCnt : 12);
+    const bool nt = (kSkinnyNt == 1 && T <= 32) || kSkinnyNt == 2;
+    if constexpr (BM >= 64 && NW == 4) {
+        if (kSkinnyWm) {
+            return nt ? launch_skinny_s<BM, NT, NW, 4, true, 2>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)
+                      : launch_skinny_s<BM, NT, NW, 4, false, 2>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
+        }
+    }
+    if constexpr (kDeep > 4 && BM <= 32) {
+        if (kSkinnyStages > 4)
+            return nt ? launch_skinny_s<BM, NT, NW, kDeep, true, 1>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)
+                      : launch_skinny_s<BM, NT, NW, kDeep, false, 1>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
+    }
+    return nt ? launch_skinny_s<BM, NT, NW, 4, true, 1>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)
+              : launch_skinny_s<BM, NT, NW, 4, false, 1>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
 }
 
 bool gemm_skinny_supported(int64_t T, int64_t N, int64_t K) { return T > 1 && T <= kSkinnyMaxT && K % S_BK == 0 && K / S_BK >= 4 && N >= 64; }

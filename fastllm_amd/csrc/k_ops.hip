@@ -169,7 +169,7 @@ int launch_embed_batch(Launcher &L, const void *E, const SeqRef *seqs_dev, float
 __global__ __launch_bounds__(256) void rope_kv_batch_kernel(const float *__restrict__ qkv, const SeqRef *__restrict__ seqs,
                                                             const float *__restrict__ cos_tab, const float *__restrict__ sin_tab,
                                                             int max_pos, bf16_t *__restrict__ q_out, size_t kv_layer_off, int B,
-                                                            int H, int Hkv, int d) {
+                                                            int H, int Hkv, int d, int n_slab, const float *__restrict__ bias) {
     const int half = d >> 1;
     const int nheads = H + 2 * Hkv;
     const int per_t = nheads * half;
@@ -179,7 +179,12 @@ __global__ __launch_bounds__(256) void rope_kv_batch_kernel(const float *__restr
     const int hd = rem / half, j = rem % half;
     const SeqRef &sq = seqs[b];
     const float *src = qkv + (size_t)b * nheads * d + (size_t)hd * d;
-    const float a = src[j], bb = src[j + half];
+    float a = src[j], bb = src[j + half];
+    for (int s = 1; s < n_slab; s++) {                    // K slices of the projection, summed in slab order
+        const float *ss = src + (size_t)s * B * nheads * d;
+        a += ss[j]; bb += ss[j + half];
+    }
+    if (bias) { a += bias[hd * d + j]; bb += bias[hd * d + j + half]; }
     const uint32_t pos = sq.st->pos, slot = sq.st->len;
     const size_t sa = (size_t)sq.seq_alloc;
     if (hd < H + Hkv) {
@@ -196,10 +201,11 @@ __global__ __launch_bounds__(256) void rope_kv_batch_kernel(const float *__restr
 }
 
 int launch_rope_kv_batch(Launcher &L, const float *qkv, const SeqRef *seqs_dev, const float *cos_tab, const float *sin_tab,
-                         int64_t max_pos, void *q_out, size_t kv_layer_off, int B, int64_t H, int64_t Hkv, int64_t d) {
+                         int64_t max_pos, void *q_out, size_t kv_layer_off, int B, int64_t H, int64_t Hkv, int64_t d, int n_slab,
+                         const float *bias) {
     const int64_t total = (int64_t)B * (H + 2 * Hkv) * (d / 2);
     return L.launch(KC_ROPE_KV, (double)B * (H + 2 * Hkv) * d * 6, 0, rope_kv_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
-                    0, qkv, seqs_dev, cos_tab, sin_tab, (int)max_pos, (bf16_t *)q_out, kv_layer_off, B, (int)H, (int)Hkv, (int)d);
+                    0, qkv, seqs_dev, cos_tab, sin_tab, (int)max_pos, (bf16_t *)q_out, kv_layer_off, B, (int)H, (int)Hkv, (int)d, n_slab, bias);
 }
 
 // ------------------------------------------------------------------------------- token selection + advance

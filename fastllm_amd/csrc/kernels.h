@@ -89,6 +89,7 @@ struct GemvBatchArgs {
     void *out = nullptr;            // EPI_F32: float [nks][B][N]; EPI_GATEUP: bf16 [B][N/2]
     int N = 0, K = 0, epi = EPI_F32, pro = PRO_X, B = 1, nks = 1;
     const void *x = nullptr;        // PRO_X: bf16 [B][K]
+    const float *x_scale = nullptr; // PRO_X (k_gemv_dma.hip): optional [B] factors applied to the accumulators (1/rms of a separate norm)
     // PRO_NORM: x[b] = rmsnorm(x_in[b] + sum_s delta[s][b]) * norm_w, or of the embedding row of seqs[b].st->token
     const float *x_in = nullptr, *delta = nullptr, *norm_w = nullptr;
     int n_slab = 1; long long slab_stride = 0;
@@ -104,12 +105,19 @@ struct GemvBatchArgs {
 };
 int gemv_batch_ksplit(int B, int64_t K, int64_t N, int epi);
 int launch_gemv_batch(Launcher &L, const GemvBatchArgs &a);
+// the same projections with the weights streamed by LDS-DMA into wave-private rings (k_gemv_dma.hip; 3 <= B <= 8)
+bool gemv_dma_supported(int B, int64_t N, int64_t K, int epi, int d);
+int gemv_dma_ksplit(int64_t K, int64_t N, int epi);
+int launch_gemv_dma(Launcher &L, const GemvBatchArgs &a);
 // q / out bf16 [B][H*d]; kv_layer_off = layer * Hkv * d (times each sequence's seq_alloc inside)
 int launch_attn_decode_mfma_batch(Launcher &L, const void *q, const SeqRef *seqs_dev, int B, int max_nsplit, size_t kv_layer_off,
                                   void *out, int64_t H, int64_t Hkv, int64_t d, float scale, double kv_bytes_hint);
 int launch_embed_batch(Launcher &L, const void *E, const SeqRef *seqs_dev, float *x_res, int B, int64_t h);
+// n_slab: K slices of the QKV projection ([n_slab][B][(H+2Hkv)*d] fp32, summed here); bias: added here (a K-sliced
+// projection cannot add it itself) or null
 int launch_rope_kv_batch(Launcher &L, const float *qkv, const SeqRef *seqs_dev, const float *cos_tab, const float *sin_tab,
-                         int64_t max_pos, void *q_out, size_t kv_layer_off, int B, int64_t H, int64_t Hkv, int64_t d);
+                         int64_t max_pos, void *q_out, size_t kv_layer_off, int B, int64_t H, int64_t Hkv, int64_t d, int n_slab = 1,
+                         const float *bias = nullptr);
 // logits fp32 [B][V] -> every sequence's token / step state
 int launch_select_advance_batch(Launcher &L, const float *logits, int64_t V, const SeqRef *seqs_dev, int B, int advance);
 

@@ -144,6 +144,7 @@ struct Batch {
     Model *m = nullptr;
     std::vector<Cache *> caches;
     int B = 0, max_nsplit = 1, nks_o = 1, nks_down = 1;
+    bool dma = false;                            // B >= 3: projections on the LDS-DMA ring kernel (k_gemv_dma.hip)
     bool unfused = false;                        // large B: norm / GEMM / RoPE as separate launches around the short-prompt GEMM
     Scratch sc;                                  // ... with the prefill scratch layout at T = B
     SeqRef *seqs_dev = nullptr;

@@ -352,6 +352,8 @@ static int build_rope(Model *m) {
 
 constexpr int kMaxKSplit = 4;
 constexpr int kMaxQkvSplit = 2;   // QKV projection of a mid-size prompt (its grid leaves CUs idle); rope_kv sums the slabs
+constexpr int kMaxQkvSplitShort = 4;   // ... of a short prompt / a decode batch (T <= 128: the projection is a weight stream)
+static int qkv_split_cap(int64_t T) { return T <= 1 ? 1 : (T <= 128 ? kMaxQkvSplitShort : kMaxQkvSplit); }
 
 // owner: who frees the buffers (default: the shard, i.e. at model destruction)
 static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T, std::vector<void *> *owner = nullptr) {
@@ -366,7 +368,7 @@ static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T, std::vecto
     FL_TRY(dev_alloc(own, (void **)&sc.delta, (size_t)T * D.h * 4 * (T > 1 ? kMaxKSplit : 1), acct));   // split-K slabs
     FL_TRY(dev_alloc(own, &sc.xn, (size_t)T * D.h * es, acct));
     FL_TRY(dev_alloc(own, (void **)&sc.inv_rms, (size_t)T * 4, acct));
-    FL_TRY(dev_alloc(own, (void **)&sc.qkv, (size_t)T * nq * 4 * (T > 1 ? kMaxQkvSplit : 1), acct));    // split-K slabs
+    FL_TRY(dev_alloc(own, (void **)&sc.qkv, (size_t)std::max<int64_t>(T * qkv_split_cap(T), std::min<int64_t>(T, 128) * kMaxQkvSplitShort) * nq * 4, acct));    // split-K slabs of any prompt <= T
     FL_TRY(dev_alloc(own, &sc.q, (size_t)T * sh.Hs * D.d * es, acct));
     FL_TRY(dev_alloc(own, &sc.ao, (size_t)T * sh.Hs * D.d * es, acct));
     FL_TRY(dev_alloc(own, &sc.act, (size_t)T * sh.Ip * es, acct));
@@ -937,8 +939,9 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             void *kc = (char *)cs.k + kv_layer, *vc = (char *)cs.v + kv_layer;
             FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, l == 0 ? nullptr : sc.delta, ly.ln1, D.eps, sc.xn, sc.inv_rms, T, D.h, nslab, slab));
             int qkv_slabs = 1;
-            static const int qkv_split = env_int("FL_QKV_SPLIT", kMaxQkvSplit);
-            FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, ly.bqkv, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms, T > 1 ? std::min(qkv_split, kMaxQkvSplit) : 1, &qkv_slabs));
+            static const int qkv_split = env_int("FL_QKV_SPLIT", kMaxQkvSplitShort);
+            FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, ly.bqkv, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms,
+                                 std::min(qkv_split, qkv_split_cap(T)), &qkv_slabs));
             const int64_t sa = (int64_t)c->seq_alloc;
             FL_TRY(launch_rope_kv(L, dt, sc.qkv, cs.st, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, kc, vc, T, sh.Hs, sh.Hkvs, D.d, sa, c->v_transposed, qkv_slabs));
             if (T == 1) {
@@ -1203,6 +1206,9 @@ int batch_create(Model *m, Cache *const *caches, size_t B, Batch **out) {
     std::lock_guard<std::mutex> lock(m->mu);
     b->m = m; b->B = (int)B;
     b->caches.assign(caches, caches + B);
+    // B >= 3: the prefill-shaped step (separate norm / RoPE launches) with the wide projections on the LDS-DMA ring kernel
+    b->dma = B >= (size_t)env_int("FL_BATCH_DMA_MIN", 3) && gemv_dma_supported((int)B, 2 * sh.Ip, D.h, EPI_GATEUP, 0) &&
+             gemv_dma_supported((int)B, D.V, D.h, EPI_F32, 0) && gemv_dma_ksplit(D.h, 0, EPI_GATEUP) == 1;
     b->nks_o = gemv_batch_ksplit((int)B, sh.Hs * D.d, D.h, EPI_F32);
     b->nks_down = gemv_batch_ksplit((int)B, sh.Ip, D.h, EPI_F32);
     if (gemv_batch_ksplit((int)B, D.h, 2 * sh.Ip, EPI_GATEUP) != 1) FL_FAIL(FL_ERR_UNSUPPORTED, "hidden size %lld too large for the batched norm prologue", (long long)D.h);
@@ -1227,7 +1233,7 @@ int batch_create(Model *m, Cache *const *caches, size_t B, Batch **out) {
     // B >= 7: every projection through the short-prompt GEMM with the norm and RoPE / KV append as their own small
     // launches, i.e. the prefill pipeline at T = B with per-sequence positions and caches.  Measured (Mistral-7B,
     // ms per step, unfused vs fused): B = 3 4.16 / 3.87, 4 4.21 / 3.99, 6 4.24 / 4.18, 8 4.26 / 4.38
-    b->unfused = B >= (size_t)env_int("FL_BATCH_UNFUSED_MIN", 7) && gemm_skinny_supported((int64_t)B, D.h, D.h) &&
+    b->unfused = B >= (size_t)env_int("FL_BATCH_UNFUSED_MIN", b->dma ? 3 : 7) && gemm_skinny_supported((int64_t)B, D.h, D.h) &&
                  gemm_skinny_supported((int64_t)B, D.h, sh.Ip);
     if (b->unfused) {
         FL_TRY(alloc_scratch(m, sh, b->sc, (int64_t)B, &b->allocs));
@@ -1294,23 +1300,34 @@ static int enqueue_batch_step_unfused(Batch *b) {
     const int dt = m->dtype, B = b->B;
     const int64_t T = B, slab = T * D.h;
     int nslab = 1;
+    // the two wide projections (gate/up, lm_head: thousands of 16-row units) stream fastest through the LDS-DMA ring kernel;
+    // the narrow ones (QKV, o_proj, down_proj: one or two units per CU) through K slices of the short-prompt GEMM
+    auto wide = [&](const void *W, void *out, int64_t N, int epi) -> int {
+        if (!b->dma) return launch_linear(L, dt, W, sc.xn, nullptr, out, T, N, D.h, epi, sc.inv_rms);
+        GemvBatchArgs ga;
+        ga.W = W; ga.x = sc.xn; ga.x_scale = sc.inv_rms; ga.out = out; ga.N = (int)N; ga.K = (int)D.h; ga.epi = epi; ga.pro = PRO_X; ga.B = B; ga.nks = 1;
+        return launch_gemv_dma(L, ga);
+    };
     FL_TRY(launch_embed_batch(L, sh.embed, b->seqs_dev, sc.x_res, B, D.h));
     for (int64_t l = 0; l < D.L; l++) {
         LayerW &ly = sh.layers[l];
         const int64_t nq = (sh.Hs + 2 * sh.Hkvs) * D.d;
         FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, l == 0 ? nullptr : sc.delta, ly.ln1, D.eps, sc.xn, sc.inv_rms, T, D.h, nslab, slab));
-        FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, ly.bqkv, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms));
+        // K slices for the QKV stream too (96 strips of 64 rows otherwise: a third of the chip); the bias, if any, moves
+        // into the RoPE launch, which sums the slabs anyway
+        int qkv_slabs = 1;
+        FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, nullptr, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms, kMaxQkvSplitShort, &qkv_slabs));
         FL_TRY(launch_rope_kv_batch(L, sc.qkv, b->seqs_dev, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, (size_t)l * sh.Hkvs * D.d, B, sh.Hs,
-                                    sh.Hkvs, D.d));
+                                    sh.Hkvs, D.d, qkv_slabs, ly.bqkv));
         FL_TRY(launch_attn_decode_mfma_batch(L, sc.q, b->seqs_dev, B, b->max_nsplit, (size_t)l * sh.Hkvs * D.d, sc.ao, sh.Hs, sh.Hkvs,
                                              D.d, D.scale, 0.0));
         FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, T, D.h, sh.Hs * D.d, EPI_F32, nullptr, kMaxKSplit, &nslab));
         FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, sc.delta, ly.ln2, D.eps, sc.xn, sc.inv_rms, T, D.h, nslab, slab));
-        FL_TRY(launch_linear(L, dt, ly.wgu, sc.xn, nullptr, sc.act, T, 2 * sh.Ip, D.h, EPI_GATEUP, sc.inv_rms));
+        FL_TRY(wide(ly.wgu, sc.act, 2 * sh.Ip, EPI_GATEUP));
         FL_TRY(launch_linear(L, dt, ly.wd, sc.act, nullptr, sc.delta, T, D.h, sh.Ip, EPI_F32, nullptr, kMaxKSplit, &nslab));
     }
     FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, sc.delta, sh.norm, D.eps, sc.xn, sc.inv_rms, T, D.h, nslab, slab));
-    FL_TRY(launch_linear(L, dt, sh.lm_head, sc.xn, nullptr, b->logits, T, D.V, D.h, EPI_F32, sc.inv_rms));
+    FL_TRY(wide(sh.lm_head, b->logits, D.V, EPI_F32));
     return launch_select_advance_batch(L, b->logits, D.V, b->seqs_dev, B, 1);
 }
 

@@ -51,12 +51,12 @@ def test_two_ranks_on_one_gpu_no_launcher(start_level):
 
 
 @pytest.mark.gpu
-def test_broken_level0_falls_back_to_level1():
-    """The fused all-reduce forced onto two ranks that share ONE GPU with full-chip grids cannot make progress (each
-    rank's waves wait for the other's, which are not resident): the bounded waits give up, every rank rebuilds at
-    level 1 and the run completes."""
+def test_failed_level0_falls_back_to_level1():
+    """One rank's health check fails at level 0 (injected: a real failure there is a bounded wait that gave up or an RCCL
+    error): EVERY rank must rebuild one level more conservative and the run must complete at level 1."""
     p, js = run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--model", "tinyllama-1.1b", "--prompt", "64",
                        "--no-cpu-baseline"],
-                      {"FL_BENCH_SAME_DEVICE": "1", "FL_TP_FUSED_AR": "2", "FL_AR_TIMEOUT_MS": "1500", "FL_BENCH_BATCH": "0"})
+                      {"FL_BENCH_SAME_DEVICE": "1", "FL_BENCH_INJECT_LEVEL0_FAILURE": "1", "FL_BENCH_BATCH": "0"})
     assert p.returncode == 0, p.stderr[-3000:]
-    assert js["n_gpus"] == 2 and js["ranks_agree"] is True and js["config"]["tp_fallback_level"] >= 1
+    assert "health check failed at level 0" in p.stderr
+    assert js["n_gpus"] == 2 and js["ranks_agree"] is True and js["config"]["tp_fallback_level"] == 1

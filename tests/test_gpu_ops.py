@@ -136,3 +136,27 @@ def test_linear_skinny_kernel(fa, T, N, K, epi, bias):
         np.testing.assert_allclose(y, ref, atol=2e-5 * np.sqrt(K) + 1e-5, rtol=1e-5)
     for _ in range(5):                                            # counted-wait pipeline: same bits every launch
         np.testing.assert_array_equal(fa.op_linear(xb, wb, b, epilogue=epi), y)
+
+
+# batched-decode wide projection on the LDS-DMA ring kernel (k_gemv_dma.hip), routed through fl_op_linear by
+# FL_OP_LINEAR_DMA=1: every K-tiles-per-wave bucket (4/8/12/16), K slices, ragged last unit, B = 1..8, SiLU gate;
+# a wave-private ring ordered only by counted waits: same bits on every launch
+@pytest.mark.parametrize("T,N,K,epi", [(8, 4096, 4096, 0), (3, 1000, 256, 0), (5, 2000, 1536, 0), (8, 512, 7168, 0),
+                                       (1, 320, 512, 0), (8, 4096, 14336, 0), (7, 33, 64, 0),
+                                       (8, 14336, 4096, 1), (4, 352, 256, 1), (6, 5632, 2048, 1), (2, 16, 128, 1)])
+def test_linear_dma_ring_kernel(fa, T, N, K, epi, monkeypatch):
+    monkeypatch.setenv("FL_OP_LINEAR_DMA", "1")
+    x, w = _rand((T, K), 41), _rand((N if not epi else 2 * N, K), 42, 0.05)
+    xb, wb = synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w)
+    y = fa.op_linear(xb, wb, None, epilogue=epi)
+    ref = _ref(synth.bf16_bits_to_f32(xb), synth.bf16_bits_to_f32(wb), None, epi)
+    if epi:
+        np.testing.assert_allclose(y, ref, atol=1e-3, rtol=2 ** -8)
+    else:
+        np.testing.assert_allclose(y, ref, atol=2e-5 * np.sqrt(K) + 1e-5, rtol=1e-5)
+    for _ in range(8):
+        np.testing.assert_array_equal(fa.op_linear(xb, wb, None, epilogue=epi), y)
+    monkeypatch.delenv("FL_OP_LINEAR_DMA")
+    tight = fa.op_linear(xb, wb, None, epilogue=epi)              # the other kernels on the same data: same result up to summation order
+    # (gate/up outputs are bf16 on both sides: each may sit one ulp off the exact value, in opposite directions)
+    np.testing.assert_allclose(y, tight, atol=(2e-3 if epi else 2e-5 * np.sqrt(K) + 1e-5), rtol=2 ** -7 if epi else 1e-5)
