@@ -95,6 +95,7 @@ def lib():
         L.fl_forward_sample.argtypes = [vp, vp, vp, sz, sz, C.POINTER(FlSampling), vp]
         L.fl_decode_sample.argtypes = [vp, vp, C.c_uint32, sz, sz, C.c_int64, C.POINTER(FlSampling), vp, C.POINTER(sz)]
         L.fl_op_sample.argtypes = [vp, C.c_int64, C.POINTER(FlSampling), C.c_int64, vp]
+        L.fl_op_attention.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp]
         L.fl_batch_create.argtypes = [vp, vp, sz, C.POINTER(vp)]
         L.fl_batch_destroy.argtypes = [vp]
         L.fl_batch_destroy.restype = None
@@ -363,6 +364,16 @@ class Cache:
 
 def tune(key, value):
     _check(lib().fl_tune(key.encode(), int(value)))
+
+
+def op_attention(q, k, v, s_past, H, Hkv, d, window=-1, kernel=0, nsplit=0):
+    """The bf16 MFMA attention kernels alone.  q [T, H*d], k / v [s_past + T, Hkv*d]: uint16 bf16 bits; returns [T, H*d] f32."""
+    q, k, v = (np.ascontiguousarray(a, dtype=np.uint16) for a in (q, k, v))
+    T = q.shape[0]
+    assert q.shape == (T, H * d) and k.shape == (s_past + T, Hkv * d) and v.shape == k.shape
+    out = np.empty((T, H * d), dtype=np.float32)
+    _check(lib().fl_op_attention(q.ctypes.data, k.ctypes.data, v.ctypes.data, T, s_past, H, Hkv, d, window, kernel, nsplit, out.ctypes.data))
+    return out
 
 
 def op_linear(x, w, bias=None, epilogue=0, iters=0):

@@ -8,6 +8,7 @@
 #include <exception>
 #include <memory>
 #include <new>
+#include <vector>
 
 #include "model.h"
 
@@ -421,6 +422,64 @@ int fl_op_linear(const void *x, const void *w, const float *bias, int64_t T, int
                 }
             }
         }
+        return FL_OK;
+    });
+}
+
+int fl_op_attention(const void *q, const void *k, const void *v, int64_t T, int64_t s_past, int64_t H, int64_t Hkv, int64_t d,
+                    int64_t window, int32_t kernel, int32_t nsplit, float *out) {
+    return guarded([&]() -> int {
+        if (!q || !k || !v || !out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+        if (T < 1 || s_past < 0 || H < 1 || Hkv < 1 || kernel < 0 || kernel > 3 || nsplit < 0 || nsplit > 64) FL_FAIL(FL_ERR_BAD_ARGUMENT, "bad shape / kernel");
+        if (!attn_mfma_supported(FL_DTYPE_BF16, H, Hkv, d)) FL_FAIL(FL_ERR_UNSUPPORTED, "MFMA attention: head_dim 64 / 128, at most 8 query heads per kv head");
+        if (kernel == 1 && T != 1) FL_FAIL(FL_ERR_BAD_ARGUMENT, "the decode kernel takes one query token");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FL_FAIL(FL_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU path");
+        FL_HIP(hipSetDevice(0));
+        const int64_t S = s_past + T, sa = (S + 31) / 32 * 32;
+        // the cache layout of the model: K [Hkv][sa][d], V transposed [Hkv][d][sa], zero padding (model.hip cache_create)
+        std::vector<bf16_t> kc((size_t)Hkv * sa * d, 0), vt((size_t)Hkv * d * sa, 0);
+        const bf16_t *kh = reinterpret_cast<const bf16_t *>(k), *vh = reinterpret_cast<const bf16_t *>(v);
+        for (int64_t s = 0; s < S; s++)
+            for (int64_t h = 0; h < Hkv; h++)
+                for (int64_t j = 0; j < d; j++) {
+                    kc[((size_t)h * sa + s) * d + j] = kh[((size_t)s * Hkv + h) * d + j];
+                    vt[((size_t)h * d + j) * sa + s] = vh[((size_t)s * Hkv + h) * d + j];
+                }
+        if (nsplit == 0) nsplit = (int)std::max<int64_t>(1, std::min<int64_t>((S + 127) / 128, 48));
+        struct Bufs { void *q = 0, *k = 0, *v = 0, *o = 0; StepState *st = 0; float *pm = 0, *pl = 0, *po = 0; unsigned *cnt = 0; hipStream_t s = 0;
+                      ~Bufs() { (void)hipFree(q); (void)hipFree(k); (void)hipFree(v); (void)hipFree(o); (void)hipFree(st); (void)hipFree(pm);
+                                (void)hipFree(pl); (void)hipFree(po); (void)hipFree(cnt); if (s) (void)hipStreamDestroy(s); } } B;
+        const size_t qb = (size_t)T * H * d * 2;
+        FL_HIP(hipStreamCreate(&B.s));
+        FL_HIP(hipMalloc(&B.q, qb)); FL_HIP(hipMalloc(&B.o, qb));
+        FL_HIP(hipMalloc(&B.k, kc.size() * 2)); FL_HIP(hipMalloc(&B.v, vt.size() * 2));
+        FL_HIP(hipMalloc((void **)&B.st, sizeof(StepState)));
+        FL_HIP(hipMalloc((void **)&B.pm, (size_t)H * nsplit * 4)); FL_HIP(hipMalloc((void **)&B.pl, (size_t)H * nsplit * 4));
+        FL_HIP(hipMalloc((void **)&B.po, (size_t)H * nsplit * d * 4)); FL_HIP(hipMalloc((void **)&B.cnt, (size_t)H * 4));
+        StepState st{}; st.pos = (uint32_t)s_past; st.len = (uint32_t)s_past; st.call0 = (uint32_t)s_past; st.eos = -1;
+        FL_HIP(hipMemcpy(B.q, q, qb, hipMemcpyHostToDevice));
+        FL_HIP(hipMemcpy(B.k, kc.data(), kc.size() * 2, hipMemcpyHostToDevice));
+        FL_HIP(hipMemcpy(B.v, vt.data(), vt.size() * 2, hipMemcpyHostToDevice));
+        FL_HIP(hipMemcpy(B.st, &st, sizeof st, hipMemcpyHostToDevice));
+        FL_HIP(hipMemset(B.cnt, 0, (size_t)H * 4));
+        FL_HIP(hipMemset(B.o, 0xff, qb));                         // NaN pattern: an element the kernel does not write shows up
+        Launcher L; L.stream = B.s;
+        const float scale = 1.0f / sqrtf((float)d);
+        int rc;
+        if (kernel == 1 || (kernel == 0 && T == 1)) {
+            AttnScratch as{B.pm, B.pl, B.po, B.cnt, nsplit, S};
+            rc = launch_attn_decode_mfma(L, B.q, B.k, B.v, B.st, B.o, as, H, Hkv, d, sa, scale);
+        } else {
+            attn_prefill_force(kernel);
+            rc = launch_attn_prefill_mfma(L, B.q, B.k, B.v, B.st, B.o, T, H, Hkv, d, sa, scale, window < 0 ? -1 : window);
+            attn_prefill_force(0);
+        }
+        FL_TRY(rc);
+        FL_HIP(hipStreamSynchronize(B.s));
+        std::vector<bf16_t> oh((size_t)T * H * d);
+        FL_HIP(hipMemcpy(oh.data(), B.o, qb, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < oh.size(); i++) out[i] = bf16_bits_to_float(oh[i]);
         return FL_OK;
     });
 }

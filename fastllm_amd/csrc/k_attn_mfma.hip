@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "attn_mfma.h"
 
@@ -588,6 +589,9 @@ static int launch_pf32(Launcher &L, const void *q, const void *k_cache, const vo
                      scale * 1.44269504088896340736f, (int)window, paired);
 }
 
+static std::atomic<int> g_prefill_force{0};
+void attn_prefill_force(int which) { g_prefill_force = which; }
+
 int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, const void *v_cache_T, const StepState *st,
                              void *out, int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t seq_alloc, float scale,
                              int64_t window) {
@@ -595,7 +599,8 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
     if (G > 8) FL_FAIL(FL_ERR_UNSUPPORTED, "mfma prefill attention: at most 8 query heads per kv head");
     // 32-row waves (attn_prefill32_kernel) once the prompt is long enough to fill the chip with their workgroups
     static const int pf32_min_t = getenv("FL_ATTN_PF32_MIN_T") ? atoi(getenv("FL_ATTN_PF32_MIN_T")) : 1024;
-    if (T >= pf32_min_t && scale > 0.f) {
+    const int force = g_prefill_force.load();                        // fl_op_attention pins one kernel (unit tests)
+    if ((force == 3 || (force == 0 && T >= pf32_min_t)) && scale > 0.f) {
         // waves per workgroup: 8 (G = 1, 2, 4), 6 (G = 3), else G.  Paired (balanced) grids win as soon as they cover
         // ~3/4 of the chip -- Mistral-7B per layer: T = 3072 134 us paired (192 workgroups) vs 197 unpaired, T = 4096
         // 177 vs 305, T = 8192 681 vs 693; T = 2048 (128 paired workgroups) 98 vs 85.  4-wave workgroups (half the K/V

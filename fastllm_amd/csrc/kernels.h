@@ -214,6 +214,8 @@ int launch_attn_decode_mfma(Launcher &L, const void *q, const void *k_cache, con
 int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, const void *v_cache_T, const StepState *st,
                              void *out, int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t seq_alloc, float scale,
                              int64_t window);
+// test hook (fl_op_attention): 0 = pick by prompt length, 2 = the 16-row kernel, 3 = the 32-row kernel
+void attn_prefill_force(int which);
 
 // decode attention + o_proj in one launch (k_attn_oproj.hip): W_o is pulled into LDS while attention runs
 bool attn_oproj_plan(int64_t H, int64_t Hkv, int64_t d, int64_t h, int nsplit, int cus, int *n_blocks, int *rows_attn,

@@ -270,6 +270,16 @@ int fl_op_linear(const void *x, const void *w, const float *bias, int64_t T, int
  * vector (consuming successive words of the seeded stream; ArgMax when temperature < 1e-7). */
 int fl_op_sample(const float *logits, int64_t V, const fl_sampling *sampling, int64_t n_draws, uint32_t *tokens_out);
 
+/* The bf16 MFMA attention kernels alone, for unit tests against an fp64 reference (they are otherwise only seen through
+ * whole-model logits).  One sequence: q [T][H*d] (RoPE already applied), k / v [s_past + T][Hkv*d], all bf16 row-major; the
+ * first s_past positions are the cache, the last T the new tokens.  Mask as the forward pass applies it:
+ * T == 1: no mask; T > 1: cached keys visible, new key j visible to query t iff j <= t and j + window >= t (window < 0: no
+ * window).  kernel: 0 = what the model would launch, 1 = decode kernel (T must be 1), 2 = 16-row prefill kernel, 3 =
+ * 32-row prefill kernel.  nsplit: key splits of the decode kernel (0 = as fl_cache_create picks; 1 = one wide workgroup
+ * per kv head).  out [T][H*d] fp32 (the kernels' bf16 output widened). */
+int fl_op_attention(const void *q, const void *k, const void *v, int64_t T, int64_t s_past, int64_t H, int64_t Hkv,
+                    int64_t d, int64_t window, int32_t kernel, int32_t nsplit, float *out);
+
 #ifdef __cplusplus
 }
 #endif
