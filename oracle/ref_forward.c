@@ -291,6 +291,11 @@ static void rmsnorm_fwd(const orc_model *m, const float *x, const float *w, int6
         float ss = 0.f;
         for (int64_t i = 0; i < h; i++) ss += xr[i] * xr[i];
         float r = sqrtf(ss / (float)h + m->eps);
+        if (m->round_bf16 == 2) {               /* candle bf16 (App. A.2): m and every op's result rounded to bf16 */
+            const float rb = round_bf16f(r);
+            for (int64_t i = 0; i < h; i++) yr[i] = round_bf16f(round_bf16f(xr[i] / rb) * w[i]);
+            continue;
+        }
         for (int64_t i = 0; i < h; i++) {
             /* bf16 emulation: the MI355X path stores x*w in bf16 and applies 1/rms after the
              * projection's dot product, so the rounding point is x*w */
@@ -309,6 +314,16 @@ static void rope_fwd(const orc_model *m, float *x, int64_t T, int64_t nh, size_t
             for (int64_t j = 0; j < half; j++) {
                 float ang = p * m->inv_freq[j];
                 float c = cosf(ang), s = sinf(ang);
+                if (m->round_bf16 == 2) {
+                    /* candle bf16 tables (App. A.4): Llama builds the angles in f32 and casts cos / sin to bf16;
+                     * Mistral / Qwen2 cast inv_freq AND the position vector to bf16 before the outer product (positions
+                     * above 256 are already rounded) and take cos / sin of the bf16 product */
+                    if (m->cfg.family == ORC_LLAMA) { c = round_bf16f(c); s = round_bf16f(s); }
+                    else {
+                        const float fb = round_bf16f(round_bf16f(p) * round_bf16f(m->inv_freq[j]));
+                        c = round_bf16f(cosf(fb)); s = round_bf16f(sinf(fb));
+                    }
+                }
                 float a = v[j], b = v[j + half];
                 v[j] = a * c - b * s;
                 v[j + half] = a * s + b * c;
@@ -320,6 +335,7 @@ static void rope_fwd(const orc_model *m, float *x, int64_t T, int64_t nh, size_t
 static void maybe_round(const orc_model *m, float *x, size_t n) {
     if (m->round_bf16) for (size_t i = 0; i < n; i++) x[i] = round_bf16f(x[i]);
 }
+static void round_all(float *x, size_t n) { for (size_t i = 0; i < n; i++) x[i] = round_bf16f(x[i]); }
 
 /* Causal SDPA over the cache (App. A.3, A.5, A.6).  q [T][H][d]; keys 0..len+T.
  * Mask (only when T > 1): key index kj < len (cached prefix) is visible; for the
@@ -329,6 +345,7 @@ static void attention_fwd(const orc_model *m, const orc_cache *c, int64_t layer,
                           int64_t T, size_t len, float *out) {
     const int64_t H = m->H, Hkv = m->Hkv, d = m->d, G = H / Hkv;
     const size_t S = len + (size_t)T;
+    const int cmode = m->round_bf16 == 2 && m->cfg.family != ORC_LLAMA;
     int nt = orc_model_threads(m); (void)nt;
 #pragma omp parallel for collapse(2) schedule(static) num_threads(nt) if ((double)H * (double)T * (double)S * (double)d > 2e6)
     for (int64_t hq = 0; hq < H; hq++) {
@@ -347,7 +364,12 @@ static void attention_fwd(const orc_model *m, const orc_cache *c, int64_t layer,
                     else if (m->window >= 0 && j + m->window < t) masked = 1;
                 }
                 float s = -INFINITY;
-                if (!masked) s = dot_f32(kb + kj * d, qv, d) * m->scale;
+                if (!masked) {
+                    s = dot_f32(kb + kj * d, qv, d);
+                    /* candle bf16, Mistral / Qwen2 (App. A.3): the q.k^T matmul and the scaling each round to bf16; Llama
+                     * upcasts q, k, v to f32 and divides by sqrt(d) there */
+                    if (cmode) s = round_bf16f(round_bf16f(s) * round_bf16f(m->scale)); else s *= m->scale;
+                }
                 sc[kj] = s; if (s > mx) mx = s;
             }
             float sum = 0.f;
@@ -356,6 +378,7 @@ static void attention_fwd(const orc_model *m, const orc_cache *c, int64_t layer,
             for (int64_t j = 0; j < d; j++) o[j] = 0.f;
             for (size_t kj = 0; kj < S; kj++) {
                 float pw = sc[kj] / sum;
+                if (cmode) pw = round_bf16f(pw);                    /* softmax_last_dim returns bf16 probabilities */
                 if (pw == 0.f) continue;
                 const float *vr = vb + kj * d;
                 for (int64_t j = 0; j < d; j++) o[j] += pw * vr[j];
@@ -391,12 +414,17 @@ int orc_forward(orc_model *m, orc_cache *c, const uint32_t *ids, size_t T_, size
             x[(size_t)t * h + i] = m->embed_b ? bf16_to_f32(m->embed_b[(size_t)ids[t] * h + i]) : m->embed_f[(size_t)ids[t] * h + i];
 
     const size_t len = c->len;
+    /* round_bf16 == 2: candle's bf16 execution, every op's output a bf16 tensor ([UPSTREAM-RECALLED]:
+     * the crate is not in /root/reference).  Used only to MEASURE how far the product's bf16 logits are from what the
+     * reference's hard-wired BF16 run (main.rs:120) would produce; the parity bar itself is the fp32 mode. */
+    const int candle = m->round_bf16 == 2;
     for (int64_t l = 0; l < m->L; l++) {
         const layer_t *ly = &m->layers[l];
         rmsnorm_fwd(m, x, ly->ln1, T, xn);
         linear_fwd(m, &ly->q, xn, T, q);
         linear_fwd(m, &ly->k, xn, T, k);
         linear_fwd(m, &ly->v, xn, T, v);
+        if (candle) { round_all(q, (size_t)T * H * d); round_all(k, (size_t)T * Hkv * d); round_all(v, (size_t)T * Hkv * d); }
         rope_fwd(m, q, T, H, pos);
         rope_fwd(m, k, T, Hkv, pos);
         maybe_round(m, q, (size_t)T * H * d); maybe_round(m, k, (size_t)T * Hkv * d); maybe_round(m, v, (size_t)T * Hkv * d);
@@ -411,22 +439,30 @@ int orc_forward(orc_model *m, orc_cache *c, const uint32_t *ids, size_t T_, size
         maybe_round(m, ao, (size_t)T * H * d);
         linear_fwd(m, &ly->o, ao, T, tmp);
         if (m->allreduce) m->allreduce(tmp, (size_t)T * h, m->allreduce_ctx);
+        if (candle) round_all(tmp, (size_t)T * h);
         for (size_t i = 0; i < (size_t)T * h; i++) x[i] += tmp[i];
+        if (candle) round_all(x, (size_t)T * h);                /* the residual stream itself is a bf16 tensor in candle */
         rmsnorm_fwd(m, x, ly->ln2, T, xn);
         linear_fwd(m, &ly->gate, xn, T, g);
         linear_fwd(m, &ly->up, xn, T, u);
+        if (candle) { round_all(g, (size_t)T * I); round_all(u, (size_t)T * I); }
         for (size_t i = 0; i < (size_t)T * I; i++) {       /* silu(g) * u; silu = x / (1 + exp(-x)) */
-            float a = g[i] / (1.0f + expf(-g[i])) * u[i];
+            float sg = g[i] / (1.0f + expf(-g[i]));
+            if (candle) sg = round_bf16f(sg);                   /* Activation::Silu, then the multiply: one rounding each */
+            float a = sg * u[i];
             g[i] = m->round_bf16 ? round_bf16f(a) : a;
         }
         linear_fwd(m, &ly->down, g, T, tmp);
         if (m->allreduce) m->allreduce(tmp, (size_t)T * h, m->allreduce_ctx);
+        if (candle) round_all(tmp, (size_t)T * h);
         for (size_t i = 0; i < (size_t)T * h; i++) x[i] += tmp[i];
+        if (candle) round_all(x, (size_t)T * h);
     }
     c->len = len + (size_t)T;
     /* narrow(1, T-1, 1) -> final norm -> lm_head; logits as f32 (App. A.1) */
     rmsnorm_fwd(m, x + (size_t)(T - 1) * h, m->norm, 1, xn);
     linear_fwd(m, &m->lm_head, xn, 1, logits_out);
+    if (candle) round_all(logits_out, (size_t)m->V);            /* the lm_head matmul returns bf16 (Llama widens it afterwards) */
     free(x); free(xn); free(q); free(k); free(v); free(ao); free(tmp); free(g); free(u);
     return 0;
 }

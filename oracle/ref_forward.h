@@ -73,7 +73,13 @@ typedef void (*orc_allreduce_fn)(float *buf, size_t n, void *ctx);
  * round_bf16 = 1: fp32 arithmetic, but activations are rounded to bf16 at the
  *   tensor boundaries where the MI355X bf16 path stores bf16 (x*norm_weight, q/k/v
  *   after RoPE, attention output, SiLU-gate product).  Residual stream, norms,
- *   softmax and logits stay fp32. */
+ *   softmax and logits stay fp32.
+ * round_bf16 = 2: candle's bf16 execution (the reference hard-wires DType::BF16, main.rs:120): every op's output is a
+ *   bf16 tensor -- residual stream, norm (m rounded, divide and multiply each rounded), every Linear, RoPE tables
+ *   (Mistral / Qwen2: inv_freq AND positions cast to bf16 before the outer product), Mistral / Qwen2 scores, scaling and
+ *   probabilities (Llama runs attention in f32), SiLU, products, logits ([UPSTREAM-RECALLED]:
+ *   the candle crates are not under /root/reference).  Measures the distance between the product's bf16 logits and the
+ *   reference's bf16 run; never a pass/fail oracle on its own. */
 int  orc_model_create(const orc_config *cfg, const orc_tensor *tensors, size_t n,
                       int round_bf16, orc_model **out);
 void orc_model_destroy(orc_model *m);

@@ -75,3 +75,37 @@ def test_bf16_weight_storage_matches_f32(case):
     mb = oracle.OracleModel(cfg, w)           # uint16 = bf16 bits, kept as bf16
     c1, c2 = m.new_cache(32), mb.new_cache(32)
     np.testing.assert_array_equal(m.forward(c1, z["prompt"], 0), mb.forward(c2, z["prompt"], 0))
+
+
+def _teacher_forced(model, z, meta, cap=64):
+    """Last-position logits of the prefill and of every decode step, fed the fixture's fp32 greedy tokens."""
+    c = model.new_cache(cap)
+    out = [model.forward(c, z["prompt"], 0)]
+    if meta["n_gen"]:
+        for i, tok in enumerate(z["gen_tokens"][:-1]):
+            out.append(model.forward(c, [int(tok)], meta["T"] + i))
+    return np.stack(out)
+
+
+def _fp32_rows(z, meta):
+    return np.concatenate([z["prefill_logits"][None], z["gen_logits"][1:]]) if meta["n_gen"] else z["prefill_logits"][None]
+
+
+def test_candle_bf16_emulation_sits_where_a_bf16_execution_sits(case):
+    """round_bf16 = 2 restates candle's bf16 execution (every op's output a bf16 tensor).  There is no
+    candle here to pin it to; the nearest independent datum is HuggingFace run in bfloat16 on the same weights
+    (hf_bf16_* in the fixtures).  Both are "round after every op" executions of the same architecture, so their
+    distances to the fp32 logits must be of the same size -- and the emulation must not be the fp32 or the
+    product-rounding mode in disguise."""
+    z, meta, cfg, m = case
+    w = synth.as_f32(synth.synth_weights(cfg))
+    ref = _fp32_rows(z, meta)
+    hf = np.concatenate([z["hf_bf16_prefill_logits"][None], z["hf_bf16_gen_logits"][1:]]) if meta["n_gen"] else z["hf_bf16_prefill_logits"][None]
+    cand = _teacher_forced(oracle.OracleModel(cfg, w, round_bf16=2), z, meta)
+    prod = _teacher_forced(oracle.OracleModel(cfg, w, round_bf16=1), z, meta)
+    n = np.linalg.norm(ref)
+    e_hf, e_cand, e_prod = (np.linalg.norm(a - ref) / n for a in (hf, cand, prod))
+    assert 0.4 * e_hf <= e_cand <= 2.5 * e_hf, (e_hf, e_cand)
+    assert e_prod < e_cand, (e_prod, e_cand)          # fp32 residual stream + fewer rounding points: closer to fp32
+    # bf16 logits: every value of the emulation is representable in bf16
+    assert np.array_equal(synth.bf16_bits_to_f32(synth.f32_to_bf16_bits(cand)), cand)
