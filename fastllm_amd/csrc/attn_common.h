@@ -39,9 +39,9 @@ __device__ __forceinline__ void combine_lds(const float *lds, int g, int j4, flo
     for (int w = 0; w < NW; w++) {
         const float *p = lds + ((size_t)w * GMAX + g) * STR;
         const float wt = p[D] == -INFINITY ? 0.f : __expf(p[D] - M);
-        L += p[D + 1] * wt;
-#pragma unroll
-        for (int j = 0; j < 4; j++) O[j] += p[j4 + j] * wt;
+        L = fmaf(p[D + 1], wt, L);                                 // explicit FMAs: hipcc contracted the two inlined copies of this
+#pragma unroll                                                     // loop differently (1-ulp differences between call sites)
+        for (int j = 0; j < 4; j++) O[j] = fmaf(p[j4 + j], wt, O[j]);
     }
 }
 
@@ -135,10 +135,10 @@ __device__ __forceinline__ bool decode_tail(float *lds, int *is_last, int G, int
         for (int sp = part; sp < nsplit; sp += parts) {
             const float mm = lm[g * nsplit + sp];
             const float w = mm == -INFINITY ? 0.f : __expf(mm - M);
-            L += ll[g * nsplit + sp] * w;
+            L = fmaf(ll[g * nsplit + sp], w, L);
             const float4v o4 = *reinterpret_cast<const float4v *>(part_o + (hb + sp) * D + j4);
 #pragma unroll
-            for (int j = 0; j < 4; j++) O[j] += o4[j] * w;
+            for (int j = 0; j < 4; j++) O[j] = fmaf(o4[j], w, O[j]);
         }
         if (parts > 1) {
             float *r = red + ((size_t)part * slots + slot) * 5;
