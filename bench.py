@@ -451,10 +451,12 @@ def main():
             # HBM bytes per launch from the PMC passes committed with the profiles (tools/pmc_traffic.py);
             # only comparable when the workload is the one they were collected on
             traffic, tsrc = None, None
-            tf = os.path.join(ROOT, "profiles", "r01", "traffic_gemv.json")
-            if os.path.exists(tf) and args.model == "mistral-7b" and world == 1:
-                tj = json.load(open(tf))
-                traffic, tsrc = round(tj["hbm_bytes_per_launch"]), "profiles/r01/traffic_gemv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+            import glob
+            tfs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "traffic_gemv.json")))      # newest round's PMC passes
+            if tfs and args.model == "mistral-7b" and world == 1:
+                tj = json.load(open(tfs[-1]))
+                traffic = round(tj["hbm_bytes_per_launch"])
+                tsrc = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, separate runs, gfx950 x2 read correction)" % os.path.relpath(tfs[-1], ROOT)
             roof = {"bound": "hbm", "kernel": "gemv_kernel<bf16> (QKV/O/gate-up/down/lm_head weight stream)",
                     "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
                     "traffic": traffic, "traffic_source": tsrc, "launches_per_step": gemv["launches"] // n_prof,

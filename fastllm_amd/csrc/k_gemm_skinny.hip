@@ -188,10 +188,15 @@ static int launch_skinny_t(Launcher &L, const void *W, const void *x, const floa
     constexpr int kFit = 152 * 1024 / STG, kCnt = 63 / PW + 2;
     constexpr int kDeep = kFit < kCnt ? (kFit < 12 ? kFit : 12) : (kCnt < 12 ? kCnt : 12);
     const bool nt = (kSkinnyNt == 1 && T <= 32) || kSkinnyNt == 2;
-    if constexpr (BM >= 64 && NW == 4) {
+    if constexpr (BM >= 64) {
+        // wave rows: 2 for the 4-column workgroups; the narrow (2-column) strips of small matrices get 4 (128 tokens, gate/up
+        // pairs: 24 staging instructions per K tile over 8 waves instead of 2) or 2 where the instruction count divides
+        constexpr int NI = (BM + BN) / 8;
+        constexpr int WM = NW == 4 ? 2 : (BM == 128 && NI % 8 == 0 ? 4 : 2);
+        static_assert(NI % (NW * WM) == 0 && BM % (16 * WM) == 0, "wave rows must divide the stage and the token tiles");
         if (kSkinnyWm) {
-            return nt ? launch_skinny_s<BM, NT, NW, 4, true, 2>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)
-                      : launch_skinny_s<BM, NT, NW, 4, false, 2>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
+            return nt ? launch_skinny_s<BM, NT, NW, 4, true, WM>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)
+                      : launch_skinny_s<BM, NT, NW, 4, false, WM>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
         }
     }
     if constexpr (kDeep > 4 && BM <= 32) {

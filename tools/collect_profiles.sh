@@ -19,9 +19,16 @@ timeout -k 10 300 python3 tools/batch_bench.py --profile --batches 1,2,3,4,6,8 >
 timeout -k 10 200 python3 tools/sample_cost.py > $O/sample_cost.txt 2> $O/sample.err || exit 1
 timeout -k 10 200 python3 tools/gemm_probe.py > $O/gemm_probe.txt 2> $O/gemm_probe.err || exit 1
 (timeout -k 10 200 python3 tools/prefill_sweep.py mistral-7b; timeout -k 10 200 python3 tools/prefill_sweep.py tinyllama-1.1b) 2> $O/prefill_sweep.err | grep 'T=' > $O/prefill_sweep.txt || exit 1
+# the way the driver invokes the N-GPU bench: no launcher (bench.py starts its ranks itself)
 for n in 2 4; do
-  FL_BENCH_SAME_DEVICE=1 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29520 + n)) bench.py --gpus $n --steps 64 --warmup 8 > $O/bench_tp${n}_same_device.json 2> $O/bench_tp${n}.err || exit 1
+  FL_BENCH_SAME_DEVICE=1 FL_BENCH_BATCH=0 timeout -k 10 400 python3 bench.py --gpus $n --steps 64 --warmup 8 --no-cpu-baseline > $O/bench_tp${n}_same_device.json 2> $O/bench_tp${n}.err || exit 1
 done
+timeout -k 10 300 python3 tools/skinny_probe.py 1,8,128 > $O/projection_probe_cold.txt 2> $O/skinny.err || exit 1
+timeout -k 10 500 python3 tools/cpu_baseline_full.py > $O/cpu_baseline_full_depth.txt 2> $O/cpu_full.err || exit 1
+cd /tmp
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 $R/tools/prefill_profile.py mistral-7b 512 > /dev/null 2> $O/pmc_mfma.err || exit 1
+cd $R
+python3 tools/pmc_mfma.py $O/pmc_mfma $O/pmc_mfma_mistral_t512.json > /dev/null
 python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/traffic_gemv.json > /dev/null
 # keep the merged output small: the per-dispatch traces are large
 find $O -name '*kernel_trace.csv' -size +20M -delete

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Sweep the decode GEMV kernel's tuning knobs on the Mistral-7B / TinyLlama layer shapes.
+"""Sweep the decode GEMV kernel's tuning knobs on the Mistral-7B / TinyLlama layer shapes (cold caches: fl_op_linear
+rotates over copies of W that exceed the Infinity Cache; round 1's sweep re-read ONE copy and flattered the short matrices).
 Usage (GPU box): python tools/gemv_sweep.py > gpurun_out/gemv_sweep.txt"""
 import os
 import sys
@@ -21,8 +22,8 @@ def main():
         w = (w & 0x807F) | 0x3C00                                        # |w| in [1/64.. ) small, finite
         x = (rs.randint(0, 65536, size=(1, K), dtype=np.uint16) & 0x807F) | 0x3C00
         best = None
-        for R, U in ((2, 2), (2, 4), (2, 8), (4, 2)):
-            for blocks, waves in ((0, 0), (256, 4), (256, 8), (256, 12), (512, 4), (512, 6), (768, 4), (1024, 4)):
+        for R, U in ((2, 2), (2, 4), (4, 2)):
+            for blocks, waves in ((0, 0), (256, 6), (256, 8), (256, 10), (256, 12), (512, 4), (512, 6), (768, 4), (1024, 4), (128, 12)):
                 fa.tune("gemv_r", R); fa.tune("gemv_u", U); fa.tune("gemv_blocks", blocks); fa.tune("gemv_waves", waves)
                 _, ms = fa.op_linear(x, w, None, epilogue=epi, iters=50)
                 gbs = N * K * 2 / ms / 1e6
