@@ -208,7 +208,16 @@ static int launch_skinny_t(Launcher &L, const void *W, const void *x, const floa
               : launch_skinny_s<BM, NT, NW, 4, false, 1>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
 }
 
-bool gemm_skinny_supported(int64_t T, int64_t N, int64_t K) { return T > 1 && T <= kSkinnyMaxT && K % S_BK == 0 && K / S_BK >= 4 && N >= 64; }
+// T <= 128: always (one token block).  129..256 tokens (two token blocks, the strip re-read through L2) only for matrices
+// below 24 Mi elements, where the tiled kernels' grids are far short of the chip -- measured per projection at T = 256,
+// 8-wave workgroups: TinyLlama QKV 18.2 -> 15.3 us, gate/up 38.6 -> 27.1, down 30.7 -> 15.8, Mistral o_proj 27.0 -> 24.2, but
+// Mistral QKV 31.0 -> 36.2, gate/up 91 -> 112, lm_head 94 -> 172 (TinyLlama T = 256 prefill 3.05 -> 2.0 ms).
+bool gemm_skinny_supported(int64_t T, int64_t N, int64_t K) {
+    if (!(T > 1 && K % S_BK == 0 && K / S_BK >= 4 && N >= 64)) return false;
+    if (T <= kSkinnyMaxT) return true;
+    static const int max2 = getenv("FL_GEMM_SKINNY_MAXT2") ? atoi(getenv("FL_GEMM_SKINNY_MAXT2")) : 256;
+    return T <= max2 && N * K < ((int64_t)24 << 20);
+}
 
 // K slices for the fp32 epilogue: enough workgroups to cover the chip twice, at least 8 K tiles per slice
 int gemm_skinny_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
