@@ -316,6 +316,8 @@ def main():
         log("parity gate: %s (rel_l2 %.2e, max_abs %.3g, argmax_equal %s) in %.1fs"
             % ("ok" if parity["ok"] else "FAILED", parity["rel_l2"], parity["max_abs"], parity["argmax_equal"], time.perf_counter() - t0))
     if world > 1:
+        # (rank 0 was busy with the oracle: the others must not already sit in a collective with a bounded wait)
+        barrier()
         # the tensor-parallel group against ONE GPU running the whole model: same weights, same prompt, logits of the last position
         hp = np.random.RandomState(11).randint(0, cfg["vocab_size"], size=32).astype(np.uint32)
         hc = model.new_cache(48)
