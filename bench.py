@@ -330,7 +330,11 @@ def main():
             sc_.close(); sm.close()
             rel = float(np.linalg.norm(lt - ls) / max(np.linalg.norm(ls), 1e-30))
             parity["tp_vs_single_gpu_rel_l2"] = round(rel, 6)
-            parity["ok"] = bool(parity["ok"] and rel <= 1e-2)
+            # a tensor-parallel sum runs in another order: bf16 roundings downstream flip and 32 layers carry them along
+            # (Mistral-7B, 2 ranks: 1.7e-2; the same model against itself with another attention split count: ~2e-2);
+            # a wrong shard or a lost all-reduce is O(1)
+            parity["ok"] = bool(parity["ok"] and rel <= 5e-2)
+            parity["tp_tolerance"] = "rel_l2 <= 5e-2 against one GPU running the whole model (bf16, summation order differs)"
             log("parity gate: TP=%d logits vs one GPU: rel_l2 %.2e" % (world, rel))
         pk = torch.tensor([1 if (parity is None or parity["ok"]) else 0], dtype=torch.int32)
         dist.all_reduce(pk, op=dist.ReduceOp.MIN)

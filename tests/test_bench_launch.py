@@ -46,7 +46,7 @@ def test_two_ranks_on_one_gpu_no_launcher(start_level):
     assert js["n_gpus"] == 2 and js["ranks_agree"] is True
     assert js["config"]["tp_fallback_level"] == start_level
     assert js["config"]["rccl_ranks"] == 0                     # IPC-only group
-    assert js["parity_check"]["ok"] and js["parity_check"]["tp_vs_single_gpu_rel_l2"] <= 1e-2
+    assert js["parity_check"]["ok"] and js["parity_check"]["tp_vs_single_gpu_rel_l2"] <= 5e-2
     assert js["value"] > 0 and js["steps"] == 8
 
 
