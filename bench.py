@@ -61,15 +61,16 @@ def as_fl_tensors(tensors, dev_index):
 
 def cpu_baseline(torch, cfg, dev_tensors, kv_prompt=16, n_decode=8):
     """The reference's CPU path cannot be built here (Rust + candle, no toolchain); its stand-in is
-    the C restatement in oracle/ ("port").  Bounded sample: the same weights, L_s = 2 and 8 of the
+    the C restatement in oracle/ ("port").  Bounded sample: the same weights, L_s = 8 and 16 of the
     model's layers + full lm_head, n_decode greedy steps each; per-layer and head cost are separated
-    and extrapolated to the full depth."""
+    and extrapolated to the full depth.  (Round 1 sampled 2 and 8 layers: a 2-layer model mostly fits the
+    host's last-level cache and the extrapolation read 1.4-1.9x the full-depth run, profiles/r02/README.md.)"""
     from oracle import oracle
     L = cfg["num_hidden_layers"]
     res = {}
     threads = oracle.default_threads()
     prompt = np.arange(1, kv_prompt + 1, dtype=np.uint32)
-    for ls in (2, 8):
+    for ls in (8, 16):
         ls = min(ls, L)
         c = dict(cfg, num_hidden_layers=ls)
         host = {}
@@ -89,7 +90,12 @@ def cpu_baseline(torch, cfg, dev_tensors, kv_prompt=16, n_decode=8):
         res[ls] = (time.perf_counter() - t0) / n_decode
         om.close()
         del host
-    ls_a, ls_b = sorted(res)
+    ls_a, ls_b = (sorted(res) * 2)[:2]
+    if len(res) < 2:                                                    # a model with <= 8 layers was run whole
+        (ls_a, t_a), = res.items()
+        return {"value": round(1.0 / t_a, 3), "unit": "tokens/s", "cores": threads, "kind": "port",
+                "sample": "oracle/ref_forward.c (fp32 math on the same bf16 weights), %d greedy decode steps at kv_len %d..%d, all %d layers"
+                          % (n_decode, kv_prompt, kv_prompt + n_decode, ls_a)}
     per_layer = (res[ls_b] - res[ls_a]) / max(1, ls_b - ls_a) if ls_b > ls_a else res[ls_a] / ls_a
     head = max(0.0, res[ls_a] - ls_a * per_layer)
     t_tok = head + L * per_layer
