@@ -66,7 +66,7 @@ __device__ inline void stage_half(const bf16_t *__restrict__ M, int nrows, int K
 __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
                                                       const float *__restrict__ bias, void *__restrict__ out,
                                                       int T, int N, int K, int epi, int tiles_m, int tiles_n,
-                                                      const float *__restrict__ row_scale, int ksplit) {
+                                                      const float *__restrict__ row_scale, int ksplit, int ldc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [parity][A0 A1 B0 B1]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
@@ -175,14 +175,14 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__
                         const int qq = (n >> 5) * 16 + (n & 15);
                         const float gt = acc[i][j][rg] * rs, up = acc[i][j + 1][rg] * rs;
                         const float a = gt / (1.0f + expf(-gt)) * up;
-                        reinterpret_cast<bf16_t *>(out)[(size_t)m * (N / 2) + qq] = float_to_bf16_bits(a);
+                        reinterpret_cast<bf16_t *>(out)[(size_t)m * (ldc / 2) + qq] = float_to_bf16_bits(a);
                     }
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int n = n0 + wc * 64 + j * 16 + cn;
-                    if (n < N) reinterpret_cast<float *>(out)[(size_t)m * N + n] = acc[i][j][rg] * rs + (bias ? bias[n] : 0.f);
+                    if (n < N) reinterpret_cast<float *>(out)[(size_t)m * ldc + n] = acc[i][j][rg] * rs + (bias ? bias[n] : 0.f);
                 }
             }
         }
@@ -190,7 +190,9 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__
 }
 
 int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
-                   int epi, const float *row_scale, int ksplit) {
+                   int epi, const float *row_scale, int ksplit, int64_t ldc) {
+    if (ldc <= 0) ldc = N;
+    if (ksplit > 1 && ldc != N) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: K slices write whole slabs (ldc == N)");
     const int tiles_m = (int)((T + P_BM - 1) / P_BM), tiles_n = (int)((N + P_BN - 1) / P_BN);
     if (K % P_BK || K / P_BK / ksplit < 2) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: K must give at least two 64-wide tiles per slice");
     if (ksplit > 1 && (bias || epi != EPI_F32)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "split-K GEMM: fp32 epilogue without bias only");
@@ -200,7 +202,7 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
     snprintf(tag, sizeof tag, "8p,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");
     Launcher LL = L; LL.tag = tag;
     return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, gemm_8p_kernel, dim3((unsigned)(tiles_m * tiles_n), (unsigned)ksplit), dim3(512),
-                     P_LDS, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit);
+                     P_LDS, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc);
 }
 
 }  // namespace fl

@@ -52,7 +52,7 @@ __device__ inline bf16x8 read_frag(const unsigned char *lds_tile, int row, int c
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
                                                         const float *__restrict__ bias, void *__restrict__ out,
                                                         int T, int N, int K, int epi, int tiles_m, int tiles_n,
-                                                        const float *__restrict__ row_scale, int ksplit) {
+                                                        const float *__restrict__ row_scale, int ksplit, int ldc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2 buffers][X tile | W tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -120,14 +120,14 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const bf16_t *__restrict
                         const int qq = (n >> 5) * 16 + (n & 15);
                         float gt = acc[i][j][rg] * rs, up = acc[i][j + 1][rg] * rs;
                         float a = gt / (1.0f + expf(-gt)) * up;
-                        reinterpret_cast<bf16_t *>(out)[(size_t)m * (N / 2) + qq] = float_to_bf16_bits(a);
+                        reinterpret_cast<bf16_t *>(out)[(size_t)m * (ldc / 2) + qq] = float_to_bf16_bits(a);
                     }
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int n = n0 + wn * 64 + j * 16 + cn;
-                    if (n < N) reinterpret_cast<float *>(out)[(size_t)m * N + n] = acc[i][j][rg] * rs + (bias ? bias[n] : 0.f);
+                    if (n < N) reinterpret_cast<float *>(out)[(size_t)m * ldc + n] = acc[i][j][rg] * rs + (bias ? bias[n] : 0.f);
                 }
             }
         }
@@ -160,7 +160,7 @@ __device__ inline void stage_rows8(const bf16_t *__restrict__ M, int nrows, int 
 __global__ __launch_bounds__(512) void gemm_mfma256_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
                                                            const float *__restrict__ bias, void *__restrict__ out,
                                                            int T, int N, int K, int epi, int tiles_m, int tiles_n,
-                                                           const float *__restrict__ row_scale, int ksplit) {
+                                                           const float *__restrict__ row_scale, int ksplit, int ldc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [3 stages][X 256x64 | W 128x64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -229,14 +229,14 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(const bf16_t *__restr
                         const int qq = (n >> 5) * 16 + (n & 15);
                         float gt = acc[i][j][rg] * rs, up = acc[i][j + 1][rg] * rs;
                         float av = gt / (1.0f + expf(-gt)) * up;
-                        reinterpret_cast<bf16_t *>(out)[(size_t)m * (N / 2) + qq] = float_to_bf16_bits(av);
+                        reinterpret_cast<bf16_t *>(out)[(size_t)m * (ldc / 2) + qq] = float_to_bf16_bits(av);
                     }
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int n = n0 + wn * 64 + j * 16 + cn;
-                    if (n < N) reinterpret_cast<float *>(out)[(size_t)m * N + n] = acc[i][j][rg] * rs + (bias ? bias[n] : 0.f);
+                    if (n < N) reinterpret_cast<float *>(out)[(size_t)m * ldc + n] = acc[i][j][rg] * rs + (bias ? bias[n] : 0.f);
                 }
             }
         }
@@ -306,15 +306,46 @@ int gemm_mfma_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
     return ks < 1 ? 1 : ks;
 }
 
+// One launch over the column range this call was given (all of N, or a piece of a peeled matrix): ldc = the row stride
+// of the full output; allow8p = false keeps the 256x256 kernel out (the tail of a peeled matrix).
+static int launch_gemm_mfma_impl(Launcher &L, const void *W, const void *x, const float *bias, void *y,
+                                 int64_t T, int64_t N, int64_t K, int epi, const float *row_scale, int ksplit, int64_t ldc, bool allow8p);
+
+// A long prompt's grid of 256x256 tiles rarely fills whole rounds of the chip: Qwen2-7B at T = 4096 has 288 QKV tiles
+// (1.125 rounds: the kernel was rejected and the projection ran on 128x128 tiles at 0.65 PFLOP/s) and 2368 gate/up
+// tiles (9.25 rounds: the last quarter round costs a full one).  So the matrix is PEELED by columns: as many whole
+// rounds as fit run on the 256x256 kernel, the remaining columns -- when they would fill at most a quarter of a round --
+// as a second launch on the smaller tiles.  Each launch writes its own column range of the same output (ldc).
 int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bias, void *y,
                      int64_t T, int64_t N, int64_t K, int epi, const float *row_scale, int ksplit) {
+    static const int peel = getenv("FL_GEMM_PEEL") ? atoi(getenv("FL_GEMM_PEEL")) : 1;
+    const char *e8 = getenv("FL_GEMM_8P");
+    const int use8p = e8 && *e8 ? atoi(e8) : 1;
+    if (peel && use8p == 1 && ksplit == 1 && T >= 256 && K % 64 == 0 && (K / 64) >= 16) {
+        const int64_t tm = (T + 255) / 256, tn = (N + 255) / 256, t8 = tm * tn;
+        const int64_t full = t8 / 256, rem = t8 % 256;
+        const int64_t n_main_tiles = full * 256 / tm;                 // whole column tiles inside the full rounds
+        if (full >= 1 && rem > 0 && rem <= 64 && n_main_tiles >= 1 && n_main_tiles < tn && tm * n_main_tiles >= 224) {
+            const int64_t n_main = n_main_tiles * 256, n_tail = N - n_main;           // (256 | 32: gate/up pairs stay whole)
+            const size_t es_out = epi == EPI_GATEUP ? 2 : 4;
+            const int64_t col_main = epi == EPI_GATEUP ? n_main / 2 : n_main;
+            FL_TRY(launch_gemm_mfma_impl(L, W, x, bias, y, T, n_main, K, epi, row_scale, 1, N, true));
+            return launch_gemm_mfma_impl(L, (const bf16_t *)W + (size_t)n_main * K, x, bias ? bias + n_main : nullptr,
+                                         (char *)y + (size_t)col_main * es_out, T, n_tail, K, epi, row_scale, 1, N, false);
+        }
+    }
+    return launch_gemm_mfma_impl(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit, N, true);
+}
+
+static int launch_gemm_mfma_impl(Launcher &L, const void *W, const void *x, const float *bias, void *y,
+                                 int64_t T, int64_t N, int64_t K, int epi, const float *row_scale, int ksplit, int64_t ldc, bool allow8p) {
     // 256x256 phase-interleaved kernel (k_gemm_8p.hip).  FL_GEMM_8P: 0 off, 1 when the grid fills the chip, 2 always
     const char *e8 = getenv("FL_GEMM_8P");                      // read per call: tests switch it
-    const int use8p = e8 && *e8 ? atoi(e8) : 1;
+    const int use8p = !allow8p ? 0 : (e8 && *e8 ? atoi(e8) : 1);
     if (use8p && K % 64 == 0 && (K / 64) / ksplit >= 2 && (ksplit == 1 || (!bias && epi == EPI_F32))) {
         // one workgroup per CU: worth it when the last round of tiles is nearly full (gemm_8p_fill)
         if (use8p >= 2 || gemm_8p_fill(T, N, K, ksplit) > 0)
-            return launch_gemm_8p(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
+            return launch_gemm_8p(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit, ldc);
     }
     static const int use256 = getenv("FL_GEMM_256") ? atoi(getenv("FL_GEMM_256")) : 1;
     if (use256 && T >= 192 && K / BK >= 3 && (ksplit == 1 || (!bias && epi == EPI_F32))) {
@@ -332,7 +363,7 @@ int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bia
             snprintf(tag2, sizeof tag2, "256x128,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");
             Launcher L2 = L; L2.tag = tag2;
             return L2.launch(KC_GEMM_MFMA, bytes2, 2.0 * T * N * K, gemm_mfma256_kernel, dim3((unsigned)(tm2 * tn2), (unsigned)ksplit), dim3(512),
-                            lds2, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tm2, tn2, row_scale, ksplit);
+                            lds2, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tm2, tn2, row_scale, ksplit, (int)ldc);
         }
     }
     const int tiles_m = (int)((T + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
@@ -345,7 +376,7 @@ int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bia
     Launcher LL = L; LL.tag = tag;
     return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, gemm_mfma_kernel, dim3((unsigned)(tiles_m * tiles_n), (unsigned)ksplit),
                     dim3(256), lds, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi,
-                    tiles_m, tiles_n, row_scale, ksplit);
+                    tiles_m, tiles_n, row_scale, ksplit, (int)ldc);
 }
 
 }  // namespace fl

@@ -160,3 +160,24 @@ def test_linear_dma_ring_kernel(fa, T, N, K, epi, monkeypatch):
     tight = fa.op_linear(xb, wb, None, epilogue=epi)              # the other kernels on the same data: same result up to summation order
     # (gate/up outputs are bf16 on both sides: each may sit one ulp off the exact value, in opposite directions)
     np.testing.assert_allclose(y, tight, atol=(2e-3 if epi else 2e-5 * np.sqrt(K) + 1e-5), rtol=2 ** -7 if epi else 1e-5)
+
+
+# column-peeled GEMM (k_gemm_mfma.hip launch_gemm_mfma): whole rounds of 256x256 tiles on the phase-interleaved kernel, the
+# remaining columns (<= a quarter round) as a second launch on smaller tiles writing its own column range of the same output
+@pytest.mark.parametrize("T,N,K,epi,bias", [(4096, 4352, 1024, 0, True), (2048, 8448, 1024, 0, False), (4096, 2176, 1024, 1, False),
+                                            (4000, 4300, 1088, 0, True)])
+def test_linear_peeled_columns(fa, T, N, K, epi, bias):
+    x, w = _rand((T, K), 51), _rand((N if not epi else 2 * N, K), 52, 0.05)
+    b = _rand((N,), 53) if bias else None
+    xb, wb = synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w)
+    y = fa.op_linear(xb, wb, b, epilogue=epi)
+    xf, wf = synth.bf16_bits_to_f32(xb), synth.bf16_bits_to_f32(wb)
+    ref = xf @ wf.T                                               # fp32 BLAS: 1e-5-level agreement is all that is asked
+    if b is not None:
+        ref = ref + b
+    if epi:
+        g, u = ref[:, :N].astype(np.float64), ref[:, N:].astype(np.float64)
+        ref = g / (1.0 + np.exp(-g)) * u
+        np.testing.assert_allclose(y, ref, atol=2e-3, rtol=2 ** -7)
+    else:
+        np.testing.assert_allclose(y, ref, atol=4e-5 * np.sqrt(K) + 1e-4, rtol=1e-4)
