@@ -26,7 +26,13 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <type_traits>
+#include <utility>
+#include <vector>
 
+#include "attn_common.h"
 #include "kernels.h"
 
 namespace fl {
@@ -63,146 +69,355 @@ __device__ inline void stage_half(const bf16_t *__restrict__ M, int nrows, int K
     }
 }
 
+// Stream-K workspace (SK instantiation; otherwise the grid is tiles x K slices, one segment per workgroup)
+struct StreamK {
+    float *part;          // [workgroups][2][256 * 256] fp32 partial accumulators, lane-major (16-B coalesced)
+    unsigned *flag;       // [tiles] tickets: pieces of the tile that have been published (the last arriver resets it)
+};
+
+// STAMP: diagnostic instantiation (FL_8P_STAMPS=file): every workgroup records the 100 MHz wall clock and the core clock at
+// entry / after the (first) prologue / after the (last) K loop / at exit; the production instantiation holds no stamp code.
+//
+// SK (stream-K): the grid is ONE workgroup per CU and the work is the line of (tile, K step) units, cut into equal
+// pieces; a workgroup walks its piece as up to three segments -- the end of a tile another workgroup began, whole tiles,
+// the beginning of a tile the next workgroup(s) finish.  Every piece of a split tile is published as fp32 partial
+// accumulators (written through, sc1) and takes a ticket of the tile; the LAST arriver adds the pieces in K order and runs
+// the tile's epilogue.  Nobody ever waits for another workgroup, so the grid need not be co-resident.
+template <bool STAMP, bool SK>
 __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
                                                       const float *__restrict__ bias, void *__restrict__ out,
                                                       int T, int N, int K, int epi, int tiles_m, int tiles_n,
-                                                      const float *__restrict__ row_scale, int ksplit, int ldc) {
+                                                      const float *__restrict__ row_scale, int ksplit, int ldc,
+                                                      unsigned long long *__restrict__ stamps, StreamK sk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [parity][A0 A1 B0 B1]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform values live in SGPRs)
     const int wr = wave >> 2, wc = wave & 3;
     const int m16 = lane & 15, kg = lane >> 4;
+    unsigned long long st[8];
+    if (STAMP) { st[0] = __builtin_amdgcn_s_memrealtime(); st[1] = __builtin_amdgcn_s_memtime(); }
 
     // XCD-aware remap (bijective): ids that share an XCD get consecutive tiles (same W panel in its L2)
-    const int nwg = tiles_m * tiles_n, bid = blockIdx.x;
+    const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
-    const int li = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-    const int tn = li / tiles_m, tm = li % tiles_m;
-    const int m0 = tm * P_BM, n0 = tn * P_BN;
+    const int wid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int nk_all = K / P_BK;
+    const int U = tiles_m * tiles_n * nk_all;                                     // stream-K: units on the line (host: < 2^31 / grid)
+    auto cut = [&](int w) { return (int)((long long)U * w / nwg); };
+    int u = SK ? cut(wid) : 0;
+    const int u_end = SK ? cut(wid + 1) : 0;
+    bool first_seg = true;
 
-    // split-K: blockIdx.y owns K tiles [kt0, kt0 + nk) and writes its own fp32 slab
-    const int nk_all = K / P_BK, kz = blockIdx.y;
-    const int kt0 = (int)((long long)nk_all * kz / ksplit), nk = (int)((long long)nk_all * (kz + 1) / ksplit) - kt0;
-    X += (size_t)kt0 * P_BK; W += (size_t)kt0 * P_BK;
-    if (ksplit > 1) out = reinterpret_cast<float *>(out) + (size_t)kz * T * N;
+    for (;;) {
+        // ---- this segment: tile li, K tiles [kt0, kt0 + nk) ----
+        int li, kt0, nk;
+        if (SK) {
+            if (u >= u_end) break;
+            li = u / nk_all; kt0 = u - li * nk_all;
+            nk = min(nk_all - kt0, u_end - u);
+            u += nk;
+        } else {                                                                   // split-K: blockIdx.y owns a K slice and its own fp32 slab
+            const int kz = blockIdx.y;
+            li = wid;
+            kt0 = (int)((long long)nk_all * kz / ksplit); nk = (int)((long long)nk_all * (kz + 1) / ksplit) - kt0;
+        }
+        const int tn = li / tiles_m, tm = li % tiles_m;
+        const int m0 = tm * P_BM, n0 = tn * P_BN;
+        const bf16_t *Xs = X + (size_t)kt0 * P_BK, *Ws = W + (size_t)kt0 * P_BK;
 
-    float4v acc[8][4];
+        float4v acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+        for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; j++) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
-    auto hbuf = [&](int tile, int which) -> unsigned char * { return lds + ((tile & 1) * 4 + which) * P_HALF; };   // which: 0 A0, 1 A1, 2 B0, 3 B1
-    auto stA = [&](int h, int tile) { if (tile < nk) stage_half<true>(X, T, K, m0, tile * P_BK, h, hbuf(tile, h), wave, lane); };
-    auto stB = [&](int h, int tile) { if (tile < nk) stage_half<false>(W, N, K, n0, tile * P_BK, h, hbuf(tile, 2 + h), wave, lane); };
+        auto hbuf = [&](int tile, int which) -> unsigned char * { return lds + ((tile & 1) * 4 + which) * P_HALF; };   // which: 0 A0, 1 A1, 2 B0, 3 B1
+        auto stA = [&](int h, int tile) { if (tile < nk) stage_half<true>(Xs, T, K, m0, tile * P_BK, h, hbuf(tile, h), wave, lane); };
+        auto stB = [&](int h, int tile) { if (tile < nk) stage_half<false>(Ws, N, K, n0, tile * P_BK, h, hbuf(tile, 2 + h), wave, lane); };
 
-    // prologue: tile 0 whole, A0 / B0 of tile 1 (what phases 3, 4 of "tile -1" would have staged)
-    stA(0, 0); stB(0, 0); stB(1, 0); stA(1, 0); stA(0, 1); stB(0, 1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs half a phase behind (+10 %, gemm_probe)
+        // prologue: tile 0 whole, A0 / B0 of tile 1 (what phases 3, 4 of "tile -1" would have staged)
+        stA(0, 0); stB(0, 0); stB(1, 0); stA(1, 0); stA(0, 1); stB(0, 1);
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs half a phase behind (+10 %, gemm_probe)
+        if (STAMP && first_seg) { st[2] = __builtin_amdgcn_s_memrealtime(); st[3] = __builtin_amdgcn_s_memtime(); }
 
-    bf16x8p fa[4][2], fb0[2][2], fb1[2][2];
-    const int arow = wr * 64 + m16, brow = wc * 32 + m16;
+        bf16x8p fa[4][2], fb0[2][2], fb1[2][2];
+        const int arow = wr * 64 + m16, brow = wc * 32 + m16;
 #define P_WAIT(TAIL)                                                                   \
-    if (TAIL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         \
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (TAIL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #define P_MFMA(MI0, NJ0, FB)                                                           \
-    __builtin_amdgcn_s_barrier();                                                      \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
-    __builtin_amdgcn_sched_barrier(0);   /* pins the cluster between the barriers; s_setprio around it: -2.5 % */ \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                   \
-        _Pragma("unroll") for (int i = 0; i < 4; i++)                                  \
-            _Pragma("unroll") for (int j = 0; j < 2; j++)                              \
-                acc[MI0 + i][NJ0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], FB[j][ks], acc[MI0 + i][NJ0 + j], 0, 0, 0); \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-    __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                             \
+        __builtin_amdgcn_sched_barrier(0);   /* pins the cluster between the barriers; s_setprio around it: -2.5 % */ \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                               \
+            _Pragma("unroll") for (int i = 0; i < 4; i++)                              \
+                _Pragma("unroll") for (int j = 0; j < 2; j++)                          \
+                    acc[MI0 + i][NJ0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], FB[j][ks], acc[MI0 + i][NJ0 + j], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        __builtin_amdgcn_s_barrier();
 
-    for (int u = 0; u < nk; u++) {
-        const bool tail = u + 2 >= nk;                            // fewer than four young half tiles behind us
-        const unsigned char *A0 = hbuf(u, 0), *A1 = hbuf(u, 1), *B0 = hbuf(u, 2), *B1 = hbuf(u, 3);
-        // ---- phase 1: quadrant (m0, n0) ----
+        for (int t = 0; t < nk; t++) {
+            const bool tail = t + 2 >= nk;                            // fewer than four young half tiles behind us
+            const unsigned char *A0 = hbuf(t, 0), *A1 = hbuf(t, 1), *B0 = hbuf(t, 2), *B1 = hbuf(t, 3);
+            // ---- phase 1: quadrant (m0, n0) ----
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+            for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) fb0[j][ks] = frag(B0, brow + j * 16, ks * 4 + kg);
+                for (int ks = 0; ks < 2; ks++) fb0[j][ks] = frag(B0, brow + j * 16, ks * 4 + kg);
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+            for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) fa[i][ks] = frag(A0, arow + i * 16, ks * 4 + kg);
-        stB(1, u + 1);
-        P_WAIT(tail)
-        P_MFMA(0, 0, fb0)
-        // ---- phase 2: (m0, n1) ----
+                for (int ks = 0; ks < 2; ks++) fa[i][ks] = frag(A0, arow + i * 16, ks * 4 + kg);
+            stB(1, t + 1);
+            P_WAIT(tail)
+            P_MFMA(0, 0, fb0)
+            // ---- phase 2: (m0, n1) ----
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+            for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) fb1[j][ks] = frag(B1, brow + j * 16, ks * 4 + kg);
-        stA(1, u + 1);
-        P_WAIT(tail)
-        P_MFMA(0, 2, fb1)
-        // ---- phase 3: (m1, n1) ----
+                for (int ks = 0; ks < 2; ks++) fb1[j][ks] = frag(B1, brow + j * 16, ks * 4 + kg);
+            stA(1, t + 1);
+            P_WAIT(tail)
+            P_MFMA(0, 2, fb1)
+            // ---- phase 3: (m1, n1) ----
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+            for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) fa[i][ks] = frag(A1, arow + i * 16, ks * 4 + kg);
-        stA(0, u + 2);
-        P_WAIT(tail)
-        P_MFMA(4, 2, fb1)
-        // ---- phase 4: (m1, n0) ----
-        stB(0, u + 2);
-        P_WAIT(tail)
-        P_MFMA(4, 0, fb0)
-    }
+                for (int ks = 0; ks < 2; ks++) fa[i][ks] = frag(A1, arow + i * 16, ks * 4 + kg);
+            stA(0, t + 2);
+            P_WAIT(tail)
+            P_MFMA(4, 2, fb1)
+            // ---- phase 4: (m1, n0) ----
+            stB(0, t + 2);
+            P_WAIT(tail)
+            P_MFMA(4, 0, fb0)
+        }
 #undef P_MFMA
 #undef P_WAIT
-    if (wr == 0) __builtin_amdgcn_s_barrier();                    // balances group 1's extra barrier
+        if (wr == 0) __builtin_amdgcn_s_barrier();                    // balances group 1's extra barrier
+        if (STAMP) { st[4] = __builtin_amdgcn_s_memrealtime(); st[5] = __builtin_amdgcn_s_memtime(); }
+        __builtin_amdgcn_s_barrier();                                  // every wave is past its last fragment read: LDS is free
+        first_seg = false;
 
-    // C/D map of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-    const int cn = lane & 15, rm = (lane >> 4) * 4;
+        // (lane-derived addresses of the code below must not be hoisted over the K loop, where every register counts:
+        // they hang off a thread id the optimiser cannot see through)
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));
+
+        // ---- epilogue.  C/D map of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.  The row scales of the tile go
+        // through LDS (one global load per row, not one per accumulator row per lane); whole tiles take a path without
+        // bounds checks (the checked one spends a branch pair per store: ~6 us of VALU per tile, tools/stamps_8p.py).
+        void *outz = out;
+        if (!SK && ksplit > 1) outz = reinterpret_cast<float *>(out) + (size_t)blockIdx.y * T * N;
+        const int cn = tid_e & 15, rm = ((tid_e >> 4) & 3) * 4;
+        float *rs_lds = reinterpret_cast<float *>(lds);
+        int *last_lds = reinterpret_cast<int *>(lds + 2048);
+        if (tid_e < P_BM) rs_lds[tid_e] = row_scale ? row_scale[min(m0 + tid_e, T - 1)] : 1.0f;
+        __syncthreads();
+        const bool whole = m0 + P_BM <= T && n0 + P_BN <= N;
+        const int mw = m0 + wr * 128 + rm, nw = n0 + wc * 64 + cn;
+        float bj[4];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-            const int m = m0 + wr * 128 + i * 16 + rm + rg;
-            if (m >= T) continue;
-            const float rs = row_scale ? row_scale[m] : 1.0f;
+        for (int j = 0; j < 4; j++) bj[j] = bias && epi != EPI_GATEUP && nw + j * 16 < N ? bias[nw + j * 16] : 0.f;
+        // rows [16 i, 16 i + 16) of this wave's 128 x 64 block: v[j] = the accumulator tile of column block j
+        auto store_rows = [&](auto checked, int i, const float4v (&v)[4]) {
+            constexpr bool CHK = decltype(checked)::value;
+            const float4v rs4 = *reinterpret_cast<const float4v *>(rs_lds + wr * 128 + i * 16 + rm);
             if (epi == EPI_GATEUP) {
+                bf16_t *ob = reinterpret_cast<bf16_t *>(outz) + (size_t)(mw + i * 16) * (ldc / 2) + (nw >> 5) * 16 + cn;   // j = 2: + 16
 #pragma unroll
-                for (int j = 0; j < 4; j += 2) {
-                    const int n = n0 + wc * 64 + j * 16 + cn;        // gate column; up = n + 16
-                    if (n + 16 < N) {
-                        const int qq = (n >> 5) * 16 + (n & 15);
-                        const float gt = acc[i][j][rg] * rs, up = acc[i][j + 1][rg] * rs;
-                        const float a = gt / (1.0f + expf(-gt)) * up;
-                        reinterpret_cast<bf16_t *>(out)[(size_t)m * (ldc / 2) + qq] = float_to_bf16_bits(a);
+                for (int rg = 0; rg < 4; rg++) {
+                    if (CHK && mw + i * 16 + rg >= T) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; j += 2) {
+                        if (CHK && nw + j * 16 + 16 >= N) continue;                   // gate column nw + 16 j, up 16 further
+                        const float gt = v[j][rg] * rs4[rg], up = v[j + 1][rg] * rs4[rg];
+                        // silu(g) * u: v_exp + v_rcp (1 ulp each); the result is rounded to bf16
+                        const float av = gt * up * __builtin_amdgcn_rcpf(1.0f + __expf(-gt));
+                        ob[(size_t)rg * (ldc / 2) + j * 8] = float_to_bf16_bits(av);
                     }
                 }
             } else {
+                float *ob = reinterpret_cast<float *>(outz) + (size_t)(mw + i * 16) * ldc + nw;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int n = n0 + wc * 64 + j * 16 + cn;
-                    if (n < N) reinterpret_cast<float *>(out)[(size_t)m * ldc + n] = acc[i][j][rg] * rs + (bias ? bias[n] : 0.f);
+                for (int rg = 0; rg < 4; rg++) {
+                    if (CHK && mw + i * 16 + rg >= T) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (CHK && nw + j * 16 >= N) continue;
+                        ob[(size_t)rg * ldc + j * 16] = v[j][rg] * rs4[rg] + bj[j];
+                    }
                 }
             }
+        };
+
+        if (!SK || nk == nk_all) {
+            // ---- the whole K of the tile is in this workgroup's accumulators ----
+            if (whole) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) store_rows(std::false_type{}, i, acc[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) store_rows(std::true_type{}, i, acc[i]);
+            }
+        } else {
+            // ---- a piece of a tile: publish the partial accumulators (slot 0: the piece ends the tile or lies inside it =
+            // this workgroup's first segment; slot 1: it begins the tile = its last segment), take a ticket; the last
+            // arriver sums the pieces in K order and runs the epilogue ----
+            float *pw = sk.part + (((size_t)wid * 2 + (kt0 > 0 ? 0 : 1)) * (P_BM * P_BN) + (size_t)tid_e * 4);
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) st_sc1_x4(pw + (size_t)(i * 4 + j) * 2048, acc[i][j]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int t0 = li * nk_all, t1 = t0 + nk_all;
+            int w0 = (int)((long long)t0 * nwg / U);                  // the workgroup whose piece holds the tile's K step 0
+            while (cut(w0 + 1) <= t0) w0++;
+            while (cut(w0) > t0) w0--;
+            int nseg = 1;
+            while (cut(w0 + nseg) < t1) nseg++;
+            __syncthreads();
+            if (tid_e == 0) {
+                const unsigned tk = __hip_atomic_fetch_add(sk.flag + li, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = tk == (unsigned)nseg - 1;
+                if (last) {
+                    __hip_atomic_store(sk.flag + li, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everyone has arrived
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                *last_lds = last;
+            }
+            __syncthreads();
+            if (*last_lds) {
+                // (the accumulators are dead: four pieces x four tiles are loaded at once, then added in K order)
+                const float4v *p0 = reinterpret_cast<const float4v *>(sk.part) + tid_e;
+#pragma unroll 1
+                for (int i = 0; i < 8; i++) {
+                    float4v v[4] = {float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}};
+                    for (int sg0 = 0; sg0 < nseg; sg0 += 4) {
+                        float4v t[4][4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            if (sg0 + e < nseg) {
+                                const int wq = w0 + sg0 + e, slot = cut(wq) > t0 ? 0 : 1;
+                                const float4v *pq = p0 + ((size_t)wq * 2 + slot) * (P_BM * P_BN / 4) + (size_t)(i * 4) * 512;
+#pragma unroll
+                                for (int j = 0; j < 4; j++) t[e][j] = pq[(size_t)j * 512];
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            if (sg0 + e < nseg) {
+#pragma unroll
+                                for (int j = 0; j < 4; j++) v[j] += t[e][j];
+                            }
+                        }
+                    }
+                    if (whole) store_rows(std::false_type{}, i, v);
+                    else store_rows(std::true_type{}, i, v);
+                }
+            }
+        }
+        if (!SK) break;
+        __syncthreads();                                               // the row scales are read: the next prologue may write LDS
+    }
+    if (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st[6] = __builtin_amdgcn_s_memrealtime(); st[7] = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            unsigned xccid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xccid));
+            unsigned long long *o = stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 10;
+            for (int i = 0; i < 8; i++) o[i] = st[i];
+            o[8] = hwid; o[9] = xccid;
         }
     }
 }
 
+// Stream-K workspace of one stream: two partial tiles per workgroup and a ticket per tile (zero between launches)
+struct SkSpace { float *part = nullptr; unsigned *flag = nullptr; int nwg = 0, ntile = 0; };
+static int streamk_space(hipStream_t stream, int nwg, int ntile, StreamK *sk) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, SkSpace> spaces;     // never freed: 128 MiB per stream that runs long-prompt GEMMs
+    int dev = 0;
+    FL_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    SkSpace &sp = spaces[{dev, stream}];
+    if (sp.nwg < nwg || sp.ntile < ntile) {
+        if (sp.part) { FL_HIP(hipStreamSynchronize(stream)); (void)hipFree(sp.part); (void)hipFree(sp.flag); }
+        sp = SkSpace{};
+        const int nt = std::max(ntile, 4096);
+        FL_HIP(hipMalloc(&sp.part, (size_t)nwg * 2 * P_BM * P_BN * sizeof(float)));
+        FL_HIP(hipMalloc(&sp.flag, (size_t)nt * sizeof(unsigned)));
+        FL_HIP(hipMemset(sp.flag, 0, (size_t)nt * sizeof(unsigned)));
+        sp.nwg = nwg; sp.ntile = nt;
+    }
+    *sk = StreamK{sp.part, sp.flag};
+    return FL_OK;
+}
+
+static int cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cached[dev]) cached[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    return cached[dev];
+}
+
 int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
-                   int epi, const float *row_scale, int ksplit, int64_t ldc) {
+                   int epi, const float *row_scale, int ksplit, int64_t ldc, bool streamk) {
     if (ldc <= 0) ldc = N;
     if (ksplit > 1 && ldc != N) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: K slices write whole slabs (ldc == N)");
+    if (streamk && ksplit != 1) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: stream-K takes the whole K");
     const int tiles_m = (int)((T + P_BM - 1) / P_BM), tiles_n = (int)((N + P_BN - 1) / P_BN);
     if (K % P_BK || K / P_BK / ksplit < 2) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: K must give at least two 64-wide tiles per slice");
     if (ksplit > 1 && (bias || epi != EPI_F32)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "split-K GEMM: fp32 epilogue without bias only");
-    FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(gemm_8p_kernel), P_LDS));
     const double bytes = ((double)N * K + (double)T * K) * 2.0;
     char tag[32];
-    snprintf(tag, sizeof tag, "8p,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");
+    snprintf(tag, sizeof tag, "8p,%lldx%lld%s", (long long)N, (long long)K, streamk ? ",streamK" : ksplit > 1 ? ",splitK" : "");
     Launcher LL = L; LL.tag = tag;
-    return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, gemm_8p_kernel, dim3((unsigned)(tiles_m * tiles_n), (unsigned)ksplit), dim3(512),
-                     P_LDS, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc);
+    StreamK sk{nullptr, nullptr};
+    dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)ksplit);
+    if (streamk) {
+        // one workgroup per CU, but never more than one per two K steps of work
+        const int64_t units = (int64_t)tiles_m * tiles_n * (K / P_BK);
+        if (units >= (int64_t)1 << 30) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: stream-K line too long");
+        // pieces aligned with the tiles keep the workgroups that share a W or X panel in lock step (its L2 hits): split every
+        // tile into the same number of pieces, at most eight (the last arriver adds them), while the grid fits the chip
+        const int64_t nt = (int64_t)tiles_m * tiles_n, cus = cu_count();
+        const int64_t split = std::max<int64_t>(1, std::min<int64_t>({(int64_t)8, cus / std::max<int64_t>(1, nt), (K / P_BK) / 4}));
+        const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>(nt * split, units / 2));
+        FL_TRY(streamk_space(L.stream, nwg, tiles_m * tiles_n, &sk));
+        grid = dim3((unsigned)nwg, 1);
+    }
+    const bool stamp = getenv("FL_8P_STAMPS") != nullptr;           // diagnostics only: synchronous, appends one record per launch
+    auto kern = streamk ? (stamp ? gemm_8p_kernel<true, true> : gemm_8p_kernel<false, true>) : (stamp ? gemm_8p_kernel<true, false> : gemm_8p_kernel<false, false>);
+    FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), P_LDS));
+    if (stamp) {
+        const char *path = getenv("FL_8P_STAMPS");
+        const size_t nwg = (size_t)grid.x * grid.y;
+        unsigned long long *d = nullptr;
+        FL_HIP(hipMalloc(&d, nwg * 80));
+        const int rc = LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, grid, dim3(512), P_LDS, (const bf16_t *)W,
+                                 (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, d, sk);
+        std::vector<unsigned long long> h(nwg * 10);
+        FL_HIP(hipStreamSynchronize(L.stream));
+        FL_HIP(hipMemcpy(h.data(), d, nwg * 80, hipMemcpyDeviceToHost));
+        (void)hipFree(d);
+        if (FILE *f = fopen(path, "a")) {
+            fprintf(f, "launch %lld %lld %lld %d %zu\n", (long long)T, (long long)N, (long long)K, epi, nwg);
+            for (size_t i = 0; i < nwg; i++) {
+                for (int j = 0; j < 10; j++) fprintf(f, "%llu ", h[i * 10 + j]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+        return rc;
+    }
+    return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, grid, dim3(512), P_LDS, (const bf16_t *)W, (const bf16_t *)x,
+                     bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, (unsigned long long *)nullptr, sk);
 }
 
 }  // namespace fl

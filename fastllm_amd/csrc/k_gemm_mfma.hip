@@ -289,7 +289,9 @@ static int gemm_256_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_spl
 }
 
 // how many K splits the launcher will use for this shape when the caller allows up to max_split slabs
+static bool gemm_streamk_whole(int64_t T, int64_t N, int64_t K, int epi);
 int gemm_mfma_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
+    if (gemm_streamk_whole(T, N, K, epi)) return 1;                 // one launch, partials meet inside it
     {
         const char *e8 = getenv("FL_GEMM_8P");
         if (!(e8 && *e8 && atoi(e8) == 0)) {
@@ -312,26 +314,53 @@ static int launch_gemm_mfma_impl(Launcher &L, const void *W, const void *x, cons
                                  int64_t T, int64_t N, int64_t K, int epi, const float *row_scale, int ksplit, int64_t ldc, bool allow8p);
 
 // A long prompt's grid of 256x256 tiles rarely fills whole rounds of the chip: Qwen2-7B at T = 4096 has 288 QKV tiles
-// (1.125 rounds: the kernel was rejected and the projection ran on 128x128 tiles at 0.65 PFLOP/s) and 2368 gate/up
-// tiles (9.25 rounds: the last quarter round costs a full one).  So the matrix is PEELED by columns: as many whole
-// rounds as fit run on the 256x256 kernel, the remaining columns -- when they would fill at most a quarter of a round --
-// as a second launch on the smaller tiles.  Each launch writes its own column range of the same output (ldc).
+// (1.125 rounds: the kernel was rejected and the projection ran on 128x128 tiles at 0.65 PFLOP/s), 2368 gate/up tiles
+// (9.25 rounds: the last quarter round costs a full one) and 224 o_proj / down tiles (an eighth of the chip idle).  So the
+// matrix is PEELED by columns: as many whole rounds as fit run as plain tiles, the remaining columns as a second launch
+// that writes its own column range of the same output (ldc) -- in stream-K form (k_gemm_8p.hip: one workgroup per CU,
+// the (tile, K step) line cut into equal pieces), or, with FL_GEMM_STREAMK=0, on the smaller tiles when the remainder
+// is at most a quarter round.  A grid of less than one round runs stream-K whole when that saves more than it costs.
+static int streamk_on() {
+    const char *e = getenv("FL_GEMM_STREAMK");                  // read per call: tests switch it
+    return e && *e ? atoi(e) : 1;
+}
+// Whole-matrix stream-K (FL_GEMM_STREAMK=2: grids of 96..255 tiles; =3: every shape the kernel takes -- tests).  Off by
+// default: measured on Qwen2-7B's down_proj at T = 4096 (224 tiles, an eighth of the chip idle) it LOST 440 -> 535 us --
+// pieces that start inside a tile take the workgroups that share a W or X panel out of lock step (their L2 hits become
+// MALL/HBM reads), and every split tile moves its fp32 accumulators through memory twice (profiles/r02/README.md).
+static bool gemm_streamk_whole(int64_t T, int64_t N, int64_t K, int epi) {
+    const char *e8 = getenv("FL_GEMM_8P");
+    const int sk = streamk_on();
+    (void)epi;
+    if (sk < 2 || (e8 && *e8 && atoi(e8) != 1) || T < 256 || K % 64 || K / 64 < 8) return false;
+    if (sk >= 3) return true;
+    const int64_t t8 = ((T + 255) / 256) * ((N + 255) / 256);
+    return T >= 1024 && K / 64 >= 32 && t8 >= 96 && t8 < 256;
+}
+
 int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bias, void *y,
                      int64_t T, int64_t N, int64_t K, int epi, const float *row_scale, int ksplit) {
     static const int peel = getenv("FL_GEMM_PEEL") ? atoi(getenv("FL_GEMM_PEEL")) : 1;
     const char *e8 = getenv("FL_GEMM_8P");
     const int use8p = e8 && *e8 ? atoi(e8) : 1;
+    const int sk = streamk_on();
+    if (ksplit == 1 && gemm_streamk_whole(T, N, K, epi))
+        return launch_gemm_8p(L, W, x, bias, y, T, N, K, epi, row_scale, 1, N, true);
     if (peel && use8p == 1 && ksplit == 1 && T >= 256 && K % 64 == 0 && (K / 64) >= 16) {
         const int64_t tm = (T + 255) / 256, tn = (N + 255) / 256, t8 = tm * tn;
-        const int64_t full = t8 / 256, rem = t8 % 256;
+        const int64_t full = t8 / 256;
         const int64_t n_main_tiles = full * 256 / tm;                 // whole column tiles inside the full rounds
-        if (full >= 1 && rem > 0 && rem <= 64 && n_main_tiles >= 1 && n_main_tiles < tn && tm * n_main_tiles >= 224) {
+        const int64_t tail_tiles = t8 - tm * n_main_tiles;
+        if (full >= 1 && tail_tiles > 0 && tail_tiles <= (sk ? 128 : 64) && n_main_tiles >= 1 && n_main_tiles < tn && tm * n_main_tiles >= 224) {
             const int64_t n_main = n_main_tiles * 256, n_tail = N - n_main;           // (256 | 32: gate/up pairs stay whole)
             const size_t es_out = epi == EPI_GATEUP ? 2 : 4;
             const int64_t col_main = epi == EPI_GATEUP ? n_main / 2 : n_main;
             FL_TRY(launch_gemm_mfma_impl(L, W, x, bias, y, T, n_main, K, epi, row_scale, 1, N, true));
-            return launch_gemm_mfma_impl(L, (const bf16_t *)W + (size_t)n_main * K, x, bias ? bias + n_main : nullptr,
-                                         (char *)y + (size_t)col_main * es_out, T, n_tail, K, epi, row_scale, 1, N, false);
+            const bf16_t *Wt = (const bf16_t *)W + (size_t)n_main * K;
+            const float *bt = bias ? bias + n_main : nullptr;
+            void *yt = (char *)y + (size_t)col_main * es_out;
+            if (sk) return launch_gemm_8p(L, Wt, x, bt, yt, T, n_tail, K, epi, row_scale, 1, N, true);
+            return launch_gemm_mfma_impl(L, Wt, x, bt, yt, T, n_tail, K, epi, row_scale, 1, N, false);
         }
     }
     return launch_gemm_mfma_impl(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit, N, true);

@@ -137,7 +137,7 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
                   int max_split = 1, int *n_split_out = nullptr);
 // ldc: row stride of y in elements of the FULL output width (0 = N): a launch may cover a column range of a wider matrix
 int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
-                   int epi, const float *row_scale, int ksplit, int64_t ldc = 0);
+                   int epi, const float *row_scale, int ksplit, int64_t ldc = 0, bool streamk = false);
 bool gemm_skinny_supported(int64_t T, int64_t N, int64_t K);
 int gemm_skinny_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split);
 int launch_gemm_skinny(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,

@@ -181,3 +181,26 @@ def test_linear_peeled_columns(fa, T, N, K, epi, bias):
         np.testing.assert_allclose(y, ref, atol=2e-3, rtol=2 ** -7)
     else:
         np.testing.assert_allclose(y, ref, atol=4e-5 * np.sqrt(K) + 1e-4, rtol=1e-4)
+
+
+# stream-K form of the 256x256 kernel (one workgroup per CU over the (tile, K step) line; pieces of a tile meet through fp32
+# partials and a per-tile ticket).  The product uses it for the peeled tail of a long prompt's GEMM (above); FL_GEMM_STREAMK=3
+# runs whole matrices through it: aligned pieces, pieces that straddle tiles (41 K steps cut in two), ragged edges, gate/up
+@pytest.mark.parametrize("T,N,K,epi,bias", [(2048, 3584, 4096, 0, False), (1024, 6144, 2624, 0, True), (2000, 3000, 1088, 0, True),
+                                            (1024, 2176, 2624, 1, False), (300, 520, 512, 0, False)])
+def test_linear_streamk_whole(fa, monkeypatch, T, N, K, epi, bias):
+    monkeypatch.setenv("FL_GEMM_STREAMK", "3")
+    x, w = _rand((T, K), 61), _rand((N if not epi else 2 * N, K), 62, 0.05)
+    b = _rand((N,), 63) if bias else None
+    xb, wb = synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w)
+    y = fa.op_linear(xb, wb, b, epilogue=epi)
+    y2 = fa.op_linear(xb, wb, b, epilogue=epi)                    # tickets are back at zero, partial slots are reused
+    assert np.array_equal(y, y2)
+    ref = synth.bf16_bits_to_f32(xb) @ synth.bf16_bits_to_f32(wb).T
+    if b is not None:
+        ref = ref + b
+    if epi:
+        g, u = ref[:, :N].astype(np.float64), ref[:, N:].astype(np.float64)
+        np.testing.assert_allclose(y, g / (1.0 + np.exp(-g)) * u, atol=2e-3, rtol=2 ** -7)
+    else:
+        np.testing.assert_allclose(y, ref, atol=4e-5 * np.sqrt(K) + 1e-4, rtol=1e-4)
