@@ -253,7 +253,8 @@ bool gemm_mfma_supported(int dtype, int64_t T, int64_t N, int64_t K) {
 // (Mistral QKV T = 2048: 152 -> 123 us, T = 1024 with two slices: 78 -> 71 us) and loses when they are 16 K tiles
 // (o_proj T = 768 in four slices: 41 -> 50 us).
 static int gemm_8p_fill(int64_t T, int64_t N, int64_t K, int ks) {
-    if (T < 256 || K % 64 || ks < 1 || (K / 64) / ks < 16) return 0;   // keep the pipeline long enough to pay for its ramp
+    static const int mink = getenv("FL_8P_MINK") ? atoi(getenv("FL_8P_MINK")) : 8;   // K steps per slice (16 before the epilogue was trimmed: gemm_probe)
+    if (T < 256 || K % 64 || ks < 1 || (K / 64) / ks < mink) return 0;   // keep the pipeline long enough to pay for its ramp
     const int64_t t8 = ((T + 255) / 256) * ((N + 255) / 256) * ks, rounds = (t8 + 255) / 256;
     const int fill = (int)(t8 * 1024 / (rounds * 256));
     if (t8 < 192) return 0;
@@ -261,12 +262,19 @@ static int gemm_8p_fill(int64_t T, int64_t N, int64_t K, int ks) {
     return fill >= 768 && (K / 64) / ks >= 24 ? fill : 0;               // 75 %: long slices only
 }
 
-// K slices that let the 256x256 kernel cover the chip best (ties: fewer slices): 0 if none does
+// K slices for the 256x256 kernel: among the splits whose grid covers the chip well enough (gemm_8p_fill), the cheapest by
+// a three-term model fitted to tools/gemm_probe.py / prefill_profile.py -- rounds x (K steps per slice x 1.56 us + ~6 us of
+// prologue and epilogue) + the slabs' trip through memory (written here, read by the summing launch, ~4 TB/s each way).
+// (Best fill alone picked 5 slices of two rounds for Mistral-7B's QKV at T = 1024: 77 us + a 35 us RoPE against 56 + 11 at 2.)
+// 0 if no split qualifies.
 static int gemm_8p_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
-    int best = 0, best_fill = 0;
+    int best = 0;
+    double best_us = 0.0;
     for (int ks = 1; ks <= (epi == EPI_F32 ? max_split : 1); ks++) {
-        const int f = gemm_8p_fill(T, N, K, ks);
-        if (f > best_fill) { best = ks; best_fill = f; }
+        if (gemm_8p_fill(T, N, K, ks) <= 0) continue;
+        const int64_t t8 = ((T + 255) / 256) * ((N + 255) / 256) * ks, rounds = (t8 + 255) / 256;
+        const double us = (double)rounds * ((double)(K / 64) / ks * 1.56 + 6.0) + (ks > 1 ? (double)ks * T * N * 8.0 / 4.0e6 : 0.0);
+        if (best == 0 || us < best_us) { best = ks; best_us = us; }
     }
     return best;
 }

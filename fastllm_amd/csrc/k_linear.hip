@@ -9,6 +9,8 @@
 
 #include <atomic>
 
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace fl {
@@ -112,7 +114,7 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
         if (T == 1 && gemv_supported(dtype, N, K)) return launch_gemv(L, dtype, plain_args(W, x, bias, y, N, K, epi, row_scale));
         static const int use_skinny = env_int("FL_GEMM_SKINNY", 1);
         if (!force_generic && use_skinny && gemm_skinny_supported(T, N, K)) {     // short prompts: a weight stream
-            const int ks = (n_split_out && !bias) ? gemm_skinny_ksplit(T, N, K, epi, max_split) : 1;
+            const int ks = (n_split_out && !bias) ? gemm_skinny_ksplit(T, N, K, epi, std::min(max_split, 4)) : 1;   // (more slabs cost the summing launch more than they save here)
             if (n_split_out) *n_split_out = ks;
             return launch_gemm_skinny(L, W, x, bias, y, T, N, K, epi, row_scale, ks);
         }

@@ -350,10 +350,21 @@ static int build_rope(Model *m) {
     return FL_OK;
 }
 
+// K slices (fp32 slabs that the next launch -- rmsnorm_add, rope_kv -- sums) a projection may use at T tokens.  Mid-size
+// prompts (T = 256..1024: 1-4 row tiles of 256) get up to eight: on the 256x256 kernel Mistral-7B's T = 512 QKV takes
+// 47 -> 34.5 us at 5 slices of 12.8 K steps, down_proj 78 -> 59 us at 8 (tools/gemm_probe.py), for ~5 us more in each summing launch.
 constexpr int kMaxKSplit = 4;
-constexpr int kMaxQkvSplit = 2;   // QKV projection of a mid-size prompt (its grid leaves CUs idle); rope_kv sums the slabs
+constexpr int kMaxKSplitMid = 8;
+constexpr int kMidT = 1024;
+constexpr int kMaxQkvSplit = 2;   // QKV projection of a long prompt (its grid leaves CUs idle); rope_kv sums the slabs
 constexpr int kMaxQkvSplitShort = 4;   // ... of a short prompt / a decode batch (T <= 128: the projection is a weight stream)
-static int qkv_split_cap(int64_t T) { return T <= 1 ? 1 : (T <= 128 ? kMaxQkvSplitShort : kMaxQkvSplit); }
+static int mid_cap(int dflt) { static const int v = env_int("FL_KSPLIT_MID", 0); return v > 0 ? std::min(v, kMaxKSplitMid) : dflt; }
+static int ksplit_cap(int64_t T) { return T <= 1 ? 1 : (T > 128 && T <= kMidT ? mid_cap(kMaxKSplitMid) : kMaxKSplit); }
+static int qkv_split_cap(int64_t T) { return T <= 1 ? 1 : (T <= 128 ? kMaxQkvSplitShort : (T <= kMidT ? mid_cap(kMaxKSplitMid) : kMaxQkvSplit)); }
+// rows of slab storage that serve every prompt of at most T tokens
+static int64_t slab_rows(int64_t T, int (*cap)(int64_t)) {
+    return std::max<int64_t>({T * cap(T), std::min<int64_t>(T, kMidT) * cap(std::min<int64_t>(T, kMidT)), std::min<int64_t>(T, 128) * cap(std::min<int64_t>(T, 128))});
+}
 
 // owner: who frees the buffers (default: the shard, i.e. at model destruction)
 static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T, std::vector<void *> *owner = nullptr) {
@@ -365,10 +376,10 @@ static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T, std::vecto
     sc.cap_T = T;
     FL_TRY(dev_alloc(own, (void **)&sc.x_res, (size_t)T * D.h * 4, acct));
     if (T == 1) FL_TRY(dev_alloc(own, (void **)&sc.x_res2, (size_t)D.h * 4, acct));
-    FL_TRY(dev_alloc(own, (void **)&sc.delta, (size_t)T * D.h * 4 * (T > 1 ? kMaxKSplit : 1), acct));   // split-K slabs
+    FL_TRY(dev_alloc(own, (void **)&sc.delta, (size_t)slab_rows(T, ksplit_cap) * D.h * 4, acct));   // split-K slabs of any prompt <= T
     FL_TRY(dev_alloc(own, &sc.xn, (size_t)T * D.h * es, acct));
     FL_TRY(dev_alloc(own, (void **)&sc.inv_rms, (size_t)T * 4, acct));
-    FL_TRY(dev_alloc(own, (void **)&sc.qkv, (size_t)std::max<int64_t>(T * qkv_split_cap(T), std::min<int64_t>(T, 128) * kMaxQkvSplitShort) * nq * 4, acct));    // split-K slabs of any prompt <= T
+    FL_TRY(dev_alloc(own, (void **)&sc.qkv, (size_t)slab_rows(T, qkv_split_cap) * nq * 4, acct));    // split-K slabs of any prompt <= T
     FL_TRY(dev_alloc(own, &sc.q, (size_t)T * sh.Hs * D.d * es, acct));
     FL_TRY(dev_alloc(own, &sc.ao, (size_t)T * sh.Hs * D.d * es, acct));
     FL_TRY(dev_alloc(own, &sc.act, (size_t)T * sh.Ip * es, acct));
@@ -926,7 +937,7 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
     }
     // split-K of the row-parallel GEMMs (o_proj, down_proj) only without tensor parallelism: the
     // all-reduce wants one summed buffer
-    const int max_split = (m->tp == 1 && T > 1) ? kMaxKSplit : 1;
+    const int max_split = (m->tp == 1 && T > 1) ? ksplit_cap(T) : 1;
     const int64_t slab = T * D.h;
     int nslab = 1;                        // slabs the current delta consists of (same on every shard)
     for (int64_t l = 0; l < D.L; l++) {
@@ -939,7 +950,7 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             void *kc = (char *)cs.k + kv_layer, *vc = (char *)cs.v + kv_layer;
             FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, l == 0 ? nullptr : sc.delta, ly.ln1, D.eps, sc.xn, sc.inv_rms, T, D.h, nslab, slab));
             int qkv_slabs = 1;
-            static const int qkv_split = env_int("FL_QKV_SPLIT", kMaxQkvSplitShort);
+            static const int qkv_split = env_int("FL_QKV_SPLIT", kMaxKSplitMid);
             FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, ly.bqkv, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms,
                                  std::min(qkv_split, qkv_split_cap(T)), &qkv_slabs));
             const int64_t sa = (int64_t)c->seq_alloc;
