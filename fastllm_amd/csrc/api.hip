@@ -346,8 +346,8 @@ int fl_op_linear(const void *x, const void *w, const float *bias, int64_t T, int
         FL_HIP(hipMalloc(&B.x, (size_t)T * K * es));
         FL_HIP(hipMalloc(&B.w, (size_t)Nw * K * es));
         const size_t ybytes = (size_t)T * Ny * (epilogue == EPI_GATEUP ? es : 4);
-        static const int op_split = getenv("FL_OP_MAXSPLIT") ? atoi(getenv("FL_OP_MAXSPLIT")) : 4;
-        const int max_split = (epilogue == EPI_F32 && !bias) ? op_split : 1;      // exercise split-K where the model would
+        static const int op_split = getenv("FL_OP_MAXSPLIT") ? atoi(getenv("FL_OP_MAXSPLIT")) : 0;
+        const int max_split = (epilogue == EPI_F32 && !bias) ? (op_split > 0 ? op_split : std::max(4, ksplit_cap(T))) : 1;      // exercise split-K where the model would
         int nsplit = 1;
         FL_HIP(hipMalloc(&B.y, ybytes * max_split));
         FL_HIP(hipMemcpy(B.x, x, (size_t)T * K * es, hipMemcpyHostToDevice));

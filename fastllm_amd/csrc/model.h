@@ -202,4 +202,7 @@ int forward(Model *m, Cache *c, const uint32_t *ids, size_t T, size_t pos, float
 int decode_greedy(Model *m, Cache *c, uint32_t first, size_t pos, size_t n_steps, int64_t eos,
                   uint32_t *tokens_out, size_t *n_out, const fl_sampling *sampling = nullptr);
 
+// most K slices (fp32 slabs summed by the next launch) a row-parallel projection may use at T tokens (model.hip)
+int ksplit_cap(int64_t T);
+
 }  // namespace fl
