@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "kernels.h"
 
@@ -36,6 +37,40 @@ __device__ inline bf16x8s frag_s(const unsigned char *tile, int row, int chunk) 
     return *reinterpret_cast<const bf16x8s *>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
+// epilogue of a wave's MT x NT accumulator tiles: tokens mw .. mw + 16 MT, W rows nw .. nw + 16 NT.
+// C/D map of 16x16 MFMA: col = lane & 15 (W row), row = (lane >> 4) * 4 + reg (token)
+template <int MT, int NT>
+__device__ inline void skinny_epilogue(const float4v (&acc)[MT][NT], void *__restrict__ out, const float *__restrict__ bias,
+                                       const float *__restrict__ row_scale, int T, int N, int epi, int mw, int nw, int lane) {
+    const int cn = lane & 15, rm = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int m = mw + i * 16 + rm + rg;
+            if (m >= T) continue;
+            const float rs = row_scale ? row_scale[m] : 1.0f;
+            if (epi == EPI_GATEUP) {
+                if constexpr (NT == 2) {
+                    const int n = nw + cn;                           // gate row; up = n + 16
+                    if (n + 16 < N) {
+                        const int qq = (n >> 5) * 16 + (n & 15);
+                        const float gt = acc[i][0][rg] * rs, up = acc[i][1][rg] * rs;
+                        const float a = gt / (1.0f + expf(-gt)) * up;
+                        reinterpret_cast<bf16_t *>(out)[(size_t)m * (N / 2) + qq] = float_to_bf16_bits(a);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    const int n = nw + j * 16 + cn;
+                    if (n < N) reinterpret_cast<float *>(out)[(size_t)m * N + n] = acc[i][j][rg] * rs + (bias ? bias[n] : 0.f);
+                }
+            }
+        }
+    }
+}
+
 // beyond BM = 128 tokens the kernel can run ceil(T / 128) token blocks per strip (FL_GEMM_SKINNY_MAXT moves the
 // limit), but the 128x128 kernel is then faster: Mistral-7B prefill T = 256 9.8 vs 9.2 ms, T = 512 18.3 vs 11.7 ms
 static const int kSkinnyMaxT = getenv("FL_GEMM_SKINNY_MAXT") ? atoi(getenv("FL_GEMM_SKINNY_MAXT")) : 128;
@@ -54,11 +89,13 @@ template <int MAXY, int PW> __device__ inline void wait_tail(int younger) {
 // NWM = 2 the token tiles are split over two wave rows (8 waves, two per SIMD): an LDS-DMA instruction costs its wave
 // ~100 cycles of issue, so at BM = 128 (32 KB per K tile = 8 instructions per wave of a 4-wave workgroup) staging, not
 // the MFMAs or HBM, set the pace; eight waves halve it and let one wave's MFMAs run under its SIMD partner's issue.
-template <int BM, int NT, int NW, int S_NSTG, bool WNT, int NWM>
+// STAMP (FL_SKINNY_STAMPS=file, diagnostics): every wave sums the core-clock cycles it spends per K step in the counted
+// wait, at the barrier, issuing its LDS-DMA and in fragment reads + MFMAs (tools/stamps_skinny.py)
+template <int BM, int NT, int NW, int S_NSTG, bool WNT, int NWM, bool STAMP = false>
 __global__ __launch_bounds__(NW * NWM * 64) void gemm_skinny_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
                                                           const float *__restrict__ bias, void *__restrict__ out,
                                                           int T, int N, int K, int epi, const float *__restrict__ row_scale,
-                                                          int ksplit) {
+                                                          int ksplit, unsigned long long *__restrict__ stamps) {
     constexpr int BN = NW * 16 * NT, MT = BM / 16 / NWM;         // MT: token tiles per wave
     constexpr int XB = BM * 128, STG = XB + BN * 128;             // bytes per stage
     constexpr int NI = (BM + BN) / 8;                              // 1 KiB DMA instructions per stage
@@ -98,9 +135,20 @@ __global__ __launch_bounds__(NW * NWM * 64) void gemm_skinny_kernel(const bf16_t
         }
     };
     // note: the swizzle of a W row uses its row index inside the W tile: r - BM keeps (r >> 1) & 7 since BM % 16 == 0
+    unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0, t_prev = 0, t_begin = 0;
+    auto tick = [&](unsigned long long &acc_c) {
+        if constexpr (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            acc_c += t - t_prev; t_prev = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if constexpr (STAMP) { t_begin = __builtin_amdgcn_s_memtime(); }
 #pragma unroll
     for (int p = 0; p < S_NSTG - 1; p++)
         if (p < nk) stage(p);
+    if constexpr (STAMP) { t_prev = __builtin_amdgcn_s_memtime(); }
     for (int kt = 0; kt < nk; kt++) {
         // tile kt has landed for this wave when at most the S_NSTG - 2 younger tiles' loads are outstanding
         {
@@ -109,8 +157,11 @@ __global__ __launch_bounds__(NW * NWM * 64) void gemm_skinny_kernel(const bf16_t
             else wait_tail<S_NSTG - 3, PW>(younger);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tick(c_wait);
         __builtin_amdgcn_s_barrier();                              // everyone's tile kt landed; slot (kt+3)%4 is free
+        tick(c_bar);
         if (kt + S_NSTG - 1 < nk) stage(kt + S_NSTG - 1);
+        tick(c_issue);
         const unsigned char *xt = lds + (kt % S_NSTG) * STG, *wt = xt + XB;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
@@ -125,36 +176,169 @@ __global__ __launch_bounds__(NW * NWM * 64) void gemm_skinny_kernel(const bf16_t
                 for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
             }
         }
+        if constexpr (STAMP) { asm volatile("s_nop 0" ::: "memory"); tick(c_comp); }
     }
 
-    // C/D map of 16x16 MFMA: col = lane & 15 (W row), row = (lane >> 4) * 4 + reg (token)
-    const int cn = lane & 15, rm = (lane >> 4) * 4;
-#pragma unroll
-    for (int i = 0; i < MT; i++) {
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-            const int m = m0 + (wm * MT + i) * 16 + rm + rg;
-            if (m >= T) continue;
-            const float rs = row_scale ? row_scale[m] : 1.0f;
-            if (epi == EPI_GATEUP) {
-                if constexpr (NT == 2) {
-                    const int n = n0 + wave * 32 + cn;               // gate row; up = n + 16
-                    if (n + 16 < N) {
-                        const int qq = (n >> 5) * 16 + (n & 15);
-                        const float gt = acc[i][0][rg] * rs, up = acc[i][1][rg] * rs;
-                        const float a = gt / (1.0f + expf(-gt)) * up;
-                        reinterpret_cast<bf16_t *>(out)[(size_t)m * (N / 2) + qq] = float_to_bf16_bits(a);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < NT; j++) {
-                    const int n = n0 + wave * 16 * NT + j * 16 + cn;
-                    if (n < N) reinterpret_cast<float *>(out)[(size_t)m * N + n] = acc[i][j][rg] * rs + (bias ? bias[n] : 0.f);
-                }
-            }
+    if constexpr (STAMP) {
+        if (lane == 0) {
+            unsigned long long *o = stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NW * NWM) * 8 + wave_all * 8;
+            o[0] = c_wait; o[1] = c_bar; o[2] = c_issue; o[3] = c_comp; o[4] = t_prev - t_begin; o[5] = nk; o[6] = __builtin_amdgcn_s_memrealtime(); o[7] = 0;
         }
     }
+    skinny_epilogue<MT, NT>(acc, out, bias, row_scale, T, N, epi, m0 + wm * MT * 16, n0 + wave * 16 * NT, lane);
+}
+
+// ---- loader waves (64 / 128 tokens).  Measured from inside (FL_SKINNY_STAMPS, tools/stamps_skinny.py; Mistral-7B gate/up at
+// T = 128, 8 waves, per K step and wave): counted vmcnt wait 140 cycles (the tile has all but landed: the kernel is NOT short
+// of bytes in flight -- two rings with 12 W stages ran 10-20 % SLOWER), barrier 80-340, issuing four 1-KiB LDS-DMA
+// instructions 400-620, fragment reads + 16 MFMAs 730-750: a wave does these one after the other, ~1630 cycles per K step,
+// 3.9 TB/s.  Here the staging moves to NLW extra waves that do nothing else (a few VGPRs each); the NW x NWM compute waves
+// only meet the barrier and multiply.  Same ring, same single raw barrier per K step.
+template <int BM, int NT, int NW, int NWM, int NLW, int S_NSTG, bool WNT, bool STAMP>
+__global__ __launch_bounds__((NW * NWM + NLW) * 64) void gemm_skinny_ld_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
+                                                                   const float *__restrict__ bias, void *__restrict__ out,
+                                                                   int T, int N, int K, int epi, const float *__restrict__ row_scale,
+                                                                   int ksplit, unsigned long long *__restrict__ stamps) {
+    constexpr int BN = NW * 16 * NT, MT = BM / 16 / NWM, NWV = NW * NWM;
+    constexpr int XB = BM * 128, STG = XB + BN * 128;             // bytes per stage
+    constexpr int NI = (BM + BN) / 8;                              // 1 KiB DMA instructions per stage
+    constexpr int PW = NI / NLW;                                   // ... per loader wave
+    static_assert(NI % NLW == 0, "stage instructions must divide evenly over the loader waves");
+    static_assert(BM % (16 * NWM) == 0, "token tiles must divide over the wave rows");
+    static_assert((S_NSTG - 2) * PW < 64, "vmcnt field");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave_all >= NWV;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.z * BM;
+    const int nk_all = K / S_BK, kz = blockIdx.y;
+    const int kt0 = (int)((long long)nk_all * kz / ksplit), nk = (int)((long long)nk_all * (kz + 1) / ksplit) - kt0;
+    X += (size_t)kt0 * S_BK; W += (size_t)kt0 * S_BK;
+    if (ksplit > 1) out = reinterpret_cast<float *>(out) + (size_t)kz * T * N;
+    unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0, t_prev = 0, t_begin = 0;
+    auto tick = [&](unsigned long long &acc_c) {
+        if constexpr (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            acc_c += t - t_prev; t_prev = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto dump = [&]() {
+        if constexpr (STAMP) {
+            if (lane == 0) {
+                unsigned long long *o = stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NWV + NLW) * 8 + wave_all * 8;
+                o[0] = c_wait; o[1] = c_bar; o[2] = c_issue; o[3] = c_comp; o[4] = t_prev - t_begin; o[5] = nk; o[6] = __builtin_amdgcn_s_memrealtime(); o[7] = loader;
+            }
+        }
+    };
+    if constexpr (STAMP) { t_begin = t_prev = __builtin_amdgcn_s_memtime(); }
+
+    if (loader) {
+        const int li = wave_all - NWV;
+        auto stage = [&](int kt) {
+            unsigned char *base = lds + (kt % S_NSTG) * STG;
+#pragma unroll
+            for (int s = 0; s < PW; s++) {
+                const int rb = (li * PW + s) * 8, r = rb + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);   // (r - BM keeps the swizzle: BM % 16 == 0)
+                if (rb < BM) {                                     // X rows (uniform per instruction)
+                    int gr = m0 + r; if (gr > T - 1) gr = T - 1;
+                    glds16s(X + (size_t)gr * K + kt * S_BK + c * 8, base + rb * 128);
+                } else {
+                    int gr = n0 + r - BM; if (gr > N - 1) gr = N - 1;
+                    if constexpr (WNT) glds16s_nt(W + (size_t)gr * K + kt * S_BK + c * 8, base + rb * 128);
+                    else glds16s(W + (size_t)gr * K + kt * S_BK + c * 8, base + rb * 128);
+                }
+            }
+        };
+#pragma unroll
+        for (int p = 0; p < S_NSTG - 1; p++)
+            if (p < nk) stage(p);
+        for (int kt = 0; kt < nk; kt++) {
+            const int younger = nk - 1 - kt;                       // tiles staged after kt (wave-uniform)
+            if (younger >= S_NSTG - 2) wait_vmcnt<(S_NSTG - 2) * PW>();
+            else wait_tail<S_NSTG - 3, PW>(younger);
+            tick(c_wait);
+            __builtin_amdgcn_s_barrier();                          // tile kt is in LDS; the compute waves are done with tile kt - 1
+            tick(c_bar);
+            if (kt + S_NSTG - 1 < nk) stage(kt + S_NSTG - 1);
+            tick(c_issue);
+        }
+        dump();
+        return;
+    }
+
+    const int wave = wave_all % NW, wm = wave_all / NW;          // wave column (W rows) / wave row (token tiles)
+    const int m16 = lane & 15, kg = lane >> 4;
+    float4v acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; kt++) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tick(c_wait);
+        __builtin_amdgcn_s_barrier();
+        tick(c_bar);
+        const unsigned char *xt = lds + (kt % S_NSTG) * STG, *wt = xt + XB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int chunk = ks * 4 + kg;
+            bf16x8s b[NT];
+#pragma unroll
+            for (int j = 0; j < NT; j++) b[j] = frag_s(wt, wave * 16 * NT + j * 16 + m16, chunk);
+#pragma unroll
+            for (int i = 0; i < MT; i++) {
+                const bf16x8s a = frag_s(xt, (wm * MT + i) * 16 + m16, chunk);
+#pragma unroll
+                for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if constexpr (STAMP) { asm volatile("s_nop 0" ::: "memory"); tick(c_comp); }
+    }
+    dump();
+    skinny_epilogue<MT, NT>(acc, out, bias, row_scale, T, N, epi, m0 + wm * MT * 16, n0 + wave * 16 * NT, lane);
+}
+
+template <int BM, int NT, int NW, int NWM, bool WNT>
+static int launch_skinny_ld_s(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
+                              int epi, const float *row_scale, int ksplit) {
+    constexpr int BN = NW * 16 * NT, NI = (BM + BN) / 8, NWV = NW * NWM;
+    constexpr int NLW = (NI % 8 == 0 && NWV + 8 <= 16) ? 8 : 4;    // loader waves: <= 4 (5) instructions each per K step
+    constexpr int STG = (BM + BN) * 128;
+    constexpr int kFit = 156 * 1024 / STG, NSTG = kFit < 6 ? kFit : 6;
+    static_assert(NSTG >= 3 && NI % NLW == 0, "loader geometry");
+    constexpr size_t lds = (size_t)NSTG * STG;
+    const dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)ksplit, (unsigned)((T + BM - 1) / BM)), block((NWV + NLW) * 64);
+    const double bytes = ((double)N * K + (double)T * K) * 2.0;
+    char tag[32];
+    snprintf(tag, sizeof tag, "skinny,ld,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");
+    Launcher LL = L; LL.tag = tag;
+    if (const char *path = getenv("FL_SKINNY_STAMPS")) {            // diagnostics: synchronous, appends one record per launch
+        auto kst = gemm_skinny_ld_kernel<BM, NT, NW, NWM, NLW, NSTG, WNT, true>;
+        FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kst), lds));
+        const size_t nw = (size_t)grid.x * grid.y * grid.z * (NWV + NLW);
+        unsigned long long *d = nullptr;
+        FL_HIP(hipMalloc(&d, nw * 64));
+        const int rc = LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kst, grid, block, lds, (const bf16_t *)W, (const bf16_t *)x, bias,
+                                 y, (int)T, (int)N, (int)K, epi, row_scale, ksplit, d);
+        std::vector<unsigned long long> h(nw * 8);
+        FL_HIP(hipStreamSynchronize(L.stream));
+        FL_HIP(hipMemcpy(h.data(), d, nw * 64, hipMemcpyDeviceToHost));
+        (void)hipFree(d);
+        if (FILE *f = fopen(path, "a")) {
+            fprintf(f, "launch %lld %lld %lld %d %zu %d\n", (long long)T, (long long)N, (long long)K, epi, nw, NWV + NLW);
+            for (size_t i = 0; i < nw; i++) {
+                for (int j = 0; j < 8; j++) fprintf(f, "%llu ", h[i * 8 + j]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+        return rc;
+    }
+    auto kern = gemm_skinny_ld_kernel<BM, NT, NW, NWM, NLW, NSTG, WNT, false>;
+    FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
+    return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, grid, block, lds, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K,
+                     epi, row_scale, ksplit, (unsigned long long *)nullptr);
 }
 
 template <int BM, int NT, int NW, int NSTG, bool WNT, int NWM>
@@ -170,8 +354,9 @@ static int launch_skinny_s(Launcher &L, const void *W, const void *x, const floa
     char tag[32];
     snprintf(tag, sizeof tag, "skinny,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");
     Launcher LL = L; LL.tag = tag;
-    return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, dim3((unsigned)((N + BN - 1) / BN), (unsigned)ksplit, (unsigned)((T + BM - 1) / BM)), dim3(NW * NWM * 64), lds,
-                     (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, row_scale, ksplit);
+    const dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)ksplit, (unsigned)((T + BM - 1) / BM));
+    return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, grid, dim3(NW * NWM * 64), lds,
+                     (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, row_scale, ksplit, (unsigned long long *)nullptr);
 }
 
 // ring depth: FL_SKINNY_STAGES (default 4; deeper rings measured SLOWER: profiles/r02/README.md); FL_SKINNY_NT: non-temporal
@@ -179,6 +364,9 @@ static int launch_skinny_s(Launcher &L, const void *W, const void *x, const floa
 static const int kSkinnyStages = getenv("FL_SKINNY_STAGES") ? atoi(getenv("FL_SKINNY_STAGES")) : 4;
 static const int kSkinnyNt = getenv("FL_SKINNY_NT") ? atoi(getenv("FL_SKINNY_NT")) : 1;
 static const int kSkinnyWm = getenv("FL_SKINNY_WM") ? atoi(getenv("FL_SKINNY_WM")) : 1;
+// 64 / 128 tokens: dedicated staging waves (gemm_skinny_ld_kernel).  Off: per projection it is -1..6 % (TinyLlama down -8..15 %)
+// and +10..19 % on short K loops, end to end (prefill_sweep) within the noise.  Read per call: tests and the stamps tool switch it.
+static int skinny_loaders() { const char *e = getenv("FL_SKINNY_LOADERS"); return e && *e ? atoi(e) : (getenv("FL_SKINNY_STAMPS") ? 1 : 0); }
 
 template <int BM, int NT, int NW>
 static int launch_skinny_t(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
@@ -195,8 +383,14 @@ static int launch_skinny_t(Launcher &L, const void *W, const void *x, const floa
         constexpr int WM = NW == 4 ? 2 : (BM == 128 && NI % 8 == 0 ? 4 : 2);
         static_assert(NI % (NW * WM) == 0 && BM % (16 * WM) == 0, "wave rows must divide the stage and the token tiles");
         if (kSkinnyWm) {
-            return nt ? launch_skinny_s<BM, NT, NW, 4, true, WM>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)
-                      : launch_skinny_s<BM, NT, NW, 4, false, WM>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
+            // (A/B on one box, three passes each: down_proj -1..3 %, gate/up -2..6 %, TinyLlama down -8..15 %; but a 64-token
+            // workgroup with only 16 K steps -- Mistral's QKV in four slices -- loses 10-19 %: the loaders' start-up is not amortised)
+            if (skinny_loaders() && (BM == 128 || (K / S_BK) / ksplit >= 20))
+                return nt ? launch_skinny_ld_s<BM, NT, NW, WM, true>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)
+                          : launch_skinny_ld_s<BM, NT, NW, WM, false>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
+            constexpr int kStg = 4 * STG <= 160 * 1024 ? 4 : 3;
+            return nt ? launch_skinny_s<BM, NT, NW, kStg, true, WM>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)
+                      : launch_skinny_s<BM, NT, NW, kStg, false, WM>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
         }
     }
     if constexpr (kDeep > 4 && BM <= 32) {
@@ -204,8 +398,10 @@ static int launch_skinny_t(Launcher &L, const void *W, const void *x, const floa
             return nt ? launch_skinny_s<BM, NT, NW, kDeep, true, 1>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)
                       : launch_skinny_s<BM, NT, NW, kDeep, false, 1>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
     }
-    return nt ? launch_skinny_s<BM, NT, NW, 4, true, 1>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)
-              : launch_skinny_s<BM, NT, NW, 4, false, 1>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
+    if constexpr (4 * STG <= 160 * 1024)
+        return nt ? launch_skinny_s<BM, NT, NW, 4, true, 1>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)
+                  : launch_skinny_s<BM, NT, NW, 4, false, 1>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
+    FL_FAIL(FL_ERR_UNSUPPORTED, "gemm_skinny: this tile needs the 8-wave form (FL_SKINNY_WM=1)");
 }
 
 // T <= 128: always (one token block).  129..256 tokens (two token blocks, the strip re-read through L2) only for matrices

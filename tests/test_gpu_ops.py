@@ -124,7 +124,9 @@ def test_8phase_kernel_is_race_free_over_repeats(fa, monkeypatch):
                                             (200, 4096, 4096, 0, False), (256, 3000, 768, 0, True),
                                             (9, 1792, 1024, 1, False), (48, 704, 512, 1, False), (100, 5632, 2048, 1, False),
                                             (256, 1408, 1024, 1, False)])
-def test_linear_skinny_kernel(fa, T, N, K, epi, bias):
+@pytest.mark.parametrize("loaders", [0, 1])      # 1: the staging moved to dedicated loader waves (64 / 128-token workgroups)
+def test_linear_skinny_kernel(fa, monkeypatch, T, N, K, epi, bias, loaders):
+    monkeypatch.setenv("FL_SKINNY_LOADERS", str(loaders))
     x, w = _rand((T, K), 31), _rand((N if not epi else 2 * N, K), 32, 0.05)
     b = _rand((N,), 33) if bias else None
     xb, wb = synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w)
