@@ -339,7 +339,7 @@ int fl_op_linear(const void *x, const void *w, const float *bias, int64_t T, int
                       std::vector<void *> copies;
                       ~Bufs() { (void)hipFree(x); (void)hipFree(w); (void)hipFree(ws); (void)hipFree(y); (void)hipFree(b);
                                 for (size_t i = 1; i < copies.size(); i++) (void)hipFree(copies[i]);
-                                if (s) (void)hipStreamDestroy(s);
+                                if (s) { (void)hipStreamSynchronize(s); gemm_8p_release_stream(s); (void)hipStreamDestroy(s); }
                                 if (e0) (void)hipEventDestroy(e0);
                                 if (e1) (void)hipEventDestroy(e1); } } B;
         FL_HIP(hipStreamCreate(&B.s));

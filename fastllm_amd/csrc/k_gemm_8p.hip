@@ -337,13 +337,27 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__
 
 // Stream-K workspace of one stream: two partial tiles per workgroup and a ticket per tile (zero between launches)
 struct SkSpace { float *part = nullptr; unsigned *flag = nullptr; int nwg = 0, ntile = 0; };
+static std::mutex g_sk_mu;
+static std::map<std::pair<int, hipStream_t>, SkSpace> g_sk_spaces;    // 128 MiB per stream that runs long-prompt GEMMs, until the stream goes
+
+// the owner of a stream calls this before destroying it (work on the stream has completed)
+void gemm_8p_release_stream(hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_sk_mu);
+    for (auto it = g_sk_spaces.begin(); it != g_sk_spaces.end();) {
+        if (it->first.second == stream) {
+            (void)hipFree(it->second.part); (void)hipFree(it->second.flag);
+            it = g_sk_spaces.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
 static int streamk_space(hipStream_t stream, int nwg, int ntile, StreamK *sk) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, SkSpace> spaces;     // never freed: 128 MiB per stream that runs long-prompt GEMMs
     int dev = 0;
     FL_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(mu);
-    SkSpace &sp = spaces[{dev, stream}];
+    std::lock_guard<std::mutex> lock(g_sk_mu);
+    SkSpace &sp = g_sk_spaces[{dev, stream}];
     if (sp.nwg < nwg || sp.ntile < ntile) {
         if (sp.part) { FL_HIP(hipStreamSynchronize(stream)); (void)hipFree(sp.part); (void)hipFree(sp.flag); }
         sp = SkSpace{};

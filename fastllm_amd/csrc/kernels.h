@@ -136,6 +136,7 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
                   int64_t T, int64_t N, int64_t K, int epi, const float *row_scale = nullptr,
                   int max_split = 1, int *n_split_out = nullptr);
 // ldc: row stride of y in elements of the FULL output width (0 = N): a launch may cover a column range of a wider matrix
+void gemm_8p_release_stream(hipStream_t stream);   // frees the stream-K workspace of a stream that is about to be destroyed
 int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
                    int epi, const float *row_scale, int ksplit, int64_t ldc = 0, bool streamk = false);
 bool gemm_skinny_supported(int64_t T, int64_t N, int64_t K);

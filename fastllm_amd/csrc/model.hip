@@ -150,6 +150,7 @@ Model::~Model() {
         for (void *p : s.pre_allocs) (void)hipFree(p);
         if (s.stream && std::find(closed.begin(), closed.end(), s.stream) == closed.end()) {
             closed.push_back(s.stream);
+            gemm_8p_release_stream(s.stream);
             (void)hipStreamDestroy(s.stream);
         }
     }
