@@ -69,10 +69,96 @@ __device__ inline void stage_half(const bf16_t *__restrict__ M, int nrows, int K
     }
 }
 
+// ---- epilogue of one wave's 128 x 64 block, shared by the GEMM kernel and the stream-K fix-up kernel.
+// C/D map of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.  The row scales of the tile go through LDS (one global
+// load per row, not one per accumulator row per lane); whole tiles take a path without bounds checks (the checked one spends a
+// branch pair per store: ~6 us of VALU per tile, tools/stamps_8p.py).
+struct EpiCtx {
+    void *out; const float *rs_rows;          // output base (slab applied); LDS row scales of this wave's rows (+ 16 i + reg)
+    int T, N, epi, ldc, mw, nw, cn, tn, wc;   // mw / nw: first row / this lane's first column of the wave's block
+    float bj[4], wj[4];                       // bias / next-norm weight of the lane's four columns
+    ResidEpi re;
+};
+__device__ inline void epi_ctx_init(EpiCtx &c, void *out, const float *bias, const float *rs_lds, int T, int N, int epi, int ldc,
+                                    int m0, int n0, int tn, int wr, int wc, int tid_e, const ResidEpi &re) {
+    const int cn = tid_e & 15, rm = ((tid_e >> 4) & 3) * 4;
+    c.out = out; c.rs_rows = rs_lds + wr * 128 + rm; c.T = T; c.N = N; c.epi = epi; c.ldc = ldc;
+    c.mw = m0 + wr * 128 + rm; c.nw = n0 + wc * 64 + cn; c.cn = cn; c.tn = tn; c.wc = wc; c.re = re;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        c.bj[j] = bias && epi != EPI_GATEUP && c.nw + j * 16 < N ? bias[c.nw + j * 16] : 0.f;
+        c.wj[j] = epi == EPI_RESID && c.nw + j * 16 < N ? re.w[c.nw + j * 16] : 0.f;
+    }
+}
+// rows [16 i, 16 i + 16) of the wave's block: v[j] = the accumulator tile of column block j
+template <bool CHK>
+__device__ inline void store_rows(const EpiCtx &c, int i, const float4v (&v)[4]) {
+    const int T = c.T, N = c.N, ldc = c.ldc, mw = c.mw, nw = c.nw;
+    const float4v rs4 = *reinterpret_cast<const float4v *>(c.rs_rows + i * 16);
+    if (c.epi == EPI_GATEUP) {
+        bf16_t *ob = reinterpret_cast<bf16_t *>(c.out) + (size_t)(mw + i * 16) * (ldc / 2) + (nw >> 5) * 16 + c.cn;   // j = 2: + 16
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            if (CHK && mw + i * 16 + rg >= T) continue;
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                if (CHK && nw + j * 16 + 16 >= N) continue;                   // gate column nw + 16 j, up 16 further
+                const float gt = v[j][rg] * rs4[rg], up = v[j + 1][rg] * rs4[rg];
+                // silu(g) * u: v_exp + v_rcp (1 ulp each); the result is rounded to bf16
+                const float av = gt * up * __builtin_amdgcn_rcpf(1.0f + __expf(-gt));
+                ob[(size_t)rg * (ldc / 2) + j * 8] = float_to_bf16_bits(av);
+            }
+        }
+    } else if (c.epi == EPI_RESID) {
+        // residual add + the next norm's x * w + this wave's share of the row sums of squares (lanes of a row: cn).
+        // All sixteen h values of the row block are requested before the first is used (the partial-sum stores are
+        // floats too: without the explicit order every row would wait for its own round trip).
+        float *__restrict__ hb = c.re.h + (size_t)(mw + i * 16) * ldc + nw;
+        bf16_t *__restrict__ xb = reinterpret_cast<bf16_t *>(c.re.xn) + (size_t)(mw + i * 16) * ldc + nw;
+        float hv[4][4], ss[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool ok = !CHK || (mw + i * 16 + rg < T && nw + j * 16 < N);
+                hv[rg][j] = ok ? hb[(size_t)rg * ldc + j * 16] : 0.f;
+            }
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            ss[rg] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (CHK && (mw + i * 16 + rg >= T || nw + j * 16 >= N)) continue;
+                const float hn = hv[rg][j] + (v[j][rg] * rs4[rg] + c.bj[j]);
+                hb[(size_t)rg * ldc + j * 16] = hn;
+                xb[(size_t)rg * ldc + j * 16] = float_to_bf16_bits(hn * c.wj[j]);
+                ss[rg] = fmaf(hn, hn, ss[rg]);
+            }
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            float sr = ss[rg];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sr += __shfl_xor(sr, o);
+            if ((!CHK || mw + i * 16 + rg < T) && c.cn == 0) c.re.part[(size_t)(mw + i * 16 + rg) * c.re.np + c.tn * 4 + c.wc] = sr;
+        }
+    } else {
+        float *ob = reinterpret_cast<float *>(c.out) + (size_t)(mw + i * 16) * ldc + nw;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            if (CHK && mw + i * 16 + rg >= T) continue;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (CHK && nw + j * 16 >= N) continue;
+                ob[(size_t)rg * ldc + j * 16] = v[j][rg] * rs4[rg] + c.bj[j];
+            }
+        }
+    }
+}
+
 // Stream-K workspace (SK instantiation; otherwise the grid is tiles x K slices, one segment per workgroup)
 struct StreamK {
     float *part;          // [workgroups][2][256 * 256] fp32 partial accumulators, lane-major (16-B coalesced)
-    unsigned *flag;       // [tiles] tickets: pieces of the tile that have been published (the last arriver resets it)
 };
 
 // STAMP: diagnostic instantiation (FL_8P_STAMPS=file): every workgroup records the 100 MHz wall clock and the core clock at
@@ -80,15 +166,18 @@ struct StreamK {
 //
 // SK (stream-K): the grid is ONE workgroup per CU and the work is the line of (tile, K step) units, cut into equal
 // pieces; a workgroup walks its piece as up to three segments -- the end of a tile another workgroup began, whole tiles,
-// the beginning of a tile the next workgroup(s) finish.  Every piece of a split tile is published as fp32 partial
-// accumulators (written through, sc1) and takes a ticket of the tile; the LAST arriver adds the pieces in K order and runs
-// the tile's epilogue.  Nobody ever waits for another workgroup, so the grid need not be co-resident.
+// the beginning of a tile the next workgroup(s) finish.  A piece of a split tile only PUBLISHES its fp32 partial accumulators
+// (slot 0: the piece ends the tile or lies inside it = the workgroup's first segment; slot 1: it begins the tile = its last
+// segment); gemm_8p_fixup_kernel, launched behind it, adds the pieces of every split tile in K order and runs the tile's
+// epilogue with one workgroup per 32-row block -- 8 x the tiles in parallel.  (A first version had the last arriver of a
+// tile do this inside the launch, on a ticket: 17-32 workgroups then read 2 MB each while the rest of the chip idled --
+// Qwen2-7B's 32-tile QKV tail 67 us.)  Nobody waits for another workgroup: the grid need not be co-resident.
 template <bool STAMP, bool SK>
 __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
                                                       const float *__restrict__ bias, void *__restrict__ out,
                                                       int T, int N, int K, int epi, int tiles_m, int tiles_n,
                                                       const float *__restrict__ row_scale, int ksplit, int ldc,
-                                                      unsigned long long *__restrict__ stamps, StreamK sk) {
+                                                      unsigned long long *__restrict__ stamps, StreamK sk, ResidEpi re) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [parity][A0 A1 B0 B1]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform values live in SGPRs)
     const int wr = wave >> 2, wc = wave & 3;
@@ -206,118 +295,28 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__
         int tid_e = tid;
         asm volatile("" : "+v"(tid_e));
 
-        // ---- epilogue.  C/D map of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.  The row scales of the tile go
-        // through LDS (one global load per row, not one per accumulator row per lane); whole tiles take a path without
-        // bounds checks (the checked one spends a branch pair per store: ~6 us of VALU per tile, tools/stamps_8p.py).
-        void *outz = out;
-        if (!SK && ksplit > 1) outz = reinterpret_cast<float *>(out) + (size_t)blockIdx.y * T * N;
-        const int cn = tid_e & 15, rm = ((tid_e >> 4) & 3) * 4;
-        float *rs_lds = reinterpret_cast<float *>(lds);
-        int *last_lds = reinterpret_cast<int *>(lds + 2048);
-        if (tid_e < P_BM) rs_lds[tid_e] = row_scale ? row_scale[min(m0 + tid_e, T - 1)] : 1.0f;
-        __syncthreads();
-        const bool whole = m0 + P_BM <= T && n0 + P_BN <= N;
-        const int mw = m0 + wr * 128 + rm, nw = n0 + wc * 64 + cn;
-        float bj[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) bj[j] = bias && epi != EPI_GATEUP && nw + j * 16 < N ? bias[nw + j * 16] : 0.f;
-        // rows [16 i, 16 i + 16) of this wave's 128 x 64 block: v[j] = the accumulator tile of column block j
-        auto store_rows = [&](auto checked, int i, const float4v (&v)[4]) {
-            constexpr bool CHK = decltype(checked)::value;
-            const float4v rs4 = *reinterpret_cast<const float4v *>(rs_lds + wr * 128 + i * 16 + rm);
-            if (epi == EPI_GATEUP) {
-                bf16_t *ob = reinterpret_cast<bf16_t *>(outz) + (size_t)(mw + i * 16) * (ldc / 2) + (nw >> 5) * 16 + cn;   // j = 2: + 16
-#pragma unroll
-                for (int rg = 0; rg < 4; rg++) {
-                    if (CHK && mw + i * 16 + rg >= T) continue;
-#pragma unroll
-                    for (int j = 0; j < 4; j += 2) {
-                        if (CHK && nw + j * 16 + 16 >= N) continue;                   // gate column nw + 16 j, up 16 further
-                        const float gt = v[j][rg] * rs4[rg], up = v[j + 1][rg] * rs4[rg];
-                        // silu(g) * u: v_exp + v_rcp (1 ulp each); the result is rounded to bf16
-                        const float av = gt * up * __builtin_amdgcn_rcpf(1.0f + __expf(-gt));
-                        ob[(size_t)rg * (ldc / 2) + j * 8] = float_to_bf16_bits(av);
-                    }
-                }
-            } else {
-                float *ob = reinterpret_cast<float *>(outz) + (size_t)(mw + i * 16) * ldc + nw;
-#pragma unroll
-                for (int rg = 0; rg < 4; rg++) {
-                    if (CHK && mw + i * 16 + rg >= T) continue;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (CHK && nw + j * 16 >= N) continue;
-                        ob[(size_t)rg * ldc + j * 16] = v[j][rg] * rs4[rg] + bj[j];
-                    }
-                }
-            }
-        };
-
+        // ---- epilogue (store_rows above) or, for a piece of a split tile, publication of the partial accumulators ----
         if (!SK || nk == nk_all) {
-            // ---- the whole K of the tile is in this workgroup's accumulators ----
-            if (whole) {
+            void *outz = out;
+            if (!SK && ksplit > 1) outz = reinterpret_cast<float *>(out) + (size_t)blockIdx.y * T * N;
+            float *rs_lds = reinterpret_cast<float *>(lds);
+            if (tid_e < P_BM) rs_lds[tid_e] = row_scale ? row_scale[min(m0 + tid_e, T - 1)] : 1.0f;
+            __syncthreads();
+            EpiCtx ctx;
+            epi_ctx_init(ctx, outz, bias, rs_lds, T, N, epi, ldc, m0, n0, tn, wr, wc, tid_e, re);
+            if (m0 + P_BM <= T && n0 + P_BN <= N) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) store_rows(std::false_type{}, i, acc[i]);
+                for (int i = 0; i < 8; i++) store_rows<false>(ctx, i, acc[i]);
             } else {
 #pragma unroll
-                for (int i = 0; i < 8; i++) store_rows(std::true_type{}, i, acc[i]);
+                for (int i = 0; i < 8; i++) store_rows<true>(ctx, i, acc[i]);
             }
         } else {
-            // ---- a piece of a tile: publish the partial accumulators (slot 0: the piece ends the tile or lies inside it =
-            // this workgroup's first segment; slot 1: it begins the tile = its last segment), take a ticket; the last
-            // arriver sums the pieces in K order and runs the epilogue ----
-            float *pw = sk.part + (((size_t)wid * 2 + (kt0 > 0 ? 0 : 1)) * (P_BM * P_BN) + (size_t)tid_e * 4);
+            float4v *pw = reinterpret_cast<float4v *>(sk.part + ((size_t)wid * 2 + (kt0 > 0 ? 0 : 1)) * (P_BM * P_BN)) + tid_e;
 #pragma unroll
             for (int i = 0; i < 8; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) st_sc1_x4(pw + (size_t)(i * 4 + j) * 2048, acc[i][j]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int t0 = li * nk_all, t1 = t0 + nk_all;
-            int w0 = (int)((long long)t0 * nwg / U);                  // the workgroup whose piece holds the tile's K step 0
-            while (cut(w0 + 1) <= t0) w0++;
-            while (cut(w0) > t0) w0--;
-            int nseg = 1;
-            while (cut(w0 + nseg) < t1) nseg++;
-            __syncthreads();
-            if (tid_e == 0) {
-                const unsigned tk = __hip_atomic_fetch_add(sk.flag + li, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int last = tk == (unsigned)nseg - 1;
-                if (last) {
-                    __hip_atomic_store(sk.flag + li, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everyone has arrived
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                }
-                *last_lds = last;
-            }
-            __syncthreads();
-            if (*last_lds) {
-                // (the accumulators are dead: four pieces x four tiles are loaded at once, then added in K order)
-                const float4v *p0 = reinterpret_cast<const float4v *>(sk.part) + tid_e;
-#pragma unroll 1
-                for (int i = 0; i < 8; i++) {
-                    float4v v[4] = {float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}};
-                    for (int sg0 = 0; sg0 < nseg; sg0 += 4) {
-                        float4v t[4][4];
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            if (sg0 + e < nseg) {
-                                const int wq = w0 + sg0 + e, slot = cut(wq) > t0 ? 0 : 1;
-                                const float4v *pq = p0 + ((size_t)wq * 2 + slot) * (P_BM * P_BN / 4) + (size_t)(i * 4) * 512;
-#pragma unroll
-                                for (int j = 0; j < 4; j++) t[e][j] = pq[(size_t)j * 512];
-                            }
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            if (sg0 + e < nseg) {
-#pragma unroll
-                                for (int j = 0; j < 4; j++) v[j] += t[e][j];
-                            }
-                        }
-                    }
-                    if (whole) store_rows(std::false_type{}, i, v);
-                    else store_rows(std::true_type{}, i, v);
-                }
-            }
+                for (int j = 0; j < 4; j++) pw[(size_t)(i * 4 + j) * 512] = acc[i][j];
         }
         if (!SK) break;
         __syncthreads();                                               // the row scales are read: the next prologue may write LDS
@@ -335,8 +334,42 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__
     }
 }
 
-// Stream-K workspace of one stream: two partial tiles per workgroup and a ticket per tile (zero between launches)
-struct SkSpace { float *part = nullptr; unsigned *flag = nullptr; int nwg = 0, ntile = 0; };
+// Fix-up of a stream-K launch (same stream, right behind it): workgroup (tile, 32-row block i) adds the published pieces
+// of a split tile in K order -- each thread the elements its lane held in the GEMM -- and runs the epilogue.
+__global__ __launch_bounds__(512) void gemm_8p_fixup_kernel(const float *__restrict__ bias, void *__restrict__ out, int T, int N, int K, int epi,
+                                                            int tiles_m, int tiles_n, const float *__restrict__ row_scale, int ldc, int nwg,
+                                                            StreamK sk, ResidEpi re) {
+    __shared__ __attribute__((aligned(16))) float rs_lds[P_BM];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 2, wc = wave & 3;
+    const int li = blockIdx.x >> 3, i = blockIdx.x & 7;
+    const int nk_all = K / P_BK, U = tiles_m * tiles_n * nk_all;
+    auto cut = [&](int w) { return (int)((long long)U * w / nwg); };
+    const int t0 = li * nk_all, t1 = t0 + nk_all;
+    int w0 = (int)((long long)t0 * nwg / U);                          // the workgroup whose piece holds the tile's K step 0
+    while (cut(w0 + 1) <= t0) w0++;
+    while (cut(w0) > t0) w0--;
+    int nseg = 1;
+    while (cut(w0 + nseg) < t1) nseg++;
+    if (nseg == 1) return;                                            // the tile was computed whole: its owner ran the epilogue
+    const int tn = li / tiles_m, tm = li % tiles_m, m0 = tm * P_BM, n0 = tn * P_BN;
+    if (tid < P_BM) rs_lds[tid] = row_scale ? row_scale[min(m0 + tid, T - 1)] : 1.0f;
+    __syncthreads();
+    float4v v[4] = {float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}};
+    const float4v *p0 = reinterpret_cast<const float4v *>(sk.part) + tid + (size_t)(i * 4) * 512;
+    for (int sg = 0; sg < nseg; sg++) {
+        const int wq = w0 + sg, slot = cut(wq) > t0 ? 0 : 1;
+        const float4v *pq = p0 + ((size_t)wq * 2 + slot) * (P_BM * P_BN / 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] += pq[(size_t)j * 512];
+    }
+    EpiCtx ctx;
+    epi_ctx_init(ctx, out, bias, rs_lds, T, N, epi, ldc, m0, n0, tn, wr, wc, tid, re);
+    if (m0 + P_BM <= T && n0 + P_BN <= N) store_rows<false>(ctx, i, v);
+    else store_rows<true>(ctx, i, v);
+}
+
+// Stream-K workspace of one stream: two partial tiles per workgroup
+struct SkSpace { float *part = nullptr; int nwg = 0; };
 static std::mutex g_sk_mu;
 static std::map<std::pair<int, hipStream_t>, SkSpace> g_sk_spaces;    // 128 MiB per stream that runs long-prompt GEMMs, until the stream goes
 
@@ -345,7 +378,7 @@ void gemm_8p_release_stream(hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_sk_mu);
     for (auto it = g_sk_spaces.begin(); it != g_sk_spaces.end();) {
         if (it->first.second == stream) {
-            (void)hipFree(it->second.part); (void)hipFree(it->second.flag);
+            (void)hipFree(it->second.part);
             it = g_sk_spaces.erase(it);
         } else {
             ++it;
@@ -353,21 +386,18 @@ void gemm_8p_release_stream(hipStream_t stream) {
     }
 }
 
-static int streamk_space(hipStream_t stream, int nwg, int ntile, StreamK *sk) {
+static int streamk_space(hipStream_t stream, int nwg, StreamK *sk) {
     int dev = 0;
     FL_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_sk_mu);
     SkSpace &sp = g_sk_spaces[{dev, stream}];
-    if (sp.nwg < nwg || sp.ntile < ntile) {
-        if (sp.part) { FL_HIP(hipStreamSynchronize(stream)); (void)hipFree(sp.part); (void)hipFree(sp.flag); }
+    if (sp.nwg < nwg) {
+        if (sp.part) { FL_HIP(hipStreamSynchronize(stream)); (void)hipFree(sp.part); }
         sp = SkSpace{};
-        const int nt = std::max(ntile, 4096);
         FL_HIP(hipMalloc(&sp.part, (size_t)nwg * 2 * P_BM * P_BN * sizeof(float)));
-        FL_HIP(hipMalloc(&sp.flag, (size_t)nt * sizeof(unsigned)));
-        FL_HIP(hipMemset(sp.flag, 0, (size_t)nt * sizeof(unsigned)));
-        sp.nwg = nwg; sp.ntile = nt;
+        sp.nwg = nwg;
     }
-    *sk = StreamK{sp.part, sp.flag};
+    *sk = StreamK{sp.part};
     return FL_OK;
 }
 
@@ -381,8 +411,11 @@ static int cu_count() {
 }
 
 int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
-                   int epi, const float *row_scale, int ksplit, int64_t ldc, bool streamk) {
+                   int epi, const float *row_scale, int ksplit, int64_t ldc, bool streamk, const ResidEpi *resid) {
     if (ldc <= 0) ldc = N;
+    if ((epi == EPI_RESID) != (resid != nullptr) || (resid && (ksplit != 1 || !resid->h || !resid->w || !resid->xn || !resid->part)))
+        FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: the residual epilogue takes its operands, whole K");
+    const ResidEpi re = resid ? *resid : ResidEpi{};
     if (ksplit > 1 && ldc != N) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: K slices write whole slabs (ldc == N)");
     if (streamk && ksplit != 1) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: stream-K takes the whole K");
     const int tiles_m = (int)((T + P_BM - 1) / P_BM), tiles_n = (int)((N + P_BN - 1) / P_BN);
@@ -390,22 +423,28 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
     if (ksplit > 1 && (bias || epi != EPI_F32)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "split-K GEMM: fp32 epilogue without bias only");
     const double bytes = ((double)N * K + (double)T * K) * 2.0;
     char tag[32];
-    snprintf(tag, sizeof tag, "8p,%lldx%lld%s", (long long)N, (long long)K, streamk ? ",streamK" : ksplit > 1 ? ",splitK" : "");
+    snprintf(tag, sizeof tag, "8p,%lldx%lld%s%s", (long long)N, (long long)K, streamk ? ",streamK" : ksplit > 1 ? ",splitK" : "", resid ? ",resid" : "");
     Launcher LL = L; LL.tag = tag;
-    StreamK sk{nullptr, nullptr};
+    StreamK sk{nullptr};
     dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)ksplit);
     if (streamk) {
         // one workgroup per CU, but never more than one per two K steps of work
         const int64_t units = (int64_t)tiles_m * tiles_n * (K / P_BK);
         if (units >= (int64_t)1 << 30) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: stream-K line too long");
         // pieces aligned with the tiles keep the workgroups that share a W or X panel in lock step (its L2 hits): split every
-        // tile into the same number of pieces, at most eight (the last arriver adds them), while the grid fits the chip
+        // tile into the same number of pieces, at most eight, while the grid fits the chip
         const int64_t nt = (int64_t)tiles_m * tiles_n, cus = cu_count();
         const int64_t split = std::max<int64_t>(1, std::min<int64_t>({(int64_t)8, cus / std::max<int64_t>(1, nt), (K / P_BK) / 4}));
         const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>(nt * split, units / 2));
-        FL_TRY(streamk_space(L.stream, nwg, tiles_m * tiles_n, &sk));
+        FL_TRY(streamk_space(L.stream, nwg, &sk));
         grid = dim3((unsigned)nwg, 1);
     }
+    auto fixup = [&]() -> int {                                     // behind a stream-K launch: the split tiles' sums and epilogues
+        if (!streamk) return FL_OK;
+        Launcher LF = L; LF.tag = "8p,fixup";
+        return LF.launch(KC_GEMM_MFMA, 0.0, 0.0, gemm_8p_fixup_kernel, dim3((unsigned)(tiles_m * tiles_n * 8)), dim3(512), 0, bias, y, (int)T, (int)N,
+                         (int)K, epi, tiles_m, tiles_n, row_scale, (int)ldc, (int)grid.x, sk, re);
+    };
     const bool stamp = getenv("FL_8P_STAMPS") != nullptr;           // diagnostics only: synchronous, appends one record per launch
     auto kern = streamk ? (stamp ? gemm_8p_kernel<true, true> : gemm_8p_kernel<false, true>) : (stamp ? gemm_8p_kernel<true, false> : gemm_8p_kernel<false, false>);
     FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), P_LDS));
@@ -415,7 +454,8 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         unsigned long long *d = nullptr;
         FL_HIP(hipMalloc(&d, nwg * 80));
         const int rc = LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, grid, dim3(512), P_LDS, (const bf16_t *)W,
-                                 (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, d, sk);
+                                 (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, d, sk, re);
+        if (rc == FL_OK) FL_TRY(fixup());
         std::vector<unsigned long long> h(nwg * 10);
         FL_HIP(hipStreamSynchronize(L.stream));
         FL_HIP(hipMemcpy(h.data(), d, nwg * 80, hipMemcpyDeviceToHost));
@@ -430,8 +470,9 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         }
         return rc;
     }
-    return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, grid, dim3(512), P_LDS, (const bf16_t *)W, (const bf16_t *)x,
-                     bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, (unsigned long long *)nullptr, sk);
+    FL_TRY(LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, grid, dim3(512), P_LDS, (const bf16_t *)W, (const bf16_t *)x,
+                     bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, (unsigned long long *)nullptr, sk, re));
+    return fixup();
 }
 
 }  // namespace fl

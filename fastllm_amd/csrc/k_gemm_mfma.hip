@@ -298,8 +298,13 @@ static int gemm_256_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_spl
 
 // how many K splits the launcher will use for this shape when the caller allows up to max_split slabs
 static bool gemm_streamk_whole(int64_t T, int64_t N, int64_t K, int epi);
+static bool peel_plan(int64_t T, int64_t N, int64_t K, int64_t *n_main_out);
 int gemm_mfma_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
     if (gemm_streamk_whole(T, N, K, epi)) return 1;                 // one launch, partials meet inside it
+    {   // whole rounds + a stream-K tail beat K slices of a grid that large (Mistral-7B o_proj at T = 4100: 272 tiles)
+        int64_t n_main = 0;
+        if (peel_plan(T, N, K, &n_main)) return 1;
+    }
     {
         const char *e8 = getenv("FL_GEMM_8P");
         if (!(e8 && *e8 && atoi(e8) == 0)) {
@@ -346,32 +351,67 @@ static bool gemm_streamk_whole(int64_t T, int64_t N, int64_t K, int epi) {
     return T >= 1024 && K / 64 >= 32 && t8 >= 96 && t8 < 256;
 }
 
-int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bias, void *y,
-                     int64_t T, int64_t N, int64_t K, int epi, const float *row_scale, int ksplit) {
+// column peeling of a ragged 256x256 grid: whole rounds first (n_main columns), the rest as a stream-K (or 128x128) tail
+static bool peel_plan(int64_t T, int64_t N, int64_t K, int64_t *n_main_out) {
     static const int peel = getenv("FL_GEMM_PEEL") ? atoi(getenv("FL_GEMM_PEEL")) : 1;
     const char *e8 = getenv("FL_GEMM_8P");
     const int use8p = e8 && *e8 ? atoi(e8) : 1;
+    if (!(peel && use8p == 1 && T >= 256 && K % 64 == 0 && (K / 64) >= 16)) return false;
+    const int64_t tm = (T + 255) / 256, tn = (N + 255) / 256, t8 = tm * tn;
+    const int64_t full = t8 / 256;
+    const int64_t n_main_tiles = full * 256 / tm;                 // whole column tiles inside the full rounds
+    const int64_t tail_tiles = t8 - tm * n_main_tiles;
+    if (!(full >= 1 && tail_tiles > 0 && tail_tiles <= (streamk_on() ? 128 : 64) && n_main_tiles >= 1 && n_main_tiles < tn && tm * n_main_tiles >= 224))
+        return false;
+    *n_main_out = n_main_tiles * 256;                              // (256 | 32: gate/up pairs stay whole)
+    return true;
+}
+
+int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bias, void *y,
+                     int64_t T, int64_t N, int64_t K, int epi, const float *row_scale, int ksplit) {
     const int sk = streamk_on();
     if (ksplit == 1 && gemm_streamk_whole(T, N, K, epi))
         return launch_gemm_8p(L, W, x, bias, y, T, N, K, epi, row_scale, 1, N, true);
-    if (peel && use8p == 1 && ksplit == 1 && T >= 256 && K % 64 == 0 && (K / 64) >= 16) {
-        const int64_t tm = (T + 255) / 256, tn = (N + 255) / 256, t8 = tm * tn;
-        const int64_t full = t8 / 256;
-        const int64_t n_main_tiles = full * 256 / tm;                 // whole column tiles inside the full rounds
-        const int64_t tail_tiles = t8 - tm * n_main_tiles;
-        if (full >= 1 && tail_tiles > 0 && tail_tiles <= (sk ? 128 : 64) && n_main_tiles >= 1 && n_main_tiles < tn && tm * n_main_tiles >= 224) {
-            const int64_t n_main = n_main_tiles * 256, n_tail = N - n_main;           // (256 | 32: gate/up pairs stay whole)
-            const size_t es_out = epi == EPI_GATEUP ? 2 : 4;
-            const int64_t col_main = epi == EPI_GATEUP ? n_main / 2 : n_main;
-            FL_TRY(launch_gemm_mfma_impl(L, W, x, bias, y, T, n_main, K, epi, row_scale, 1, N, true));
-            const bf16_t *Wt = (const bf16_t *)W + (size_t)n_main * K;
-            const float *bt = bias ? bias + n_main : nullptr;
-            void *yt = (char *)y + (size_t)col_main * es_out;
-            if (sk) return launch_gemm_8p(L, Wt, x, bt, yt, T, n_tail, K, epi, row_scale, 1, N, true);
-            return launch_gemm_mfma_impl(L, Wt, x, bt, yt, T, n_tail, K, epi, row_scale, 1, N, false);
-        }
+    int64_t n_main = 0;
+    if (ksplit == 1 && peel_plan(T, N, K, &n_main)) {
+        const int64_t n_tail = N - n_main;
+        const size_t es_out = epi == EPI_GATEUP ? 2 : 4;
+        const int64_t col_main = epi == EPI_GATEUP ? n_main / 2 : n_main;
+        FL_TRY(launch_gemm_mfma_impl(L, W, x, bias, y, T, n_main, K, epi, row_scale, 1, N, true));
+        const bf16_t *Wt = (const bf16_t *)W + (size_t)n_main * K;
+        const float *bt = bias ? bias + n_main : nullptr;
+        void *yt = (char *)y + (size_t)col_main * es_out;
+        if (sk) return launch_gemm_8p(L, Wt, x, bt, yt, T, n_tail, K, epi, row_scale, 1, N, true);
+        return launch_gemm_mfma_impl(L, Wt, x, bt, yt, T, n_tail, K, epi, row_scale, 1, N, false);
     }
     return launch_gemm_mfma_impl(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit, N, true);
+}
+
+// ---- residual epilogue (EPI_RESID, kernels.h): only where the 256x256 kernel takes the whole K in one launch (or a peeled
+// pair of launches): long prompts.  FL_GEMM_RESID=0 keeps the rmsnorm_add launches.
+int gemm_resid_partials(int64_t N) { return (int)((N + 255) / 256) * 4; }
+bool gemm_resid_supported(int dtype, int64_t T, int64_t N, int64_t K, int max_split) {
+    const char *e = getenv("FL_GEMM_RESID");                     // read per call: tests switch it
+    if (e && *e && atoi(e) == 0) return false;
+    const char *e8 = getenv("FL_GEMM_8P");
+    if (dtype != FL_DTYPE_BF16 || (e8 && *e8 && atoi(e8) != 1) || T < 256 || K % 64 || K / 64 < 2 || N % 16) return false;
+    if (gemm_mfma_ksplit(T, N, K, EPI_F32, max_split) != 1 || gemm_streamk_whole(T, N, K, EPI_F32)) return false;
+    int64_t n_main = 0;
+    // (a peeled matrix could take it too -- launch_gemm_resid handles the pair, tests force it with FL_GEMM_RESID=2 -- but the
+    // stream-K tail's last-arriver pass with the residual read-modify-write measured slower than rmsnorm_add: Mistral-7B T = 4100)
+    if (peel_plan(T, N, K, &n_main)) return e && *e && atoi(e) == 2 && streamk_on() != 0;
+    return gemm_8p_fill(T, N, K, 1) > 0;
+}
+int launch_gemm_resid(Launcher &L, const void *W, const void *x, int64_t T, int64_t N, int64_t K, const ResidEpi &re) {
+    if (re.np != gemm_resid_partials(N)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_resid: partial-sum layout");
+    int64_t n_main = 0;
+    if (peel_plan(T, N, K, &n_main)) {
+        FL_TRY(launch_gemm_8p(L, W, x, nullptr, nullptr, T, n_main, K, EPI_RESID, nullptr, 1, N, false, &re));
+        ResidEpi rt = re;                                         // the tail's columns: same rows, later column tiles
+        rt.h += n_main; rt.w += n_main; rt.xn = (bf16_t *)rt.xn + n_main; rt.part += (n_main / 256) * 4;
+        return launch_gemm_8p(L, (const bf16_t *)W + (size_t)n_main * K, x, nullptr, nullptr, T, N - n_main, K, EPI_RESID, nullptr, 1, N, true, &rt);
+    }
+    return launch_gemm_8p(L, W, x, nullptr, nullptr, T, N, K, EPI_RESID, nullptr, 1, N, false, &re);
 }
 
 static int launch_gemm_mfma_impl(Launcher &L, const void *W, const void *x, const float *bias, void *y,

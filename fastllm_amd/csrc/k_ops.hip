@@ -86,6 +86,21 @@ int launch_rmsnorm_add(Launcher &L, int dtype, float *x_res, const float *delta,
                     x_res, delta, w, eps, (float *)xs, inv_rms, (int)h, n_slab, (long long)slab_stride);
 }
 
+// 1/rms from the partial sums of squares the EPI_RESID GEMM epilogue left (kernels.h): one wave per row, fixed tree order
+__global__ __launch_bounds__(256) void rms_finalize_kernel(const float *__restrict__ part, int np, float eps, float *__restrict__ inv_rms, int T, int h) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= T) return;
+    float ss = 0.f;
+    for (int i = lane; i < np; i += 64) ss += part[(size_t)t * np + i];
+    ss = wave_sum(ss);
+    if (lane == 0) inv_rms[t] = 1.0f / sqrtf(ss / (float)h + eps);
+}
+int launch_rms_finalize(Launcher &L, const float *part, int np, float eps, float *inv_rms, int64_t T, int64_t h) {
+    Launcher LL = L; LL.tag = "finalize";
+    return LL.launch(KC_RMSNORM, (double)T * np * 4.0, 0, rms_finalize_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, part, np, eps, inv_rms,
+                     (int)T, (int)h);
+}
+
 // ------------------------------------------------------------------------------- RoPE + KV append
 // candle_nn::rotary_emb::rope (rotate-half, App. A.4) on q and k, then the new K/V rows are
 // written in place at cache index len+t (the reference's Tensor::cat copies the whole cache every

@@ -40,7 +40,18 @@ struct Launcher {
     }
 };
 
-enum { EPI_F32 = 0, EPI_GATEUP = 1, EPI_QKV_ROPE = 2 };
+enum { EPI_F32 = 0, EPI_GATEUP = 1, EPI_QKV_ROPE = 2, EPI_RESID = 3 };
+// EPI_RESID (256x256 prefill GEMM only): the o_proj / down_proj epilogue takes over the residual add and the next
+// RMSNorm's first pass -- h += y (fp32, in place), xn = (h + y) * w in the compute dtype, and partial sums of squares of
+// h + y per (row, column tile, wave column) that rms_finalize turns into 1/rms -- instead of a y round trip through
+// HBM and an rmsnorm_add launch.
+struct ResidEpi {
+    float *h = nullptr;            // [T][N] residual stream
+    const float *w = nullptr;      // [N] weight of the NEXT RMSNorm
+    void *xn = nullptr;            // [T][N] bf16
+    float *part = nullptr;         // [T][np]
+    int np = 0;
+};
 enum { PRO_X = 0, PRO_NORM = 1 };
 
 struct LLTable;
@@ -136,9 +147,13 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
                   int64_t T, int64_t N, int64_t K, int epi, const float *row_scale = nullptr,
                   int max_split = 1, int *n_split_out = nullptr);
 // ldc: row stride of y in elements of the FULL output width (0 = N): a launch may cover a column range of a wider matrix
+bool gemm_resid_supported(int dtype, int64_t T, int64_t N, int64_t K, int max_split);   // k_gemm_mfma.hip: would launch_gemm_resid take this shape?
+int gemm_resid_partials(int64_t N);                                                       // partial sums per row (np)
+int launch_gemm_resid(Launcher &L, const void *W, const void *x, int64_t T, int64_t N, int64_t K, const ResidEpi &re);
+int launch_rms_finalize(Launcher &L, const float *part, int np, float eps, float *inv_rms, int64_t T, int64_t h);
 void gemm_8p_release_stream(hipStream_t stream);   // frees the stream-K workspace of a stream that is about to be destroyed
 int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
-                   int epi, const float *row_scale, int ksplit, int64_t ldc = 0, bool streamk = false);
+                   int epi, const float *row_scale, int ksplit, int64_t ldc = 0, bool streamk = false, const ResidEpi *resid = nullptr);
 bool gemm_skinny_supported(int64_t T, int64_t N, int64_t K);
 int gemm_skinny_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split);
 int launch_gemm_skinny(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,

@@ -38,6 +38,7 @@ struct Scratch {                 // activations of one forward chunk on one shar
     float *delta = nullptr;      // [T,h] fp32 output of o_proj / down_proj (all-reduced under TP)
     void *xn = nullptr;          // [T,h] x * norm_weight (compute dtype); RMSNorm = inv_rms * xn
     float *inv_rms = nullptr;    // [T]
+    float *rs_part = nullptr;    // [T, np] partial sums of squares left by the residual epilogue of a long prompt's o_proj / down_proj
     float *qkv = nullptr;        // [T,(Hs+2Hkvs)*d] fp32
     void *q = nullptr;           // [T,Hs*d]
     void *ao = nullptr;          // [T,Hs*d] attention output

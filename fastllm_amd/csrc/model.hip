@@ -380,6 +380,7 @@ static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T, std::vecto
     FL_TRY(dev_alloc(own, (void **)&sc.delta, (size_t)slab_rows(T, ksplit_cap) * D.h * 4, acct));   // split-K slabs of any prompt <= T
     FL_TRY(dev_alloc(own, &sc.xn, (size_t)T * D.h * es, acct));
     FL_TRY(dev_alloc(own, (void **)&sc.inv_rms, (size_t)T * 4, acct));
+    if (T >= 256) FL_TRY(dev_alloc(own, (void **)&sc.rs_part, (size_t)T * gemm_resid_partials(D.h) * 4, acct));
     FL_TRY(dev_alloc(own, (void **)&sc.qkv, (size_t)slab_rows(T, qkv_split_cap) * nq * 4, acct));    // split-K slabs of any prompt <= T
     FL_TRY(dev_alloc(own, &sc.q, (size_t)T * sh.Hs * D.d * es, acct));
     FL_TRY(dev_alloc(own, &sc.ao, (size_t)T * sh.Hs * D.d * es, acct));
@@ -941,6 +942,16 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
     const int max_split = (m->tp == 1 && T > 1) ? ksplit_cap(T) : 1;
     const int64_t slab = T * D.h;
     int nslab = 1;                        // slabs the current delta consists of (same on every shard)
+    // Long prompts on one GPU: where the 256x256 kernel takes o_proj / down_proj in one piece, its epilogue adds the residual,
+    // writes the next norm's x * w and leaves partial sums of squares (EPI_RESID) -- no delta round trip, no rmsnorm_add launch.
+    const bool resid_ok = ns == 1 && m->tp == 1 && !m->shards[0].comm && dt == FL_DTYPE_BF16 && T >= 256 && SC(m->shards[0]).rs_part != nullptr;
+    bool norm_done = false;               // xn / inv_rms for the upcoming norm were produced by the previous projection
+    auto linear_resid = [&](Launcher &L, Shard &sh, Scratch &sc, const void *W, const void *x, int64_t K, const float *next_norm_w) -> int {
+        ResidEpi re;
+        re.h = sc.x_res; re.w = next_norm_w; re.xn = sc.xn; re.part = sc.rs_part; re.np = gemm_resid_partials(D.h);
+        FL_TRY(launch_gemm_resid(L, W, x, T, D.h, K, re));
+        return launch_rms_finalize(L, sc.rs_part, re.np, D.eps, sc.inv_rms, T, D.h);
+    };
     for (int64_t l = 0; l < D.L; l++) {
         for (size_t i = 0; i < ns; i++) {
             Shard &sh = m->shards[i]; Scratch &sc = SC(sh); CacheShard &cs = c->shards[i]; LayerW &ly = sh.layers[l];
@@ -949,7 +960,8 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             const int64_t nq = (sh.Hs + 2 * sh.Hkvs) * D.d;
             const size_t kv_layer = (size_t)l * sh.Hkvs * c->seq_alloc * D.d * m->esize();
             void *kc = (char *)cs.k + kv_layer, *vc = (char *)cs.v + kv_layer;
-            FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, l == 0 ? nullptr : sc.delta, ly.ln1, D.eps, sc.xn, sc.inv_rms, T, D.h, nslab, slab));
+            if (!norm_done) FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, l == 0 ? nullptr : sc.delta, ly.ln1, D.eps, sc.xn, sc.inv_rms, T, D.h, nslab, slab));
+            norm_done = false;
             int qkv_slabs = 1;
             static const int qkv_split = env_int("FL_QKV_SPLIT", kMaxKSplitMid);
             FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, ly.bqkv, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms,
@@ -965,16 +977,27 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             } else {
                 FL_TRY(launch_attn_prefill(L, dt, sc.q, kc, vc, cs.st, sc.ao, T, sh.Hs, sh.Hkvs, D.d, sa, D.scale, D.window));
             }
-            FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, T, D.h, sh.Hs * D.d, EPI_F32, nullptr, max_split, &nslab));
+            if (resid_ok && gemm_resid_supported(dt, T, D.h, sh.Hs * D.d, max_split)) {
+                FL_TRY(linear_resid(L, sh, sc, ly.wo, sc.ao, sh.Hs * D.d, ly.ln2));
+                norm_done = true;
+            } else {
+                FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, T, D.h, sh.Hs * D.d, EPI_F32, nullptr, max_split, &nslab));
+            }
         }
         FL_TRY(all_reduce_delta(m, pre, T * D.h));
         for (size_t i = 0; i < ns; i++) {
             Shard &sh = m->shards[i]; Scratch &sc = SC(sh); LayerW &ly = sh.layers[l];
             FL_HIP(hipSetDevice(sh.device));
             Launcher L = make_launcher(m, sh);
-            FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, sc.delta, ly.ln2, D.eps, sc.xn, sc.inv_rms, T, D.h, nslab, slab));
+            if (!norm_done) FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, sc.delta, ly.ln2, D.eps, sc.xn, sc.inv_rms, T, D.h, nslab, slab));
+            norm_done = false;
             FL_TRY(launch_linear(L, dt, ly.wgu, sc.xn, nullptr, sc.act, T, 2 * sh.Ip, D.h, EPI_GATEUP, sc.inv_rms));
-            FL_TRY(launch_linear(L, dt, ly.wd, sc.act, nullptr, sc.delta, T, D.h, sh.Ip, EPI_F32, nullptr, max_split, &nslab));
+            if (resid_ok && gemm_resid_supported(dt, T, D.h, sh.Ip, max_split)) {
+                FL_TRY(linear_resid(L, sh, sc, ly.wd, sc.act, sh.Ip, l + 1 < D.L ? sh.layers[l + 1].ln1 : sh.norm));
+                norm_done = true;
+            } else {
+                FL_TRY(launch_linear(L, dt, ly.wd, sc.act, nullptr, sc.delta, T, D.h, sh.Ip, EPI_F32, nullptr, max_split, &nslab));
+            }
         }
         FL_TRY(all_reduce_delta(m, pre, T * D.h));
     }
@@ -985,7 +1008,7 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
         Launcher L = make_launcher(m, sh);
         float *xl = sc.x_res + (size_t)(T - 1) * D.h, *dl = sc.delta + (size_t)(T - 1) * D.h;
         void *xnl = (char *)sc.xn + (size_t)(T - 1) * D.h * m->esize();
-        FL_TRY(launch_rmsnorm_add(L, dt, xl, dl, sh.norm, D.eps, xnl, sc.inv_rms + (T - 1), 1, D.h, nslab, slab));
+        if (!norm_done) FL_TRY(launch_rmsnorm_add(L, dt, xl, dl, sh.norm, D.eps, xnl, sc.inv_rms + (T - 1), 1, D.h, nslab, slab));
         FL_TRY(launch_linear(L, dt, sh.lm_head, xnl, nullptr, sh.logits_local, 1, sh.Vs, D.h, EPI_F32, sc.inv_rms + (T - 1)));
     }
     FL_TRY(gather_logits(m));
