@@ -397,9 +397,7 @@ bool gemm_resid_supported(int dtype, int64_t T, int64_t N, int64_t K, int max_sp
     if (dtype != FL_DTYPE_BF16 || (e8 && *e8 && atoi(e8) != 1) || T < 256 || K % 64 || K / 64 < 2 || N % 16) return false;
     if (gemm_mfma_ksplit(T, N, K, EPI_F32, max_split) != 1 || gemm_streamk_whole(T, N, K, EPI_F32)) return false;
     int64_t n_main = 0;
-    // (a peeled matrix could take it too -- launch_gemm_resid handles the pair, tests force it with FL_GEMM_RESID=2 -- but the
-    // stream-K tail's last-arriver pass with the residual read-modify-write measured slower than rmsnorm_add: Mistral-7B T = 4100)
-    if (peel_plan(T, N, K, &n_main)) return e && *e && atoi(e) == 2 && streamk_on() != 0;
+    if (peel_plan(T, N, K, &n_main)) return streamk_on() != 0;     // main launch + stream-K tail, both with the residual epilogue
     return gemm_8p_fill(T, N, K, 1) > 0;
 }
 int launch_gemm_resid(Launcher &L, const void *W, const void *x, int64_t T, int64_t N, int64_t K, const ResidEpi &re) {

@@ -211,7 +211,8 @@ def test_mistral_7b_long_prompt_chunked(env, monkeypatch):
 def test_long_prompt_residual_epilogue_equals_rmsnorm_launches(env, monkeypatch, name, T):
     """Long prompts: the 256x256 GEMM's residual epilogue (h += y, next norm's x*w, partial sums of squares -> 1/rms;
     EPI_RESID) against the separate rmsnorm_add launches it replaces (FL_GEMM_RESID=0), full width, 3 layers: the same
-    math except the order in which a row's squares are summed.  T = 4100 has a ragged last row tile."""
+    math except the order in which a row's squares are summed.  T = 4100: a ragged last row tile, and o_proj / down_proj are
+    peeled (whole rounds + a stream-K tail whose fix-up launch runs the same epilogue)."""
     torch, fa, bench = env
     from fastllm_amd.configs import MODEL_CONFIGS
     cfg = dict(MODEL_CONFIGS[name], num_hidden_layers=3)
@@ -222,7 +223,7 @@ def test_long_prompt_residual_epilogue_equals_rmsnorm_launches(env, monkeypatch,
     ids = synth.prompt_ids(cfg, T, seed=17)
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("FL_GEMM_RESID", "2" if mode == "1" else "0")     # 2: also where the matrix is peeled (T = 4100)
+        monkeypatch.setenv("FL_GEMM_RESID", mode)
         c = gm.new_cache(T + 8)
         gm.profile_begin()
         lg = gm.forward(c, ids, 0)
