@@ -396,21 +396,33 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *_
     constexpr int CPR = D / 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m32 = lane & 31, hi = lane >> 5;
-    const int G = H / Hkv, hk = blockIdx.y;
+    const int G = H / Hkv;
     const int TB = NW / G;                                                  // 32-token blocks per workgroup
-    const int hq = hk * G + wave % G;
     const int len = (int)st->len;
     const int c0 = (int)st->call0;
+    const int krow = (m32 & 19) | ((m32 & 4) << 1) | ((m32 & 8) >> 1);      // pi(m): bits 2 and 3 swapped
+    // Causal: token block b walks ~b+1 key tiles.  paired = 1: a workgroup takes block nb-1-x and then block x, so every
+    // workgroup walks the same number of tiles (one balanced round when nb/2 x Hkv covers the chip); 0: the long blocks
+    // are dispatched first and the short ones fill the tail; 2 ("snake", long prompts): gridDim.x persistent workgroups
+    // deal themselves the (block, kv head) items -- longest first -- boustrophedon: round r goes 0..P-1, round r+1
+    // P-1..0, so consecutive rounds add up to the same work for everyone whatever nb x Hkv is (4608 tokens of Qwen2-7B are
+    // 288 paired workgroups: 1.125 rounds that took as long as two).
+    const int nb = (T + 32 * TB - 1) / (32 * TB);
+    const int npass = paired == 2 ? (nb * Hkv + (int)gridDim.x - 1) / (int)gridDim.x : (paired ? 2 : 1);
+    for (int pass = 0; pass < npass; pass++) {
+    int blk, hk;
+    if (paired == 2) {
+        const int item = pass * (int)gridDim.x + ((pass & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
+        if (item >= nb * Hkv) break;                                        // (only the last round can be short)
+        blk = nb - 1 - item / Hkv; hk = item % Hkv;
+    } else {
+        hk = blockIdx.y;
+        blk = pass == 0 ? nb - 1 - (int)blockIdx.x : (int)blockIdx.x;
+        if (pass == 1 && blk >= nb - 1 - (int)blockIdx.x) break;            // odd count: the middle block was pass 0
+    }
+    const int hq = hk * G + wave % G;
     const bf16_t *kb = kc + (size_t)hk * seq_alloc * D;
     const bf16_t *vb = vT + (size_t)hk * D * seq_alloc;
-    const int krow = (m32 & 19) | ((m32 & 4) << 1) | ((m32 & 8) >> 1);      // pi(m): bits 2 and 3 swapped
-    // Causal: token block b walks ~b+1 key tiles.  paired: a workgroup takes block nb-1-x and then block x, so every
-    // workgroup walks the same number of tiles (one balanced round when nb/2 x Hkv covers the chip); otherwise the
-    // long blocks are dispatched first and the short ones fill the tail.
-    const int nb = (T + 32 * TB - 1) / (32 * TB);
-    for (int pass = 0; pass < (paired ? 2 : 1); pass++) {
-    const int blk = pass == 0 ? nb - 1 - (int)blockIdx.x : (int)blockIdx.x;
-    if (pass == 1 && blk >= nb - 1 - (int)blockIdx.x) break;                // odd count: the middle block was pass 0
     const int tb0 = blk * TB * 32;
     const int t0 = tb0 + (wave / G) * 32;
     const bool wave_on = wave < TB * G;                                     // NW need not be a multiple of G
@@ -433,8 +445,11 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *_
     int wstart = 0;
     if (c0 == 0 && window >= 0 && len + t0 - window > 0) wstart = ((len + t0 - window) / 32) * 32;
     const int wend = (wave_on && t0 < T) ? len + min(T, t0 + 32) : 0;
-    // a tile [kb, kb+32) needs no mask for this wave when all 32 rows exist and see all of it
-    const bool rows_full = wave_on && t0 + 32 <= T;
+    // a tile [kb, kb+32) needs no mask for this wave when every EXISTING row sees all of it.  Rows past the prompt's end
+    // (a ragged last block) have q = 0 and no store: whatever they compute stays on their own lanes.  (Requiring 32
+    // existing rows sent the longest block of a T % 32 != 0 prompt down the masked path for all of its ~T/32 tiles: Qwen2-7B
+    // T = 5000 456 us per layer against 320 at T = 4992.)
+    const bool rows_full = wave_on && t0 < T;
     int lo_max = c0;                                                        // largest lower bound among the wave's rows
     if (window >= 0 && len + t0 + 31 - window > c0) lo_max = len + t0 + 31 - window;
     const int hi_min = len + t0 + 1;                                        // smallest upper bound
@@ -581,6 +596,15 @@ static int launch_pf32(Launcher &L, const void *q, const void *k_cache, const vo
                        int64_t T, int64_t H, int64_t Hkv, int64_t seq_alloc, float scale, int64_t window, int TB, int paired) {
     const int64_t nb = (T + 32 * TB - 1) / (32 * TB);
     dim3 grid((unsigned)(paired ? (nb + 1) / 2 : nb), (unsigned)Hkv);
+    if (paired == 2) {
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        static std::atomic<int> cached{0};
+        if (!cached.load() && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cached = prop.multiProcessorCount;
+        if (cached.load()) cus = cached.load();
+        grid = dim3((unsigned)cus, 1);
+    }
     const size_t lds = 3 * (size_t)(2 * 32 * D * 2);
     const double flops = 2.0 * (double)T * T * H * D;
     Launcher LL = L; LL.tag = "32row";
@@ -608,7 +632,8 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
         const int NW = G <= 4 ? (8 / G) * G : G, TB = NW / G;
         const int64_t nb = (T + 32 * TB - 1) / (32 * TB);
         static const int force_pair = getenv("FL_ATTN_PF32_PAIRED") ? atoi(getenv("FL_ATTN_PF32_PAIRED")) : -1;
-        const int paired = force_pair >= 0 ? force_pair : ((nb + 1) / 2 * Hkv >= 180 ? 1 : 0);
+        // two rounds or more of (block, kv head) items: persistent workgroups, snake order (launch_pf32)
+        const int paired = force_pair >= 0 ? force_pair : (nb * Hkv >= 2 * 256 ? 2 : ((nb + 1) / 2 * Hkv >= 180 ? 1 : 0));
 #define FL_PF32(DD, WW) if (d == DD && NW == WW) return launch_pf32<DD, WW>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired);
         FL_PF32(128, 8) FL_PF32(128, 7) FL_PF32(128, 6) FL_PF32(128, 5) FL_PF32(64, 8) FL_PF32(64, 7) FL_PF32(64, 6) FL_PF32(64, 5)
 #undef FL_PF32
