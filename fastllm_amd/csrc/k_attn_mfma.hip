@@ -631,7 +631,8 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
         // reuse, one wave per SIMD) lost everywhere: T = 2048 105 / 180 us, T = 4096 371 / 515.
         const int NW = G <= 4 ? (8 / G) * G : G, TB = NW / G;
         const int64_t nb = (T + 32 * TB - 1) / (32 * TB);
-        static const int force_pair = getenv("FL_ATTN_PF32_PAIRED") ? atoi(getenv("FL_ATTN_PF32_PAIRED")) : -1;
+        const char *fp = getenv("FL_ATTN_PF32_PAIRED");              // read per call: tests pin the schedule
+        const int force_pair = fp && *fp ? atoi(fp) : -1;
         // two rounds or more of (block, kv head) items: persistent workgroups, snake order (launch_pf32)
         const int paired = force_pair >= 0 ? force_pair : (nb * Hkv >= 2 * 256 ? 2 : ((nb + 1) / 2 * Hkv >= 180 ? 1 : 0));
 #define FL_PF32(DD, WW) if (d == DD && NW == WW) return launch_pf32<DD, WW>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired);

@@ -99,6 +99,20 @@ def test_baseline_shapes_and_the_rescale_branch(fa, d, H, Hkv):
     check(fa.op_attention(q, k, v, 0, H, Hkv, d, window=-1, kernel=0), reference(q, k, v, 0, H, Hkv, d, -1), "prefill auto")
 
 
+@pytest.mark.parametrize("d,H,Hkv", [(128, 32, 8), (128, 28, 4)])
+@pytest.mark.parametrize("sched", [0, 1, 2])
+def test_prefill32_schedules(fa, monkeypatch, d, H, Hkv, sched):
+    """The 32-row kernel's three work distributions -- plain (long blocks first), paired, snake (persistent workgroups; what
+    long prompts get) -- on a prompt whose (block, kv head) items exceed one round of the chip (264 > 256: some workgroups take
+    two), with a ragged last block (2100 % 32 = 20) and a window that bites."""
+    monkeypatch.setenv("FL_ATTN_PF32_PAIRED", str(sched))
+    T = 2100
+    q, k, v = make(T, 0, H, Hkv, d, seed=77 + sched, spike=True)
+    for window in (-1, 1000):
+        got = fa.op_attention(q, k, v, 0, H, Hkv, d, window=window, kernel=3)
+        check(got, reference(q, k, v, 0, H, Hkv, d, window), "prefill32 schedule %d window %d" % (sched, window))
+
+
 def test_bad_arguments_are_errors(fa):
     q, k, v = make(2, 0, 8, 8, 64, 1)
     with pytest.raises(fa.FastLLMError):
