@@ -1,4 +1,5 @@
-"""Per-kernel profile (HIP events per launch) of one prefill at full model shapes.  usage: prefill_profile.py [model] [T] [layers]"""
+"""Per-kernel profile (HIP events per launch) of one prefill at full model shapes.  usage: prefill_profile.py [model] [T] [layers] [tp]
+(tp > 1: FL_TP_EMULATED -- every rank's shard on this one GPU, one after the other: the per-rank kernel shapes of a tensor-parallel group)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +13,8 @@ cfg = dict(MODEL_CONFIGS[name])
 if len(sys.argv) > 3:
     cfg["num_hidden_layers"] = int(sys.argv[3])
 wts = bench.synth_device_weights(torch, cfg, torch.device("cuda", 0))
-gm = fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16")
+tp = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+gm = fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16") if tp == 1 else fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16", tp_mode=fa.binding.TP_EMULATED, tp_size=tp)
 del wts; torch.cuda.empty_cache()
 p = np.random.RandomState(0).randint(0, cfg["vocab_size"], size=T).astype(np.uint32)
 c = gm.new_cache(T + 8)
