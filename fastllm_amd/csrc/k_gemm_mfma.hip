@@ -257,9 +257,13 @@ static int gemm_8p_fill(int64_t T, int64_t N, int64_t K, int ks) {
     if (T < 256 || K % 64 || ks < 1 || (K / 64) / ks < mink) return 0;   // keep the pipeline long enough to pay for its ramp
     const int64_t t8 = ((T + 255) / 256) * ((N + 255) / 256) * ks, rounds = (t8 + 255) / 256;
     const int fill = (int)(t8 * 1024 / (rounds * 256));
-    if (t8 < 192) return 0;
-    if (fill >= 820) return fill;                                       // >= 80 %
-    return fill >= 768 && (K / 64) / ks >= 24 ? fill : 0;               // 75 %: long slices only
+    // Worth it from about half a round: the 128x128 kernel runs at 0.57-0.63 PFLOP/s on a full grid, this one at ~1.3 x fill
+    // (144 tiles = 56 %: Qwen2-7B QKV at T = 2048 118 -> 78 us, Mistral-7B QKV at T = 1536 122 -> 87).  FL_8P_MINFILL in 1/1024.
+    static const int minfill = getenv("FL_8P_MINFILL") ? atoi(getenv("FL_8P_MINFILL")) : 512;
+    // rows of a ragged last row tile are idle too: the test is on the USEFUL fill (T = 384 is 1.5 row tiles: TinyLlama +10 % without this)
+    const int64_t tm = (T + 255) / 256;
+    if (t8 < 112 || fill * T / (tm * 256) < minfill) return 0;
+    return fill;
 }
 
 // K slices for the 256x256 kernel: among the splits whose grid covers the chip well enough (gemm_8p_fill), the cheapest by

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(const float *__restrict__ 
                                                       const float *__restrict__ cos_tab, const float *__restrict__ sin_tab,
                                                       int max_pos, CT *__restrict__ q_out, CT *__restrict__ kc,
                                                       CT *__restrict__ vc, int T, int H, int Hkv, int d, int max_seq,
-                                                      int v_transposed, int nslab, long long slab_stride) {
+                                                      int v_transposed, int nslab, long long slab_stride,
+                                                      const float *__restrict__ bias) {
     const int half = d >> 1;
     const int nheads = H + 2 * Hkv;
     const int per_t = nheads * half;
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(const float *__restrict__ 
         a += src[(size_t)sl * slab_stride + j];
         b += src[(size_t)sl * slab_stride + j + half];
     }
+    if (bias) { a += bias[(size_t)hd * d + j]; b += bias[(size_t)hd * d + j + half]; }     // (the projection ran in K slices: its bias comes here)
     const uint32_t pos = st->pos + (uint32_t)t, slot = st->len + (uint32_t)t;
     if (hd < H + Hkv) {
         const uint32_t p = pos < (uint32_t)max_pos ? pos : (uint32_t)max_pos - 1;   // host validates range
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void rope_kv_vec_kernel(const float *__restric
                                                           const float *__restrict__ cos_tab, const float *__restrict__ sin_tab,
                                                           int max_pos, bf16_t *__restrict__ q_out, bf16_t *__restrict__ kc,
                                                           bf16_t *__restrict__ vc, int T, int H, int Hkv, int d, int max_seq,
-                                                          int nslab, long long slab_stride, int nA) {
+                                                          int nslab, long long slab_stride, int nA, const float *__restrict__ bias) {
     __shared__ bf16_t tile[64][40];                       // [d row][token], 80-byte rows: 16-byte aligned chunks of 8 tokens
     const int half = d >> 1, nheads = H + 2 * Hkv, tid = threadIdx.x;
     const uint32_t len = st->len, pos0 = st->pos;
@@ -171,6 +173,12 @@ __global__ __launch_bounds__(256) void rope_kv_vec_kernel(const float *__restric
             load8(src + (size_t)sl * slab_stride, a2); load8(src + (size_t)sl * slab_stride + half, b2);
 #pragma unroll
             for (int j = 0; j < 8; j++) { a[j] += a2[j]; b[j] += b2[j]; }
+        }
+        if (bias) {
+            float ba[8], bb[8];
+            load8(bias + (size_t)hd * d + j0, ba); load8(bias + (size_t)hd * d + j0 + half, bb);
+#pragma unroll
+            for (int j = 0; j < 8; j++) { a[j] += ba[j]; b[j] += bb[j]; }
         }
         const uint32_t pos = pos0 + (uint32_t)t, p = pos < (uint32_t)max_pos ? pos : (uint32_t)max_pos - 1;
         float c[8], sn[8], ra[8], rb[8];
@@ -196,6 +204,12 @@ __global__ __launch_bounds__(256) void rope_kv_vec_kernel(const float *__restric
 #pragma unroll
                 for (int j = 0; j < 8; j++) v[j] += v2[j];
             }
+            if (bias) {
+                float bv[8];
+                load8(bias + (size_t)(H + Hkv + hk) * d + d0 + j0, bv);
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] += bv[j];
+            }
 #pragma unroll
             for (int j = 0; j < 8; j++) tile[j0 + j][tl] = float_to_bf16_bits(v[j]);
         }
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(256) void rope_kv_vec_kernel(const float *__restric
 
 int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st, const float *cos_tab,
                    const float *sin_tab, int64_t max_pos, void *q_out, void *k_cache, void *v_cache,
-                   int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t max_seq, bool v_transposed, int nslab) {
+                   int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t max_seq, bool v_transposed, int nslab, const float *bias) {
     const long long slab_stride = (long long)T * (H + 2 * Hkv) * d;
     const int64_t total = T * (H + 2 * Hkv) * (d / 2);
     const unsigned blocks = (unsigned)((total + 255) / 256);
@@ -224,15 +238,15 @@ int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st
         const int nA = (int)((itemsA + 255) / 256), nB = (int)(((T + 31) / 32) * Hkv * (d / 64));
         return L.launch(KC_ROPE_KV, bytes, 0, rope_kv_vec_kernel, dim3((unsigned)(nA + nB)), dim3(256), 0, qkv, st, cos_tab, sin_tab,
                         (int)max_pos, (bf16_t *)q_out, (bf16_t *)k_cache, (bf16_t *)v_cache, (int)T, (int)H, (int)Hkv, (int)d,
-                        (int)max_seq, nslab, slab_stride, nA);
+                        (int)max_seq, nslab, slab_stride, nA, bias);
     }
     if (dtype == FL_DTYPE_BF16)
         return L.launch(KC_ROPE_KV, bytes, 0, rope_kv_kernel<bf16_t>, dim3(blocks), dim3(256), 0, qkv, st, cos_tab,
                         sin_tab, (int)max_pos, (bf16_t *)q_out, (bf16_t *)k_cache, (bf16_t *)v_cache, (int)T, (int)H,
-                        (int)Hkv, (int)d, (int)max_seq, (int)v_transposed, nslab, slab_stride);
+                        (int)Hkv, (int)d, (int)max_seq, (int)v_transposed, nslab, slab_stride, bias);
     return L.launch(KC_ROPE_KV, bytes, 0, rope_kv_kernel<float>, dim3(blocks), dim3(256), 0, qkv, st, cos_tab,
                     sin_tab, (int)max_pos, (float *)q_out, (float *)k_cache, (float *)v_cache, (int)T, (int)H,
-                    (int)Hkv, (int)d, (int)max_seq, (int)v_transposed, nslab, slab_stride);
+                    (int)Hkv, (int)d, (int)max_seq, (int)v_transposed, nslab, slab_stride, bias);
 }
 
 // ------------------------------------------------------------------------------- batched variants (row N4)

@@ -177,7 +177,8 @@ int launch_rmsnorm_add(Launcher &L, int dtype, float *x_res, const float *delta,
 // v_transposed: value cache laid out [Hkv][d][max_seq] instead of [Hkv][max_seq][d]
 int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st, const float *cos_tab,
                    const float *sin_tab, int64_t max_pos, void *q_out, void *k_cache, void *v_cache,
-                   int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t max_seq, bool v_transposed, int nslab = 1);
+                   int64_t T, int64_t H, int64_t Hkv, int64_t d, int64_t max_seq, bool v_transposed, int nslab = 1,
+                   const float *bias = nullptr);   // bias: the QKV projection's, when it ran in K slices (added after the slabs are summed)
 // (nslab > 1: qkv is nslab split-K slabs of [T][(H+2Hkv)*d], summed here in slab order)
 // logits[V] -> st->token by ArgMax (ties: last max index) or, when ss->on, by temperature sampling with
 // the seeded ChaCha12 stream; out_tokens[st->step] = token; advances pos/len/step

@@ -964,10 +964,12 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             norm_done = false;
             int qkv_slabs = 1;
             static const int qkv_split = env_int("FL_QKV_SPLIT", kMaxKSplitMid);
-            FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, ly.bqkv, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms,
+            // (Qwen2's q/k/v bias moves into the RoPE launch, which sums the slabs anyway: with the bias in the GEMM epilogue the
+            // projection could not run in K slices and a mid-size prompt's QKV sat on 128x128 tiles -- T = 512: 63 us at 0.27 PFLOP/s)
+            FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, nullptr, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms,
                                  std::min(qkv_split, qkv_split_cap(T)), &qkv_slabs));
             const int64_t sa = (int64_t)c->seq_alloc;
-            FL_TRY(launch_rope_kv(L, dt, sc.qkv, cs.st, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, kc, vc, T, sh.Hs, sh.Hkvs, D.d, sa, c->v_transposed, qkv_slabs));
+            FL_TRY(launch_rope_kv(L, dt, sc.qkv, cs.st, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, kc, vc, T, sh.Hs, sh.Hkvs, D.d, sa, c->v_transposed, qkv_slabs, ly.bqkv));
             if (T == 1) {
                 AttnScratch as{cs.part_m, cs.part_l, cs.part_o, cs.counters, c->nsplit, len_hint + 1};
                 if (c->v_transposed) FL_TRY(launch_attn_decode_mfma(L, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, sa, D.scale));
