@@ -384,20 +384,25 @@ __global__ __launch_bounds__(1024) void attn_prefill_mfma_kernel(const bf16_t *_
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef unsigned short ushort4v __attribute__((ext_vector_type(4)));
 
-template <int D, int NW>
+// KS2 (key split, prompts too short to balance otherwise): a (head, 32-token block) is served by TWO waves that take alternate
+// key tiles -- a step stages two tiles -- and meet through LDS at the end: the causal chain of the longest block, which sets the
+// launch's duration when there are too few (block, kv head) items for the snake to even out, is half as long, and the 32-token
+// blocks make twice as many items.  (Mistral-7B T = 2048: 64 blocks x 8 kv heads = 512 items, two balanced rounds.)
+template <int D, int NW, bool KS2>
 __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
                                                                  const bf16_t *__restrict__ vT, const StepState *__restrict__ st,
                                                                  bf16_t *__restrict__ out, int T, int H, int Hkv, int seq_alloc,
                                                                  float scale_log2e, int window, int paired) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // 3 x (K tile | V^T tile)
-    constexpr int TILE = 2 * 32 * D * 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // 3 x KSF x (K tile | V^T tile)
+    constexpr int TILE = 2 * 32 * D * 2, KSF = KS2 ? 2 : 1, SLOT = KSF * TILE;
     constexpr int NK = D / 16, NV = D / 16, NI = NK + NV;                  // 1-KiB wave-instructions per tile
     constexpr int PER = (NI + NW - 1) / NW;                                // issued by every wave (wrapping: duplicates are benign)
     constexpr int CPR = D / 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m32 = lane & 31, hi = lane >> 5;
     const int G = H / Hkv;
-    const int TB = NW / G;                                                  // 32-token blocks per workgroup
+    const int TB = NW / G / KSF;                                            // 32-token blocks per workgroup
+    const int sub = wave / G, tok_sub = sub / KSF, ksub = sub % KSF;       // this wave's token block and key-tile parity
     const int len = (int)st->len;
     const int c0 = (int)st->call0;
     const int krow = (m32 & 19) | ((m32 & 4) << 1) | ((m32 & 8) >> 1);      // pi(m): bits 2 and 3 swapped
@@ -424,8 +429,8 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *_
     const bf16_t *kb = kc + (size_t)hk * seq_alloc * D;
     const bf16_t *vb = vT + (size_t)hk * D * seq_alloc;
     const int tb0 = blk * TB * 32;
-    const int t0 = tb0 + (wave / G) * 32;
-    const bool wave_on = wave < TB * G;                                     // NW need not be a multiple of G
+    const int t0 = tb0 + tok_sub * 32;
+    const bool wave_on = wave < TB * G * KSF;                               // NW need not be a multiple of G
     const int t = t0 + m32;
     const bool col_ok = wave_on && t < T;
 
@@ -464,7 +469,8 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *_
     int kstart = 0;
     if (c0 == 0 && window >= 0 && len + tb0 - window > 0) kstart = ((len + tb0 - window) / 32) * 32;
     const int kend = len + min(T, tb0 + 32 * TB);
-    const int nsteps = (kend - kstart + 31) / 32;
+    const int ntiles = (kend - kstart + 31) / 32;
+    const int nsteps = (ntiles + KSF - 1) / KSF;                            // a step = KSF key tiles, one per wave of a pair
 
     auto stage = [&](int kbase, unsigned char *buf) {
         unsigned char *kt = buf, *vt = buf + 32 * D * 2;
@@ -481,17 +487,24 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *_
             }
         }
     };
-    stage(kstart, lds);
-    if (nsteps > 1) stage(kstart + 32, lds + TILE);
+    // (a step always stages KSF tiles so that the counted wait below is the same for every step: the tile behind the
+    // last one is the last one again)
+    auto stage_step = [&](int s_, unsigned char *slot) {
+#pragma unroll
+        for (int f = 0; f < KSF; f++) stage(kstart + 32 * min(s_ * KSF + f, ntiles - 1), slot + f * TILE);
+    };
+    stage_step(0, lds);
+    if (nsteps > 1) stage_step(1, lds + SLOT);
 
     for (int sidx = 0; sidx < nsteps; sidx++) {
-        if (sidx + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        if (sidx + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * KSF) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const int kbase = kstart + 32 * sidx;
-        if (sidx + 2 < nsteps) stage(kbase + 64, lds + ((sidx + 2) % 3) * TILE);
-        if (!(kbase + 32 > wstart && kbase < wend)) continue;              // wave-uniform
-        const unsigned char *kt = lds + (sidx % 3) * TILE, *vt = kt + 32 * D * 2;
+        if (sidx + 2 < nsteps) stage_step(sidx + 2, lds + ((sidx + 2) % 3) * SLOT);
+        const int jt = sidx * KSF + ksub;                                   // this wave's key tile of the step
+        const int kbase = kstart + 32 * jt;
+        if (jt >= ntiles || !(kbase + 32 > wstart && kbase < wend)) continue;   // wave-uniform
+        const unsigned char *kt = lds + (sidx % 3) * SLOT + ksub * TILE, *vt = kt + 32 * D * 2;
 
         // all K fragments are requested before the first MFMA (one register set per fragment: a shared one would
         // expose the LDS latency D/16 times per tile), the V fragments right behind them
@@ -572,8 +585,31 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *_
             for (int ks = 0; ks < 2; ks++) O[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks][db], pa[ks], O[db], 0, 0, 0);
     }
 
+    if constexpr (KS2) {
+        // the two waves of a (head, token block) meet: the odd one hands (m, l, O) over through the ring's memory
+        __builtin_amdgcn_s_barrier();                                       // every wave is done with the key tiles
+        float *mx = reinterpret_cast<float *>(lds) + (size_t)(tok_sub * G + wave % G) * (64 * (D / 2 + 2));
+        if (wave_on && ksub == 1) {
+            mx[lane] = mrow; mx[64 + lane] = lrow;
+#pragma unroll
+            for (int db = 0; db < D / 32; db++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) mx[(2 + db * 16 + r) * 64 + lane] = O[db][r];
+        }
+        __builtin_amdgcn_s_barrier();
+        if (wave_on && ksub == 0) {
+            const float m1 = mx[lane], l1 = mx[64 + lane];
+            const float mn = fmaxf(mrow, m1);
+            const float a0 = mrow == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mrow - mn), a1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m1 - mn);
+            lrow = lrow * a0 + l1 * a1;
+#pragma unroll
+            for (int db = 0; db < D / 32; db++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) O[db][r] = O[db][r] * a0 + mx[(2 + db * 16 + r) * 64 + lane] * a1;
+        }
+    }
     const float ltot = lrow + __shfl_xor(lrow, 32, 64);
-    if (col_ok) {
+    if (col_ok && ksub == 0) {
         const float inv = 1.0f / ltot;
         bf16_t *o = out + ((size_t)t * H + hq) * D;
 #pragma unroll
@@ -591,7 +627,7 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *_
     }
 }
 
-template <int D, int NW>
+template <int D, int NW, bool KS2 = false>
 static int launch_pf32(Launcher &L, const void *q, const void *k_cache, const void *v_cache_T, const StepState *st, void *out,
                        int64_t T, int64_t H, int64_t Hkv, int64_t seq_alloc, float scale, int64_t window, int TB, int paired) {
     const int64_t nb = (T + 32 * TB - 1) / (32 * TB);
@@ -605,10 +641,11 @@ static int launch_pf32(Launcher &L, const void *q, const void *k_cache, const vo
         if (cached.load()) cus = cached.load();
         grid = dim3((unsigned)cus, 1);
     }
-    const size_t lds = 3 * (size_t)(2 * 32 * D * 2);
+    const size_t lds = 3 * (size_t)(2 * 32 * D * 2) * (KS2 ? 2 : 1);
     const double flops = 2.0 * (double)T * T * H * D;
-    Launcher LL = L; LL.tag = "32row";
-    return LL.launch(KC_ATTN_PREFILL, 0, flops, attn_prefill32_kernel<D, NW>, grid, dim3(NW * 64), lds, (const bf16_t *)q,
+    Launcher LL = L; LL.tag = KS2 ? "32row,ks2" : "32row";
+    FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(attn_prefill32_kernel<D, NW, KS2>), lds));
+    return LL.launch(KC_ATTN_PREFILL, 0, flops, attn_prefill32_kernel<D, NW, KS2>, grid, dim3(NW * 64), lds, (const bf16_t *)q,
                      (const bf16_t *)k_cache, (const bf16_t *)v_cache_T, st, (bf16_t *)out, (int)T, (int)H, (int)Hkv, (int)seq_alloc,
                      scale * 1.44269504088896340736f, (int)window, paired);
 }
@@ -622,19 +659,29 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
     const int G = (int)(H / Hkv);
     if (G > 8) FL_FAIL(FL_ERR_UNSUPPORTED, "mfma prefill attention: at most 8 query heads per kv head");
     // 32-row waves (attn_prefill32_kernel) once the prompt is long enough to fill the chip with their workgroups
-    static const int pf32_min_t = getenv("FL_ATTN_PF32_MIN_T") ? atoi(getenv("FL_ATTN_PF32_MIN_T")) : 1024;
+    // (with wave pairs -- G = 1, 2, 4 -- from 640 tokens: Mistral-7B T = 768 31.9 -> 24.8 us per layer, T = 512 a tie, below slower)
+    static const int pf32_min_env = getenv("FL_ATTN_PF32_MIN_T") ? atoi(getenv("FL_ATTN_PF32_MIN_T")) : 0;
+    const int pf32_min_t = pf32_min_env > 0 ? pf32_min_env : ((G == 1 || G == 2 || G == 4) ? 640 : 1024);
     const int force = g_prefill_force.load();                        // fl_op_attention pins one kernel (unit tests)
     if ((force == 3 || (force == 0 && T >= pf32_min_t)) && scale > 0.f) {
         // waves per workgroup: 8 (G = 1, 2, 4), 6 (G = 3), else G.  Paired (balanced) grids win as soon as they cover
         // ~3/4 of the chip -- Mistral-7B per layer: T = 3072 134 us paired (192 workgroups) vs 197 unpaired, T = 4096
         // 177 vs 305, T = 8192 681 vs 693; T = 2048 (128 paired workgroups) 98 vs 85.  4-wave workgroups (half the K/V
         // reuse, one wave per SIMD) lost everywhere: T = 2048 105 / 180 us, T = 4096 371 / 515.
-        const int NW = G <= 4 ? (8 / G) * G : G, TB = NW / G;
+        const int NW = G <= 4 ? (8 / G) * G : G;
+        int TB = NW / G;
+        // too few (block, kv head) items to balance: halve the token blocks and split every block's keys over a wave pair
+        const char *eks = getenv("FL_ATTN_PF32_KS2");                // read per call: tests pin it
+        const int ks2_mode = eks && *eks ? atoi(eks) : -1;
+        const bool ks2 = NW == 8 && TB % 2 == 0 && (ks2_mode >= 0 ? ks2_mode != 0 : ((T + 32 * TB - 1) / (32 * TB)) * Hkv < 2 * 256);
+        if (ks2) TB /= 2;
         const int64_t nb = (T + 32 * TB - 1) / (32 * TB);
         const char *fp = getenv("FL_ATTN_PF32_PAIRED");              // read per call: tests pin the schedule
         const int force_pair = fp && *fp ? atoi(fp) : -1;
         // two rounds or more of (block, kv head) items: persistent workgroups, snake order (launch_pf32)
         const int paired = force_pair >= 0 ? force_pair : (nb * Hkv >= 2 * 256 ? 2 : ((nb + 1) / 2 * Hkv >= 180 ? 1 : 0));
+        if (ks2 && d == 128) return launch_pf32<128, 8, true>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired);
+        if (ks2 && d == 64) return launch_pf32<64, 8, true>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired);
 #define FL_PF32(DD, WW) if (d == DD && NW == WW) return launch_pf32<DD, WW>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired);
         FL_PF32(128, 8) FL_PF32(128, 7) FL_PF32(128, 6) FL_PF32(128, 5) FL_PF32(64, 8) FL_PF32(64, 7) FL_PF32(64, 6) FL_PF32(64, 5)
 #undef FL_PF32

@@ -99,6 +99,19 @@ def test_baseline_shapes_and_the_rescale_branch(fa, d, H, Hkv):
     check(fa.op_attention(q, k, v, 0, H, Hkv, d, window=-1, kernel=0), reference(q, k, v, 0, H, Hkv, d, -1), "prefill auto")
 
 
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("H,Hkv", [(8, 8), (8, 4), (32, 8)])                              # G = 1, 2, 4: the groups the wave pairs fit
+@pytest.mark.parametrize("T,s_past,window", [(33, 0, -1), (100, 0, 5), (257, 0, -1), (70, 129, 17), (1100, 0, 300), (2100, 0, -1)])
+def test_prefill32_key_split(fa, monkeypatch, d, H, Hkv, T, s_past, window):
+    """KS2: two waves per (head, 32-token block) on alternate key tiles, merged through LDS (what prompts of ~1-4 k tokens
+    get when there are too few blocks to balance): odd and even tile counts, a single tile, cached prefix, window, a ragged
+    last block; T = 2100 with 8 kv heads is 528 items: the snake's second round as well."""
+    monkeypatch.setenv("FL_ATTN_PF32_KS2", "1")
+    q, k, v = make(T, s_past, H, Hkv, d, seed=T + s_past + d + H, spike=T > 1000)
+    got = fa.op_attention(q, k, v, s_past, H, Hkv, d, window=window, kernel=3)
+    check(got, reference(q, k, v, s_past, H, Hkv, d, window), "prefill32 ks2 d=%d G=%d T=%d past=%d w=%d" % (d, H // Hkv, T, s_past, window))
+
+
 @pytest.mark.parametrize("d,H,Hkv", [(128, 32, 8), (128, 28, 4)])
 @pytest.mark.parametrize("sched", [0, 1, 2])
 def test_prefill32_schedules(fa, monkeypatch, d, H, Hkv, sched):
@@ -106,6 +119,7 @@ def test_prefill32_schedules(fa, monkeypatch, d, H, Hkv, sched):
     long prompts get) -- on a prompt whose (block, kv head) items exceed one round of the chip (264 > 256: some workgroups take
     two), with a ragged last block (2100 % 32 = 20) and a window that bites."""
     monkeypatch.setenv("FL_ATTN_PF32_PAIRED", str(sched))
+    monkeypatch.setenv("FL_ATTN_PF32_KS2", "0")
     T = 2100
     q, k, v = make(T, 0, H, Hkv, d, seed=77 + sched, spike=True)
     for window in (-1, 1000):
