@@ -392,7 +392,7 @@ template <int D, int NW, bool KS2>
 __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
                                                                  const bf16_t *__restrict__ vT, const StepState *__restrict__ st,
                                                                  bf16_t *__restrict__ out, int T, int H, int Hkv, int seq_alloc,
-                                                                 float scale_log2e, int window, int paired) {
+                                                                 float scale_log2e, int window, int paired, int gsub) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // 3 x KSF x (K tile | V^T tile)
     constexpr int TILE = 2 * 32 * D * 2, KSF = KS2 ? 2 : 1, SLOT = KSF * TILE;
     constexpr int NK = D / 16, NV = D / 16, NI = NK + NV;                  // 1-KiB wave-instructions per tile
@@ -400,9 +400,11 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *_
     constexpr int CPR = D / 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m32 = lane & 31, hi = lane >> 5;
-    const int G = H / Hkv;
-    const int TB = NW / G / KSF;                                            // 32-token blocks per workgroup
-    const int sub = wave / G, tok_sub = sub / KSF, ksub = sub % KSF;       // this wave's token block and key-tile parity
+    // gsub > 0 (groups of 7 or 8 query heads, which leave no room for wave pairs): a workgroup serves gsub of a kv head's G query
+    // heads, the group is dealt as nsg = ceil(G / gsub) items (Qwen2-7B: 4 + 3 heads; one wave pair of the second item idles)
+    const int G = H / Hkv, Gs = gsub > 0 ? gsub : G, nsg = (G + Gs - 1) / Gs;
+    const int TB = NW / Gs / KSF;                                           // 32-token blocks per workgroup
+    const int sub = wave / Gs, tok_sub = sub / KSF, ksub = sub % KSF;      // this wave's token block and key-tile parity
     const int len = (int)st->len;
     const int c0 = (int)st->call0;
     const int krow = (m32 & 19) | ((m32 & 4) << 1) | ((m32 & 8) >> 1);      // pi(m): bits 2 and 3 swapped
@@ -413,24 +415,26 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *_
     // P-1..0, so consecutive rounds add up to the same work for everyone whatever nb x Hkv is (4608 tokens of Qwen2-7B are
     // 288 paired workgroups: 1.125 rounds that took as long as two).
     const int nb = (T + 32 * TB - 1) / (32 * TB);
-    const int npass = paired == 2 ? (nb * Hkv + (int)gridDim.x - 1) / (int)gridDim.x : (paired ? 2 : 1);
+    const int nhs = Hkv * nsg;                                              // (kv head, head subgroup) pairs
+    const int npass = paired == 2 ? (nb * nhs + (int)gridDim.x - 1) / (int)gridDim.x : (paired ? 2 : 1);
     for (int pass = 0; pass < npass; pass++) {
-    int blk, hk;
+    int blk, hs;
     if (paired == 2) {
         const int item = pass * (int)gridDim.x + ((pass & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
-        if (item >= nb * Hkv) break;                                        // (only the last round can be short)
-        blk = nb - 1 - item / Hkv; hk = item % Hkv;
+        if (item >= nb * nhs) break;                                        // (only the last round can be short)
+        blk = nb - 1 - item / nhs; hs = item % nhs;
     } else {
-        hk = blockIdx.y;
+        hs = blockIdx.y;
         blk = pass == 0 ? nb - 1 - (int)blockIdx.x : (int)blockIdx.x;
         if (pass == 1 && blk >= nb - 1 - (int)blockIdx.x) break;            // odd count: the middle block was pass 0
     }
-    const int hq = hk * G + wave % G;
+    const int hk = hs / nsg, g = (hs % nsg) * Gs + wave % Gs;             // kv head; query head within its group
+    const int hq = hk * G + min(g, G - 1);
     const bf16_t *kb = kc + (size_t)hk * seq_alloc * D;
     const bf16_t *vb = vT + (size_t)hk * D * seq_alloc;
     const int tb0 = blk * TB * 32;
     const int t0 = tb0 + tok_sub * 32;
-    const bool wave_on = wave < TB * G * KSF;                               // NW need not be a multiple of G
+    const bool wave_on = wave < TB * Gs * KSF && g < G;                     // NW need not be a multiple of Gs; a short last subgroup
     const int t = t0 + m32;
     const bool col_ok = wave_on && t < T;
 
@@ -588,7 +592,7 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *_
     if constexpr (KS2) {
         // the two waves of a (head, token block) meet: the odd one hands (m, l, O) over through the ring's memory
         __builtin_amdgcn_s_barrier();                                       // every wave is done with the key tiles
-        float *mx = reinterpret_cast<float *>(lds) + (size_t)(tok_sub * G + wave % G) * (64 * (D / 2 + 2));
+        float *mx = reinterpret_cast<float *>(lds) + (size_t)(tok_sub * Gs + wave % Gs) * (64 * (D / 2 + 2));
         if (wave_on && ksub == 1) {
             mx[lane] = mrow; mx[64 + lane] = lrow;
 #pragma unroll
@@ -629,9 +633,10 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *_
 
 template <int D, int NW, bool KS2 = false>
 static int launch_pf32(Launcher &L, const void *q, const void *k_cache, const void *v_cache_T, const StepState *st, void *out,
-                       int64_t T, int64_t H, int64_t Hkv, int64_t seq_alloc, float scale, int64_t window, int TB, int paired) {
+                       int64_t T, int64_t H, int64_t Hkv, int64_t seq_alloc, float scale, int64_t window, int TB, int paired, int gsub = 0) {
     const int64_t nb = (T + 32 * TB - 1) / (32 * TB);
-    dim3 grid((unsigned)(paired ? (nb + 1) / 2 : nb), (unsigned)Hkv);
+    const int64_t G = H / Hkv, nsg = gsub > 0 ? (G + gsub - 1) / gsub : 1;
+    dim3 grid((unsigned)(paired ? (nb + 1) / 2 : nb), (unsigned)(Hkv * nsg));
     if (paired == 2) {
         int dev = 0, cus = 256;
         hipDeviceProp_t prop;
@@ -647,7 +652,7 @@ static int launch_pf32(Launcher &L, const void *q, const void *k_cache, const vo
     FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(attn_prefill32_kernel<D, NW, KS2>), lds));
     return LL.launch(KC_ATTN_PREFILL, 0, flops, attn_prefill32_kernel<D, NW, KS2>, grid, dim3(NW * 64), lds, (const bf16_t *)q,
                      (const bf16_t *)k_cache, (const bf16_t *)v_cache_T, st, (bf16_t *)out, (int)T, (int)H, (int)Hkv, (int)seq_alloc,
-                     scale * 1.44269504088896340736f, (int)window, paired);
+                     scale * 1.44269504088896340736f, (int)window, paired, gsub);
 }
 
 static std::atomic<int> g_prefill_force{0};
@@ -659,9 +664,10 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
     const int G = (int)(H / Hkv);
     if (G > 8) FL_FAIL(FL_ERR_UNSUPPORTED, "mfma prefill attention: at most 8 query heads per kv head");
     // 32-row waves (attn_prefill32_kernel) once the prompt is long enough to fill the chip with their workgroups
-    // (with wave pairs -- G = 1, 2, 4 -- from 640 tokens: Mistral-7B T = 768 31.9 -> 24.8 us per layer, T = 512 a tie, below slower)
+    // (with wave pairs from 640 tokens for G = 1, 2, 4: Mistral-7B T = 768 31.9 -> 24.8 us per layer, T = 512 a tie, below slower;
+    // from 256 tokens for the groups dealt as subgroups of four heads: Qwen2-7B T = 512 23.2 -> 18.3, TinyLlama 16.5 -> 13.2, T = 256 a tie)
     static const int pf32_min_env = getenv("FL_ATTN_PF32_MIN_T") ? atoi(getenv("FL_ATTN_PF32_MIN_T")) : 0;
-    const int pf32_min_t = pf32_min_env > 0 ? pf32_min_env : ((G == 1 || G == 2 || G == 4) ? 640 : 1024);
+    const int pf32_min_t = pf32_min_env > 0 ? pf32_min_env : ((G == 1 || G == 2 || G == 4) ? 640 : (G > 4 ? 256 : 1024));
     const int force = g_prefill_force.load();                        // fl_op_attention pins one kernel (unit tests)
     if ((force == 3 || (force == 0 && T >= pf32_min_t)) && scale > 0.f) {
         // waves per workgroup: 8 (G = 1, 2, 4), 6 (G = 3), else G.  Paired (balanced) grids win as soon as they cover
@@ -673,15 +679,19 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
         // too few (block, kv head) items to balance: halve the token blocks and split every block's keys over a wave pair
         const char *eks = getenv("FL_ATTN_PF32_KS2");                // read per call: tests pin it
         const int ks2_mode = eks && *eks ? atoi(eks) : -1;
-        const bool ks2 = NW == 8 && TB % 2 == 0 && (ks2_mode >= 0 ? ks2_mode != 0 : ((T + 32 * TB - 1) / (32 * TB)) * Hkv < 2 * 256);
+        bool ks2 = NW == 8 && TB % 2 == 0 && (ks2_mode >= 0 ? ks2_mode != 0 : ((T + 32 * TB - 1) / (32 * TB)) * Hkv < 2 * 256);
+        // groups of 5..8 heads: wave pairs only fit when the group is dealt in subgroups of four heads (8 waves = 4 heads x a pair)
+        int gsub = 0;
+        if (!ks2 && G > 4 && (ks2_mode >= 0 ? ks2_mode != 0 : ((T + 31) / 32) * Hkv < 2 * 256)) { ks2 = true; gsub = 4; TB = 2; }
         if (ks2) TB /= 2;
         const int64_t nb = (T + 32 * TB - 1) / (32 * TB);
+        const int64_t nhs = Hkv * (gsub ? (G + gsub - 1) / gsub : 1);
         const char *fp = getenv("FL_ATTN_PF32_PAIRED");              // read per call: tests pin the schedule
         const int force_pair = fp && *fp ? atoi(fp) : -1;
         // two rounds or more of (block, kv head) items: persistent workgroups, snake order (launch_pf32)
-        const int paired = force_pair >= 0 ? force_pair : (nb * Hkv >= 2 * 256 ? 2 : ((nb + 1) / 2 * Hkv >= 180 ? 1 : 0));
-        if (ks2 && d == 128) return launch_pf32<128, 8, true>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired);
-        if (ks2 && d == 64) return launch_pf32<64, 8, true>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired);
+        const int paired = force_pair >= 0 ? force_pair : (nb * nhs >= 2 * 256 ? 2 : ((nb + 1) / 2 * nhs >= 180 ? 1 : 0));
+        if (ks2 && d == 128) return launch_pf32<128, 8, true>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired, gsub);
+        if (ks2 && d == 64) return launch_pf32<64, 8, true>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired, gsub);
 #define FL_PF32(DD, WW) if (d == DD && NW == WW) return launch_pf32<DD, WW>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired);
         FL_PF32(128, 8) FL_PF32(128, 7) FL_PF32(128, 6) FL_PF32(128, 5) FL_PF32(64, 8) FL_PF32(64, 7) FL_PF32(64, 6) FL_PF32(64, 5)
 #undef FL_PF32

@@ -100,7 +100,7 @@ def test_baseline_shapes_and_the_rescale_branch(fa, d, H, Hkv):
 
 
 @pytest.mark.parametrize("d", [64, 128])
-@pytest.mark.parametrize("H,Hkv", [(8, 8), (8, 4), (32, 8)])                              # G = 1, 2, 4: the groups the wave pairs fit
+@pytest.mark.parametrize("H,Hkv", [(8, 8), (8, 4), (32, 8), (28, 4), (8, 1), (10, 2)])    # G = 1, 2, 4: wave pairs fit; 7, 8, 5: dealt as subgroups of 4 heads
 @pytest.mark.parametrize("T,s_past,window", [(33, 0, -1), (100, 0, 5), (257, 0, -1), (70, 129, 17), (1100, 0, 300), (2100, 0, -1)])
 def test_prefill32_key_split(fa, monkeypatch, d, H, Hkv, T, s_past, window):
     """KS2: two waves per (head, 32-token block) on alternate key tiles, merged through LDS (what prompts of ~1-4 k tokens
