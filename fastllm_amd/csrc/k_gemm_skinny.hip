@@ -299,6 +299,31 @@ __global__ __launch_bounds__((NW * NWM + NLW) * 64) void gemm_skinny_ld_kernel(c
     skinny_epilogue<MT, NT>(acc, out, bias, row_scale, T, N, epi, m0 + wm * MT * 16, n0 + wave * 16 * NT, lane);
 }
 
+// diagnostics (FL_SKINNY_STAMPS=file): run a stamped instantiation synchronously and append its per-wave counters to the file
+template <typename Kern>
+static int run_stamped(Launcher &LL, Kern kst, dim3 grid, dim3 block, size_t lds, double bytes, double flops, const char *path, int waves_per_wg,
+                       const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K, int epi, const float *row_scale, int ksplit) {
+    FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kst), lds));
+    const size_t nw = (size_t)grid.x * grid.y * grid.z * waves_per_wg;
+    unsigned long long *d = nullptr;
+    FL_HIP(hipMalloc(&d, nw * 64));
+    const int rc = LL.launch(KC_GEMM_MFMA, bytes, flops, kst, grid, block, lds, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K,
+                             epi, row_scale, ksplit, d);
+    std::vector<unsigned long long> h(nw * 8);
+    FL_HIP(hipStreamSynchronize(LL.stream));
+    FL_HIP(hipMemcpy(h.data(), d, nw * 64, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    if (FILE *f = fopen(path, "a")) {
+        fprintf(f, "launch %lld %lld %lld %d %zu %d\n", (long long)T, (long long)N, (long long)K, epi, nw, waves_per_wg);
+        for (size_t i = 0; i < nw; i++) {
+            for (int j = 0; j < 8; j++) fprintf(f, "%llu ", h[i * 8 + j]);
+            fprintf(f, "\n");
+        }
+        fclose(f);
+    }
+    return rc;
+}
+
 template <int BM, int NT, int NW, int NWM, bool WNT>
 static int launch_skinny_ld_s(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
                               int epi, const float *row_scale, int ksplit) {
@@ -313,28 +338,9 @@ static int launch_skinny_ld_s(Launcher &L, const void *W, const void *x, const f
     char tag[32];
     snprintf(tag, sizeof tag, "skinny,ld,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");
     Launcher LL = L; LL.tag = tag;
-    if (const char *path = getenv("FL_SKINNY_STAMPS")) {            // diagnostics: synchronous, appends one record per launch
-        auto kst = gemm_skinny_ld_kernel<BM, NT, NW, NWM, NLW, NSTG, WNT, true>;
-        FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kst), lds));
-        const size_t nw = (size_t)grid.x * grid.y * grid.z * (NWV + NLW);
-        unsigned long long *d = nullptr;
-        FL_HIP(hipMalloc(&d, nw * 64));
-        const int rc = LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kst, grid, block, lds, (const bf16_t *)W, (const bf16_t *)x, bias,
-                                 y, (int)T, (int)N, (int)K, epi, row_scale, ksplit, d);
-        std::vector<unsigned long long> h(nw * 8);
-        FL_HIP(hipStreamSynchronize(L.stream));
-        FL_HIP(hipMemcpy(h.data(), d, nw * 64, hipMemcpyDeviceToHost));
-        (void)hipFree(d);
-        if (FILE *f = fopen(path, "a")) {
-            fprintf(f, "launch %lld %lld %lld %d %zu %d\n", (long long)T, (long long)N, (long long)K, epi, nw, NWV + NLW);
-            for (size_t i = 0; i < nw; i++) {
-                for (int j = 0; j < 8; j++) fprintf(f, "%llu ", h[i * 8 + j]);
-                fprintf(f, "\n");
-            }
-            fclose(f);
-        }
-        return rc;
-    }
+    if (const char *path = getenv("FL_SKINNY_STAMPS"))
+        return run_stamped(LL, gemm_skinny_ld_kernel<BM, NT, NW, NWM, NLW, NSTG, WNT, true>, grid, block, lds, bytes, 2.0 * T * N * K, path, NWV + NLW,
+                           W, x, bias, y, T, N, K, epi, row_scale, ksplit);
     auto kern = gemm_skinny_ld_kernel<BM, NT, NW, NWM, NLW, NSTG, WNT, false>;
     FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
     return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, grid, block, lds, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K,
@@ -355,6 +361,11 @@ static int launch_skinny_s(Launcher &L, const void *W, const void *x, const floa
     snprintf(tag, sizeof tag, "skinny,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");
     Launcher LL = L; LL.tag = tag;
     const dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)ksplit, (unsigned)((T + BM - 1) / BM));
+    if constexpr (BM == 128 && !WNT && NSTG == 4) {                // (the shipped kernel's own counters: FL_SKINNY_STAMPS with FL_SKINNY_LOADERS=0)
+        if (const char *path = getenv("FL_SKINNY_STAMPS"))
+            return run_stamped(LL, gemm_skinny_kernel<BM, NT, NW, NSTG, WNT, NWM, true>, grid, dim3(NW * NWM * 64), lds, bytes, 2.0 * T * N * K, path,
+                               NW * NWM, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
+    }
     return LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, grid, dim3(NW * NWM * 64), lds,
                      (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, row_scale, ksplit, (unsigned long long *)nullptr);
 }

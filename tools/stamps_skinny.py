@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise FL_SKINNY_STAMPS records (k_gemm_skinny.hip diagnostic instantiation, 128-token workgroups): core-clock cycles
+"""Summarise FL_SKINNY_STAMPS records (k_gemm_skinny.hip diagnostic instantiations; FL_SKINNY_LOADERS=0: the shipped kernel at 128 tokens, default: the loader-wave variant): core-clock cycles
 per K step a wave spends in the counted vmcnt wait / at the barrier / issuing LDS-DMA / in fragment reads + MFMAs.
 Usage: FL_SKINNY_STAMPS=f python tools/stamps_run.py 128 N K epi; python tools/stamps_skinny.py f"""
 import sys
