@@ -637,13 +637,17 @@ static int launch_pf32(Launcher &L, const void *q, const void *k_cache, const vo
     const int64_t nb = (T + 32 * TB - 1) / (32 * TB);
     const int64_t G = H / Hkv, nsg = gsub > 0 ? (G + gsub - 1) / gsub : 1;
     dim3 grid((unsigned)(paired ? (nb + 1) / 2 : nb), (unsigned)(Hkv * nsg));
-    if (paired == 2) {
+    if (paired == 2) {                                              // one persistent workgroup per CU of the CURRENT device
+        static std::atomic<int> cached[64];
         int dev = 0, cus = 256;
-        hipDeviceProp_t prop;
-        static std::atomic<int> cached{0};
-        if (!cached.load() && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            cached = prop.multiProcessorCount;
-        if (cached.load()) cus = cached.load();
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            cus = cached[dev].load();
+            if (!cus) {
+                hipDeviceProp_t prop;
+                cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+                cached[dev].store(cus);
+            }
+        }
         grid = dim3((unsigned)cus, 1);
     }
     const size_t lds = 3 * (size_t)(2 * 32 * D * 2) * (KS2 ? 2 : 1);
