@@ -58,11 +58,19 @@ __global__ __launch_bounds__(256) void rmsnorm_add_kernel(float *__restrict__ x_
         load8(xr + c * 8, v);
         load8(w + c * 8, wv);
         if (dr) {
-            for (int sl = 0; sl < n_slab; sl++) {            // split-K slabs, fixed order
-                float d[8];
-                load8(dr + (size_t)sl * slab_stride + c * 8, d);
+            // split-K slabs, summed in slab order; four are requested at a time (one slab per round trip made this launch a
+            // latency chain at eight slabs: Mistral-7B T = 512 13.3 us)
+            for (int sl = 0; sl < n_slab; sl += 4) {
+                float d[4][8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] += d[j];
+                for (int u = 0; u < 4; u++)
+                    if (sl + u < n_slab) load8(dr + (size_t)(sl + u) * slab_stride + c * 8, d[u]);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (sl + u < n_slab) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) v[j] += d[u][j];
+                    }
             }
             store8(xr + c * 8, v);
         }
