@@ -19,6 +19,8 @@ timeout -k 10 300 python3 tools/batch_bench.py --profile --batches 1,2,3,4,6,8 >
 timeout -k 10 200 python3 tools/sample_cost.py > $O/sample_cost.txt 2> $O/sample.err || exit 1
 timeout -k 10 200 python3 tools/gemm_probe.py > $O/gemm_probe.txt 2> $O/gemm_probe.err || exit 1
 (timeout -k 10 200 python3 tools/prefill_sweep.py mistral-7b; timeout -k 10 200 python3 tools/prefill_sweep.py tinyllama-1.1b) 2> $O/prefill_sweep.err | grep 'T=' > $O/prefill_sweep.txt || exit 1
+# prompt lengths that are not round numbers (tile / block quantisation), Mistral-7B, Qwen2-7B, TinyLlama
+(timeout -k 10 300 python3 tools/prefill_ragged.py mistral-7b; timeout -k 10 300 python3 tools/prefill_ragged.py qwen2-7b; timeout -k 10 200 python3 tools/prefill_ragged.py tinyllama-1.1b 256 384 512 640 768 1024 1100 1536 2048) 2> $O/prefill_ragged.err | grep 'T=' > $O/prefill_ragged.txt || exit 1
 # the way the driver invokes the N-GPU bench: no launcher (bench.py starts its ranks itself)
 for n in 2 4; do
   FL_BENCH_SAME_DEVICE=1 FL_BENCH_BATCH=0 timeout -k 10 400 python3 bench.py --gpus $n --steps 64 --warmup 8 --no-cpu-baseline > $O/bench_tp${n}_same_device.json 2> $O/bench_tp${n}.err || exit 1
