@@ -241,8 +241,9 @@ def test_long_prompt_residual_epilogue_equals_rmsnorm_launches(env, monkeypatch,
     gm.close()
 
 
-@pytest.mark.parametrize("name,T", [("mistral-7b", 1100), ("qwen2-7b", 1100), ("mistral-7b", 4100), ("qwen2-7b", 4096)])
-def test_7b_width_long_prompt_vs_oracle(env, name, T):
+@pytest.mark.parametrize("name,T,tp", [("mistral-7b", 1100, 1), ("qwen2-7b", 1100, 1), ("mistral-7b", 4100, 1), ("qwen2-7b", 4096, 1),
+                                       ("mistral-7b", 512, 8), ("qwen2-7b", 4096, 4)])      # the last two: BASELINE configs C4 / C5, emulated ranks
+def test_7b_width_long_prompt_vs_oracle(env, name, T, tp):
     """The long-prompt kernels against the fp32 ORACLE (not against each other): full width, 2 layers.  1100 tokens (ragged):
     256x256 GEMMs in K slices (Qwen2: with the q/k/v bias riding in the RoPE launch), the key-split 32-row attention.  4096 /
     4100 tokens: peeled GEMMs with stream-K tails and the fix-up launch, the residual epilogue + rms_finalize, the snake
@@ -256,7 +257,8 @@ def test_7b_width_long_prompt_vs_oracle(env, name, T):
     w = host_copy(torch, wts)
     del wts
     torch.cuda.empty_cache()
-    g16 = fa.Model(cfg, w, dtype="bf16")
+    kw = {} if tp == 1 else dict(tp_mode=fa.binding.TP_EMULATED, tp_size=tp)      # every rank's shard on this GPU, real per-rank shapes
+    g16 = fa.Model(cfg, w, dtype="bf16", **kw)
     o32 = oracle.OracleModel(cfg, w)
     ids = synth.prompt_ids(cfg, T + 4, seed=9)
     gc, oc = g16.new_cache(T + 16), o32.new_cache(T + 16)
@@ -265,7 +267,7 @@ def test_7b_width_long_prompt_vs_oracle(env, name, T):
     print("oracle prefill of %d tokens: %.1f s" % (T, time.time() - t0))
     got = g16.forward(gc, ids[:T], 0)
     n = np.linalg.norm(ref)
-    print("%s prefill(%d) bf16 vs fp32 oracle: rel L2 %.2e, argmax %s" % (name, T, np.linalg.norm(got - ref) / n, oracle.argmax(got) == oracle.argmax(ref)))
+    print("%s tp=%d prefill(%d) bf16 vs fp32 oracle: rel L2 %.2e, argmax %s" % (name, tp, T, np.linalg.norm(got - ref) / n, oracle.argmax(got) == oracle.argmax(ref)))
     # (measured 0.9-1.2e-2: bf16 storage against fp32 at full width; the same 2e-2 bound as bench.py's parity gate)
     assert np.linalg.norm(got - ref) <= 2e-2 * n, "%s prefill(%d): rel L2 %.4f" % (name, T, np.linalg.norm(got - ref) / n)
     assert oracle.argmax(got) == oracle.argmax(ref)
