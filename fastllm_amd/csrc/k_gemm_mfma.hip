@@ -247,57 +247,58 @@ bool gemm_mfma_supported(int dtype, int64_t T, int64_t N, int64_t K) {
     return dtype == FL_DTYPE_BF16 && T > 1 && K % BK == 0 && K >= BK && N >= 1;
 }
 
-// Is the 256x256 kernel (one workgroup per CU) worth it with ks K slices?  Returns the fill of its last round in
-// 1/1024 (0 = no).  Measured (gemm_probe, pipeline profiles): 224 tiles +13..29 % over the 128x128 kernel, 2368 tiles
-// +15 %; 288 tiles -6 %, 48..128 tiles -40 %; at exactly 3/4 of a round it still wins when the slices are long
-// (Mistral QKV T = 2048: 152 -> 123 us, T = 1024 with two slices: 78 -> 71 us) and loses when they are 16 K tiles
-// (o_proj T = 768 in four slices: 41 -> 50 us).
-static int gemm_8p_fill(int64_t T, int64_t N, int64_t K, int ks) {
-    static const int mink = getenv("FL_8P_MINK") ? atoi(getenv("FL_8P_MINK")) : 8;   // K steps per slice (16 before the epilogue was trimmed: gemm_probe)
-    if (T < 256 || K % 64 || ks < 1 || (K / 64) / ks < mink) return 0;   // keep the pipeline long enough to pay for its ramp
+// ---- which kernel, how many K slices.  Three tiled kernels; the choice is the cheapest by a model fitted to the probes
+// (tools/gemm_probe.py, prefill_profile.py, prefill_ragged.py), microseconds:
+//   256x256 (k_gemm_8p.hip)  rounds of 256 tiles x (K steps x (1.0 + 0.6 fill) + 6)   one workgroup per CU
+//   256x128                  rounds of 256 tiles x (K steps x 1.21 + 5)      where its own rules admit it (below)
+//   128x128                  rounds of 512 tiles x (K steps x (0.95 + 0.33 fill) + 4)  two workgroups per CU
+//   + K slices: the summing launch's read of the fp32 slabs at ~6 TB/s.
+// Rounds 1 and 2 chose by fill thresholds (>= 192 tiles and 75-82 % of the last round, later half a round of useful
+// fill); sweeping prompt lengths that are not round numbers showed what those miss: one token past a tile boundary put
+// Mistral-7B's gate/up on the 128x128 kernel in two rounds (T = 257: 134 us against 83 at T = 256 and ~106 on the 256x256
+// kernel), Qwen2-7B's at T = 255 likewise (151 us against 89 at 256).  The model reproduces the measured launches within
+// ~10 % (T = 129 gate/up 128x128 86 / 82 measured; T = 256 256x128 82 / 83; Qwen2 T = 255 128x128 151 / 151, 256x256 93 / 89).
+enum { GK_128 = 0, GK_256 = 1, GK_8P = 2 };
+static const double kNoKernel = 1e30;
+// (the write is this launch's ordinary epilogue, spread over ks times the workgroups; what is extra is the summing launch's read:
+// rmsnorm_add with eight 8.4 MB slabs 13.3 us against 5-6 with one)
+static double cost_slabs(int64_t T, int64_t N, int ks) { return ks > 1 ? (double)ks * T * N * 4.0 / 6.0e6 : 0.0; }
+static double cost_8p(int64_t T, int64_t N, int64_t K, int ks) {
+    static const int mink = getenv("FL_8P_MINK") ? atoi(getenv("FL_8P_MINK")) : 8;   // K steps per slice: keep the pipeline long enough to pay for its ramp
+    const char *e8 = getenv("FL_GEMM_8P");                        // read per call: tests switch it
+    if (e8 && *e8 && atoi(e8) == 0) return kNoKernel;
+    if (T <= 128 || K % 64 || ks < 1 || (K / 64) / ks < mink) return kNoKernel;
     const int64_t t8 = ((T + 255) / 256) * ((N + 255) / 256) * ks, rounds = (t8 + 255) / 256;
-    const int fill = (int)(t8 * 1024 / (rounds * 256));
-    // Worth it from about half a round: the 128x128 kernel runs at 0.57-0.63 PFLOP/s on a full grid, this one at ~1.3 x fill
-    // (144 tiles = 56 %: Qwen2-7B QKV at T = 2048 118 -> 78 us, Mistral-7B QKV at T = 1536 122 -> 87).  FL_8P_MINFILL in 1/1024.
-    static const int minfill = getenv("FL_8P_MINFILL") ? atoi(getenv("FL_8P_MINFILL")) : 512;
-    // rows of a ragged last row tile are idle too: the test is on the USEFUL fill (T = 384 is 1.5 row tiles: TinyLlama +10 % without this)
-    const int64_t tm = (T + 255) / 256;
-    if (t8 < 112 || fill * T / (tm * 256) < minfill) return 0;
-    return fill;
+    // a K step takes 1.3-1.4 us on a grid that leaves a quarter of the chip idle and 1.5-1.6 us on a full one (clock and memory
+    // contention): 1.0 + 0.6 x fill, per round; below one row tile every tile takes the bounds-checked epilogue (+8 us)
+    const double last = (double)(t8 - (rounds - 1) * 256) / 256.0, steps = (double)(K / 64) / ks;
+    return (double)(rounds - 1) * (steps * 1.6 + 6.0) + (steps * (1.0 + 0.6 * last) + 6.0) + (T < 256 ? 8.0 : 0.0) + cost_slabs(T, N, ks);
 }
-
-// K slices for the 256x256 kernel: among the splits whose grid covers the chip well enough (gemm_8p_fill), the cheapest by
-// a three-term model fitted to tools/gemm_probe.py / prefill_profile.py -- rounds x (K steps per slice x 1.56 us + ~6 us of
-// prologue and epilogue) + the slabs' trip through memory (written here, read by the summing launch, ~4 TB/s each way).
-// (Best fill alone picked 5 slices of two rounds for Mistral-7B's QKV at T = 1024: 77 us + a 35 us RoPE against 56 + 11 at 2.)
-// 0 if no split qualifies.
-static int gemm_8p_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
-    int best = 0;
-    double best_us = 0.0;
-    for (int ks = 1; ks <= (epi == EPI_F32 ? max_split : 1); ks++) {
-        if (gemm_8p_fill(T, N, K, ks) <= 0) continue;
-        const int64_t t8 = ((T + 255) / 256) * ((N + 255) / 256) * ks, rounds = (t8 + 255) / 256;
-        const double us = (double)rounds * ((double)(K / 64) / ks * 1.56 + 6.0) + (ks > 1 ? (double)ks * T * N * 8.0 / 4.0e6 : 0.0);
-        if (best == 0 || us < best_us) { best = ks; best_us = us; }
-    }
-    return best;
+// the 256x128 kernel keeps its measured niches: very large grids that do not suit the 256x256 one, and -- with K slices -- a
+// grid of exactly one round (224..256 workgroups, >= 8 K steps per slice: Mistral-7B T = 512 down_proj 80 -> 71.5 us in round 1)
+static double cost_256(int64_t T, int64_t N, int64_t K, int ks) {
+    static const int use256 = getenv("FL_GEMM_256") ? atoi(getenv("FL_GEMM_256")) : 1;
+    static const int split256 = getenv("FL_GEMM_256_SPLIT") ? atoi(getenv("FL_GEMM_256_SPLIT")) : 1;
+    if (!use256 || T < 192 || K % BK || K / BK < 3 || ks < 1) return kNoKernel;
+    const int64_t tiles = ((T + BM2 - 1) / BM2) * ((N + BN - 1) / BN) * ks, rounds = (tiles + 255) / 256;
+    const bool one_round = split256 && tiles >= 224 && tiles <= 256 && (K / BK) / ks >= 8;
+    if (!((ks == 1 && tiles >= 1024) || one_round)) return kNoKernel;
+    return (double)rounds * ((double)(K / BK) / ks * 1.21 + 5.0) + cost_slabs(T, N, ks);
 }
-
-// Mid-size prompts (T = 512: 2 row tiles) leave the 256x256 grid far short of the chip and the 128x128 kernel
-// (two stages, vmcnt(0) per K step) at 0.53-0.75 PFLOP/s.  The 256x128 kernel with K slices covers the chip in ONE
-// round of one workgroup per CU: the largest split within the caller's limit whose grid fits 256 workgroups,
-// provided it fills >= 224 of them and every slice keeps >= 8 K steps.  0: not applicable.  Measured in the
-// Mistral-7B pipeline at T = 512 (256 workgroups): down 80 -> 71.5 us, o_proj 30 -> 30; at 192 workgroups it is a
-// wash or worse (T = 512 QKV 48.4 -> 46.0, T = 768 down 113 -> 117, o_proj 41 -> 43), hence the threshold.
-static int gemm_256_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
-    static const int on = getenv("FL_GEMM_256_SPLIT") ? atoi(getenv("FL_GEMM_256_SPLIT")) : 1;
-    if (!on || T < 256 || K % BK) return 0;
-    const int64_t tiles = ((T + BM2 - 1) / BM2) * ((N + BN - 1) / BN);
-    if (tiles > 256) return 0;
-    int best = 0;
-    for (int ks = 1; ks <= (epi == EPI_F32 ? max_split : 1); ks++)
-        if (tiles * ks <= 256 && (K / BK) / ks >= 8) best = ks;
-    return best > 0 && tiles * best >= 224 ? best : 0;
+static double cost_128(int64_t T, int64_t N, int64_t K, int ks) {
+    if (ks < 1 || (ks > 1 && (K / BK) / ks < 8)) return kNoKernel;
+    const int64_t tiles = ((T + BM - 1) / BM) * ((N + BN - 1) / BN) * ks, rounds = (tiles + 511) / 512;
+    // the same dependence on fill as the 256x256 kernel: 1.12 us per K step at half a round (TinyLlama gate/up, T = 384), 1.28 full
+    const double last = (double)(tiles - (rounds - 1) * 512) / 512.0, steps = (double)(K / BK) / ks;
+    return (double)(rounds - 1) * (steps * 1.28 + 4.0) + (steps * (0.95 + 0.33 * last) + 4.0) + cost_slabs(T, N, ks);
+}
+static int pick_kernel(int64_t T, int64_t N, int64_t K, int ks, double *cost_out = nullptr) {
+    const double c8 = cost_8p(T, N, K, ks), c2 = cost_256(T, N, K, ks), c1 = cost_128(T, N, K, ks);
+    int k = GK_128; double c = c1;
+    if (c2 < c) { k = GK_256; c = c2; }
+    if (c8 < c) { k = GK_8P; c = c8; }
+    if (cost_out) *cost_out = c;
+    return k;
 }
 
 // how many K splits the launcher will use for this shape when the caller allows up to max_split slabs
@@ -309,20 +310,14 @@ int gemm_mfma_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split) {
         int64_t n_main = 0;
         if (peel_plan(T, N, K, &n_main)) return 1;
     }
-    {
-        const char *e8 = getenv("FL_GEMM_8P");
-        if (!(e8 && *e8 && atoi(e8) == 0)) {
-            const int k8 = gemm_8p_ksplit(T, N, K, epi, max_split);
-            if (k8 > 0) return k8;
-        }
-        const int k2 = gemm_256_ksplit(T, N, K, epi, max_split);
-        if (k2 > 0) return k2;
+    int best = 1;
+    double best_us = kNoKernel;
+    for (int ks = 1; ks <= (epi == EPI_F32 ? std::max(1, max_split) : 1); ks++) {
+        double c;
+        (void)pick_kernel(T, N, K, ks, &c);
+        if (c < best_us) { best = ks; best_us = c; }               // (ties: fewer slices)
     }
-    const int64_t tiles = ((T + BM - 1) / BM) * ((N + BN - 1) / BN);
-    if (epi != EPI_F32 || max_split <= 1 || tiles >= 256 || K < 2048) return 1;
-    int ks = (int)std::min<int64_t>(max_split, 512 / tiles);
-    while (ks > 1 && (K / BK) / ks < 8) ks--;
-    return ks < 1 ? 1 : ks;
+    return best;
 }
 
 // One launch over the column range this call was given (all of N, or a piece of a peeled matrix): ldc = the row stride
@@ -399,10 +394,21 @@ bool gemm_resid_supported(int dtype, int64_t T, int64_t N, int64_t K, int max_sp
     if (e && *e && atoi(e) == 0) return false;
     const char *e8 = getenv("FL_GEMM_8P");
     if (dtype != FL_DTYPE_BF16 || (e8 && *e8 && atoi(e8) != 1) || T < 256 || K % 64 || K / 64 < 2 || N % 16) return false;
-    if (gemm_mfma_ksplit(T, N, K, EPI_F32, max_split) != 1 || gemm_streamk_whole(T, N, K, EPI_F32)) return false;
+    if (gemm_streamk_whole(T, N, K, EPI_F32)) return false;
     int64_t n_main = 0;
     if (peel_plan(T, N, K, &n_main)) return streamk_on() != 0;     // main launch + stream-K tail, both with the residual epilogue
-    return gemm_8p_fill(T, N, K, 1) > 0;
+    if (pick_kernel(T, N, K, 1) != GK_8P) return false;
+    // against K slices + the rmsnorm_add launch that sums them (reads ks slabs and h, writes h and xn): the residual epilogue
+    // reads h and writes xn itself and leaves a 4 us finalize.  The model is good to ~10 %, the epilogue has won every
+    // measured tie (Mistral-7B down_proj at T = 3000: 314 + 4 us against 306 + 47 in four slices): it gets 15 %.
+    const double tn = (double)T * N;
+    double best_split = kNoKernel;
+    for (int ks = 1; ks <= std::max(1, max_split); ks++) {
+        double c;
+        (void)pick_kernel(T, N, K, ks, &c);
+        best_split = std::min(best_split, c - cost_slabs(T, N, ks) + tn * (4.0 * (ks + 2) + 2.0) / 6.0e6 + 3.0);
+    }
+    return cost_8p(T, N, K, 1) + tn * 6.0 / 6.0e6 + 4.3 <= 1.15 * best_split;
 }
 int launch_gemm_resid(Launcher &L, const void *W, const void *x, int64_t T, int64_t N, int64_t K, const ResidEpi &re) {
     if (re.np != gemm_resid_partials(N)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_resid: partial-sum layout");
@@ -418,32 +424,24 @@ int launch_gemm_resid(Launcher &L, const void *W, const void *x, int64_t T, int6
 
 static int launch_gemm_mfma_impl(Launcher &L, const void *W, const void *x, const float *bias, void *y,
                                  int64_t T, int64_t N, int64_t K, int epi, const float *row_scale, int ksplit, int64_t ldc, bool allow8p) {
-    // 256x256 phase-interleaved kernel (k_gemm_8p.hip).  FL_GEMM_8P: 0 off, 1 when the grid fills the chip, 2 always
+    // 256x256 phase-interleaved kernel (k_gemm_8p.hip).  FL_GEMM_8P: 0 off, 1 where the model above prefers it, 2 always
     const char *e8 = getenv("FL_GEMM_8P");                      // read per call: tests switch it
     const int use8p = !allow8p ? 0 : (e8 && *e8 ? atoi(e8) : 1);
-    if (use8p && K % 64 == 0 && (K / 64) / ksplit >= 2 && (ksplit == 1 || (!bias && epi == EPI_F32))) {
-        // one workgroup per CU: worth it when the last round of tiles is nearly full (gemm_8p_fill)
-        if (use8p >= 2 || gemm_8p_fill(T, N, K, ksplit) > 0)
-            return launch_gemm_8p(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit, ldc);
-    }
-    static const int use256 = getenv("FL_GEMM_256") ? atoi(getenv("FL_GEMM_256")) : 1;
-    if (use256 && T >= 192 && K / BK >= 3 && (ksplit == 1 || (!bias && epi == EPI_F32))) {
+    const bool splittable = ksplit == 1 || (!bias && epi == EPI_F32);
+    int kern = splittable ? pick_kernel(T, N, K, ksplit) : GK_128;
+    if (!use8p && kern == GK_8P) kern = cost_256(T, N, K, ksplit) < cost_128(T, N, K, ksplit) ? GK_256 : GK_128;
+    if (use8p >= 2 && K % 64 == 0 && (K / 64) / ksplit >= 2 && splittable) kern = GK_8P;
+    if (kern == GK_8P) return launch_gemm_8p(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit, ldc);
+    if (kern == GK_256) {
         const int tm2 = (int)((T + BM2 - 1) / BM2), tn2 = (int)((N + BN - 1) / BN);
-        // measured (profiles/r01/gemm_probe.txt): +13 % over the 128x128 kernel at thousands of tiles, -5 % at
-        // ~450 tiles (1.75 rounds of one workgroup per CU): use it only when the tail round does not matter --
-        // or when its grid (with K slices) is exactly one round (gemm_256_ksplit)
-        const bool one_round = ksplit == gemm_256_ksplit(T, N, K, epi, ksplit) && ksplit > 0 && (int64_t)tm2 * tn2 * ksplit <= 256 &&
-                               (int64_t)tm2 * tn2 * ksplit >= 224;
-        if ((ksplit == 1 && (int64_t)tm2 * tn2 >= 1024) || one_round) {
-            const size_t lds2 = 3 * (size_t)STAGE2;                     // 144 KiB
-            FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(gemm_mfma256_kernel), lds2));
-            double bytes2 = ((double)N * K + (double)T * K) * 2.0;
-            char tag2[32];
-            snprintf(tag2, sizeof tag2, "256x128,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");
-            Launcher L2 = L; L2.tag = tag2;
-            return L2.launch(KC_GEMM_MFMA, bytes2, 2.0 * T * N * K, gemm_mfma256_kernel, dim3((unsigned)(tm2 * tn2), (unsigned)ksplit), dim3(512),
-                            lds2, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tm2, tn2, row_scale, ksplit, (int)ldc);
-        }
+        const size_t lds2 = 3 * (size_t)STAGE2;                     // 144 KiB
+        FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(gemm_mfma256_kernel), lds2));
+        double bytes2 = ((double)N * K + (double)T * K) * 2.0;
+        char tag2[32];
+        snprintf(tag2, sizeof tag2, "256x128,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");
+        Launcher L2 = L; L2.tag = tag2;
+        return L2.launch(KC_GEMM_MFMA, bytes2, 2.0 * T * N * K, gemm_mfma256_kernel, dim3((unsigned)(tm2 * tn2), (unsigned)ksplit), dim3(512),
+                        lds2, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tm2, tn2, row_scale, ksplit, (int)ldc);
     }
     const int tiles_m = (int)((T + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
     if (ksplit > 1 && bias) FL_FAIL(FL_ERR_BAD_ARGUMENT, "split-K GEMM cannot add a bias");

@@ -206,3 +206,21 @@ def test_linear_streamk_whole(fa, monkeypatch, T, N, K, epi, bias):
         np.testing.assert_allclose(y, g / (1.0 + np.exp(-g)) * u, atol=2e-3, rtol=2 ** -7)
     else:
         np.testing.assert_allclose(y, ref, atol=4e-5 * np.sqrt(K) + 1e-4, rtol=1e-4)
+
+
+# the 256x256 kernel below one full row tile and just past a tile boundary (the cost model sends e.g. a 255- or 257-token gate/up
+# there): rows past T are clamped on load and skipped on store
+@pytest.mark.parametrize("T,N,K,epi,bias", [(130, 4096, 1024, 0, True), (200, 2048, 2048, 1, False), (255, 4608, 1024, 0, False),
+                                            (257, 3072, 1024, 0, True), (257, 1536, 2048, 1, False)])
+def test_linear_8phase_ragged_rows(fa, monkeypatch, T, N, K, epi, bias):
+    monkeypatch.setenv("FL_GEMM_8P", "2")
+    monkeypatch.setenv("FL_GEMM_SKINNY", "0")
+    x, w = _rand((T, K), 71), _rand((N if not epi else 2 * N, K), 72, 0.05)
+    b = _rand((N,), 73) if bias else None
+    xb, wb = synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w)
+    y = fa.op_linear(xb, wb, b, epilogue=epi)
+    ref = _ref(synth.bf16_bits_to_f32(xb), synth.bf16_bits_to_f32(wb), b, epi)
+    if epi:
+        np.testing.assert_allclose(y, ref, atol=2e-3, rtol=2 ** -7)
+    else:
+        np.testing.assert_allclose(y, ref, atol=2e-5 * np.sqrt(K) + 1e-5, rtol=1e-5)
