@@ -116,6 +116,18 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
                     load8(a.delta + c * 8, dl);
 #pragma unroll
                     for (int j = 0; j < 8; j++) v[i][j] += dl[j];
+                    for (int s0 = 1; s0 < a.delta_nslab; s0 += 7) {        // partial vectors of a K-sliced producer: up to seven per round trip, fixed order
+                        float ds[7][8];
+#pragma unroll
+                        for (int u = 0; u < 7; u++)
+                            if (s0 + u < a.delta_nslab) load8(a.delta + (size_t)(s0 + u) * K + c * 8, ds[u]);
+#pragma unroll
+                        for (int u = 0; u < 7; u++)
+                            if (s0 + u < a.delta_nslab) {
+#pragma unroll
+                                for (int j = 0; j < 8; j++) v[i][j] += ds[u][j];
+                            }
+                    }
                 }
             }
         }

@@ -65,6 +65,7 @@ struct GemvArgs {
     int N = 0, K = 0, epi = EPI_F32, pro = PRO_X;
     // PRO_NORM: x = rmsnorm(x_in + delta) * norm_w, or of the embedding row of st->token
     const float *x_in = nullptr, *delta = nullptr, *norm_w = nullptr;
+    int delta_nslab = 1;            // delta is the sum of this many [K] vectors, K floats apart (the fused attention + o_proj launch leaves one per kv head)
     float eps = 0.f;
     float *x_out = nullptr;         // updated residual, written by workgroup 0 (must differ from x_in)
     const void *embed = nullptr;    // [V,K] compute dtype, or null
@@ -103,6 +104,7 @@ struct GemvBatchArgs {
     const float *x_scale = nullptr; // PRO_X (k_gemv_dma.hip): optional [B] factors applied to the accumulators (1/rms of a separate norm)
     // PRO_NORM: x[b] = rmsnorm(x_in[b] + sum_s delta[s][b]) * norm_w, or of the embedding row of seqs[b].st->token
     const float *x_in = nullptr, *delta = nullptr, *norm_w = nullptr;
+    int delta_nslab = 1;            // delta is the sum of this many [K] vectors, K floats apart (the fused attention + o_proj launch leaves one per kv head)
     int n_slab = 1; long long slab_stride = 0;
     float eps = 0.f;
     float *x_out = nullptr;         // [B][K] updated residual (must differ from x_in)
@@ -235,12 +237,14 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
 // test hook (fl_op_attention): 0 = pick by prompt length, 2 = the 16-row kernel, 3 = the 32-row kernel
 void attn_prefill_force(int which);
 
-// decode attention + o_proj in one launch (k_attn_oproj.hip): W_o is pulled into LDS while attention runs
+// decode attention + o_proj in one launch (k_attn_oproj.hip): W_o is pulled into LDS while attention runs; the output is one
+// partial vector per kv head
 bool attn_oproj_plan(int64_t H, int64_t Hkv, int64_t d, int64_t h, int nsplit, int cus, int *n_blocks, int *rows_attn,
                      int *rows_other, size_t *lds_bytes);
 int launch_attn_oproj(Launcher &L, const void *q, const void *k_cache, const void *v_cache_T, const StepState *st,
-                      StepState *st_rw, const AttnScratch &sc, void *ao, unsigned *heads_done, const void *Wo,
-                      float *delta, int64_t H, int64_t Hkv, int64_t d, int64_t h, int64_t seq_alloc, float scale);
+                      StepState *st_rw, float *partials /* [H][nsplit][d + 4] */, unsigned *done /* [Hkv] words of this layer */,
+                      int nsplit, int attn_waves /* 1..8: 32 keys each per split and step */, int64_t kv_len_hint, const void *Wo, float *slabs /* [Hkv][h] */, int64_t H, int64_t Hkv, int64_t d,
+                      int64_t h, int64_t seq_alloc, float scale);
 
 // ---- weight conversion at model build ---------------------------------------------------------
 // dst[row_map(r)][c] = cvt(src[r0+r][c0+c]); row_mode 0: dst_row0+r, 1: gate rows, 2: up rows

@@ -101,7 +101,7 @@ struct Model {
     uint32_t *host_tokens = nullptr;
     bool use_graph = true;
     bool fused_decode = true;    // norm / RoPE / KV-append fused into the GEMV kernels
-    bool fuse_oproj = true;      // decode attention + o_proj in one launch (k_attn_oproj.hip)
+    int fuse_oproj = 0;          // decode attention + o_proj in one launch (k_attn_oproj.hip): 0 never (default), 1 wherever it fits, -1 where it pays most
     StepState *host_state = nullptr;   // pinned: device step state read back for the error word
     std::vector<ProfRecord> prof;
     bool profiling = false;
@@ -118,7 +118,8 @@ struct CacheShard {
     uint32_t *out_tokens = nullptr;
     float *part_m = nullptr, *part_l = nullptr, *part_o = nullptr;
     unsigned *counters = nullptr;        // split-S arrival tickets, [Hkvs * q-groups]
-    unsigned *heads_done = nullptr;      // [L] fused attention+o_proj: kv heads published since set_state
+    unsigned *heads_done = nullptr;      // [L][Hkv] fused attention+o_proj: split partials published per kv head since set_state
+    float *ao_part = nullptr;            // ... and the partials: [Hs][ao_nsplit][d + 4] (o, m, l)
     hipGraphExec_t graph = nullptr;
     std::vector<void *> allocs;
 };
@@ -131,6 +132,7 @@ struct Cache {
     size_t seq_alloc = 0;        // max_seq rounded up to 32: row stride of K / column stride of V^T
     bool v_transposed = false;   // bf16 MFMA attention: value cache stored [Hkvs][d][seq_alloc]
     bool fuse_oproj = false;     // this cache's decode steps use the fused attention+o_proj launch
+    int ao_nsplit = 0, ao_waves = 4;   // ... with this many key splits per kv head, 32 * ao_waves keys per split and step
     int nsplit = 1;
     int warm_steps = 0;          // eager decode steps done (graph is captured after the first)
     bool graph_failed = false;

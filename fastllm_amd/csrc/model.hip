@@ -377,7 +377,8 @@ static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T, std::vecto
     sc.cap_T = T;
     FL_TRY(dev_alloc(own, (void **)&sc.x_res, (size_t)T * D.h * 4, acct));
     if (T == 1) FL_TRY(dev_alloc(own, (void **)&sc.x_res2, (size_t)D.h * 4, acct));
-    FL_TRY(dev_alloc(own, (void **)&sc.delta, (size_t)slab_rows(T, ksplit_cap) * D.h * 4, acct));   // split-K slabs of any prompt <= T
+    // split-K slabs of any prompt <= T; decode: one partial vector per kv head (fused attention + o_proj launch)
+    FL_TRY(dev_alloc(own, (void **)&sc.delta, (size_t)std::max<int64_t>(slab_rows(T, ksplit_cap), T == 1 ? sh.Hkvs : 0) * D.h * 4, acct));
     FL_TRY(dev_alloc(own, &sc.xn, (size_t)T * D.h * es, acct));
     FL_TRY(dev_alloc(own, (void **)&sc.inv_rms, (size_t)T * 4, acct));
     if (T >= 256) FL_TRY(dev_alloc(own, (void **)&sc.rs_part, (size_t)T * gemm_resid_partials(D.h) * 4, acct));
@@ -500,7 +501,7 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
     FL_HIP(hipHostMalloc((void **)&m->host_logits, (size_t)D.V * 4, hipHostMallocDefault));
     FL_HIP(hipHostMalloc((void **)&m->host_tokens, kOutTokensCap * 4, hipHostMallocDefault));
     FL_HIP(hipHostMalloc((void **)&m->host_state, sizeof(StepState), hipHostMallocDefault));
-    m->fuse_oproj = env_int("FL_FUSE_OPROJ", 0) != 0;    // measured slower than two launches (profiles/r01/README.md)
+    m->fuse_oproj = env_int("FL_FUSE_OPROJ", 0);          // 0.0-1.5 % at best (profiles/r02/README.md): off unless asked for; -1 = where it pays most
 
     // communicators
     if (tp > 1 && P.mode == FL_TP_SINGLE_PROCESS) {
@@ -600,13 +601,24 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
     {   // decode attention + o_proj in one launch when W_o's per-CU slice fits in LDS next to the attention state
         hipDeviceProp_t prop;
         FL_HIP(hipGetDeviceProperties(&prop, m->shards[0].device));
-        // the fused launch runs 8-wave attention workgroups: 256 keys per workgroup step
-        int ns8 = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)((max_seq + 255) / 256), 64));
-        if (max_seq * (size_t)D.d * 4 <= 96 * 1024) ns8 = 1;
-        int nb, ra, ro; size_t lds;
-        c->fuse_oproj = m->fuse_oproj && m->fused_decode && c->v_transposed &&
-                        attn_oproj_plan(m->shards[0].Hs, m->shards[0].Hkvs, D.d, D.h, ns8, prop.multiProcessorCount, &nb, &ra, &ro, &lds);
-        if (c->fuse_oproj) c->nsplit = env_int("FL_ATTN_NSPLIT", ns8);
+        // the fused launch's attention workgroups take 32 keys per wave and step; of their eight waves as few take keys as
+        // keeps the splits few enough (a CU pulls only ~40 GB/s, so a split's K/V should stay small -- but every split
+        // is a workgroup that holds no rows of W_o, and the others' LDS is full at ~156 rows)
+        const int cus = prop.multiProcessorCount;
+        const int w0 = env_int("FL_AO_WAVES", 0);
+        c->fuse_oproj = false;
+        for (int aw = w0 > 0 ? std::min(w0, 8) : 4; aw <= (w0 > 0 ? std::min(w0, 8) : 8) && !c->fuse_oproj; aw++) {
+            const int ns8 = (int)std::max<int64_t>(1, (int64_t)((max_seq + 32 * aw - 1) / (32 * aw)));
+            int nb = 0, ra = 0, ro = 0; size_t lds;
+            const bool fits = m->fused_decode && c->v_transposed && m->tp == 1 && m->shards.size() == 1 && !m->shards[0].comm &&
+                              attn_oproj_plan(m->shards[0].Hs, m->shards[0].Hkvs, D.d, D.h, ns8, cus, &nb, &ra, &ro, &lds);
+            // where it pays (profiles/r02/README.md): the workgroups of a kv head are the 32 of one XCD (8 kv heads on 256 CUs)
+            // and the attention workgroups own next to no rows, i.e. short contexts of Mistral-like shapes; TinyLlama / Qwen2
+            // (4 kv heads: groups of 64 over two XCDs) and long contexts are faster as two launches
+            const bool pays = fits && cus / m->shards[0].Hkvs <= 32 && ra <= 16;
+            c->fuse_oproj = m->fuse_oproj > 0 ? fits : (m->fuse_oproj < 0 ? pays : false);
+            c->ao_nsplit = ns8; c->ao_waves = aw;
+        }
     }
     c->shards.resize(m->shards.size());
     for (size_t i = 0; i < m->shards.size(); i++) {
@@ -628,8 +640,11 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.ss, sizeof(SampleState), nullptr));
         FL_HIP(hipMemsetAsync(cs.ss, 0, sizeof(SampleState), sh.stream));
         FL_TRY(dev_alloc(cs.allocs, (void **)&cs.sel_scratch, (size_t)D.V * 4, nullptr));
-        FL_TRY(dev_alloc(cs.allocs, (void **)&cs.heads_done, (size_t)D.L * 4, nullptr));
-        FL_HIP(hipMemsetAsync(cs.heads_done, 0, (size_t)D.L * 4, sh.stream));
+        if (c->fuse_oproj) {
+            FL_TRY(dev_alloc(cs.allocs, (void **)&cs.ao_part, (size_t)sh.Hs * c->ao_nsplit * (D.d + 4) * 4, nullptr));
+        }
+        FL_TRY(dev_alloc(cs.allocs, (void **)&cs.heads_done, (size_t)D.L * sh.Hkvs * 4, nullptr));
+        FL_HIP(hipMemsetAsync(cs.heads_done, 0, (size_t)D.L * sh.Hkvs * 4, sh.stream));
         FL_HIP(hipMemsetAsync(cs.st, 0, sizeof(StepState), sh.stream));
         FL_HIP(hipStreamSynchronize(sh.stream));
     }
@@ -777,8 +792,8 @@ static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
             FL_TRY(launch_gemv(L, dt, a));
             AttnScratch as{cs.part_m, cs.part_l, cs.part_o, cs.counters, c->nsplit, len_hint + 1};
             if (c->fuse_oproj) {
-                FL_TRY(launch_attn_oproj(L, sc.q, kc, vc, cs.st, cs.st, as, sc.ao, cs.heads_done + l, ly.wo, sc.delta, sh.Hs,
-                                         sh.Hkvs, D.d, D.h, (int64_t)c->seq_alloc, D.scale));
+                FL_TRY(launch_attn_oproj(L, sc.q, kc, vc, cs.st, cs.st, cs.ao_part, cs.heads_done + l * sh.Hkvs, c->ao_nsplit, c->ao_waves, len_hint + 1, ly.wo,
+                                         sc.delta, sh.Hs, sh.Hkvs, D.d, D.h, (int64_t)c->seq_alloc, D.scale));
             } else {
                 if (c->v_transposed) FL_TRY(launch_attn_decode_mfma(L, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->seq_alloc, D.scale));
                 else FL_TRY(launch_attn_decode(L, dt, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->seq_alloc, D.scale));
@@ -794,6 +809,7 @@ static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
             GemvArgs a;
             a.W = ly.wgu; a.out = sc.act; a.N = (int)(2 * sh.Ip); a.K = (int)D.h; a.epi = EPI_GATEUP; a.pro = PRO_NORM;
             a.x_in = sc.x_res2; a.delta = sc.delta; a.norm_w = ly.ln2; a.eps = D.eps; a.x_out = sc.x_res; a.st = c->shards[i].st;
+            if (c->fuse_oproj) a.delta_nslab = (int)sh.Hkvs;           // one partial vector per kv head
             FL_TRY(launch_gemv(L, dt, a));
             if (far) FL_TRY(row_parallel(L, sh, ly.wd, sc.act, sh.Ip, sc.delta, (int)(2 * l + 2)));
             else FL_TRY(launch_linear(L, dt, ly.wd, sc.act, nullptr, sc.delta, 1, D.h, sh.Ip, EPI_F32));
@@ -1025,7 +1041,7 @@ static int set_state(Model *m, Cache *c, uint32_t token, size_t pos, size_t len,
         Shard &sh = m->shards[i];
         FL_HIP(hipSetDevice(sh.device));
         hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(64), 0, sh.stream, c->shards[i].st, token, (uint32_t)pos,
-                           (uint32_t)len, (uint32_t)call0, step, (int32_t)eos, c->shards[i].heads_done, (int)m->D.L,
+                           (uint32_t)len, (uint32_t)call0, step, (int32_t)eos, c->shards[i].heads_done, (int)(m->D.L * sh.Hkvs),
                            c->shards[i].ss, sampler ? *sampler : SampleState{}, sampler ? 1 : 0);
         FL_HIP(hipGetLastError());
     }
@@ -1421,7 +1437,7 @@ int batch_decode(Batch *b, const uint32_t *first, const size_t *pos, size_t n_st
         for (int i = 0; i < B; i++) {
             Cache *c = b->caches[i];
             hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(64), 0, sh.stream, c->shards[0].st, tok[i], (uint32_t)(pos[i] + done),
-                               (uint32_t)(len0[i] + done), (uint32_t)(len0[i] + done), 0u, (int32_t)eos, c->shards[0].heads_done, (int)m->D.L,
+                               (uint32_t)(len0[i] + done), (uint32_t)(len0[i] + done), 0u, (int32_t)eos, c->shards[0].heads_done, (int)(m->D.L * sh.Hkvs),
                                c->shards[0].ss, sampler, done == 0 ? 1 : 0);
             FL_HIP(hipGetLastError());
         }
@@ -1469,7 +1485,7 @@ int batch_forward(Batch *b, const uint32_t *tokens, const size_t *pos, float *lo
     for (int i = 0; i < B; i++) {
         Cache *c = b->caches[i];
         hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(64), 0, sh.stream, c->shards[0].st, tokens[i], (uint32_t)pos[i], (uint32_t)c->len,
-                           (uint32_t)c->len, 0u, (int32_t)-1, c->shards[0].heads_done, (int)m->D.L, c->shards[0].ss, sampler, 1);
+                           (uint32_t)c->len, 0u, (int32_t)-1, c->shards[0].heads_done, (int)(m->D.L * sh.Hkvs), c->shards[0].ss, sampler, 1);
         FL_HIP(hipGetLastError());
     }
     FL_TRY(batch_step(b));

@@ -256,8 +256,9 @@ def test_decode_split_s_path(fa, name, dtype):
 
 @pytest.mark.parametrize("name", ["llama_a", "mistral_a", "qwen2_a"])
 def test_fused_attention_oproj_launch(fa, name, monkeypatch):
-    """FL_FUSE_OPROJ=1: decode attention + o_proj in one launch (W_o slice in LDS, heads-done word, bounded
-    poll) must give the two-launch result, also across many steps of one decode call and with split S."""
+    """FL_FUSE_OPROJ=1: decode attention + o_proj in one launch (W_o cut along K by kv head, slice in LDS, one word per
+    kv head, bounded poll, partial vectors summed by the next norm prologue) must give the two-launch result, also
+    across many steps of one decode call and with split S."""
     cfg = synth.CONFIGS[name]
     w = synth.synth_weights(cfg)
     ids = synth.prompt_ids(cfg, 12, seed=9)
@@ -269,7 +270,7 @@ def test_fused_attention_oproj_launch(fa, name, monkeypatch):
     want_toks = ref.decode_greedy(rc, tok, 12, 20)
     monkeypatch.setenv("FL_FUSE_OPROJ", "1")
     m = fa.Model(cfg, w, dtype="bf16")
-    c = m.new_cache(600)                       # 600 positions -> 3 attention splits of 256
+    c = m.new_cache(600)                       # 600 positions -> 5 attention splits of 128
     m.forward(c, ids[:10], 0)
     for i, wnt in zip((10, 11), want):
         check_logits(m.forward(c, ids[i:i + 1], i), wnt, "bf16", "fused attn+oproj step %d" % i)
@@ -277,6 +278,42 @@ def test_fused_attention_oproj_launch(fa, name, monkeypatch):
     assert len(got_toks) == 20
     same = int(np.argmin(np.concatenate([got_toks == want_toks, [False]])))
     assert same >= 10, (got_toks, want_toks)   # bf16 split-order noise may fork the two greedy runs late
+
+
+@pytest.mark.parametrize("cap", [600, 768, 1000])
+def test_fused_attention_oproj_mistral_width(fa, cap, monkeypatch):
+    """The fused launch (opt-in) at Mistral-7B's layer shape (8 kv heads: one group of 32 workgroups per head, ~150 rows
+    of W_o per workgroup in LDS).  FL_FUSE_OPROJ=-1 (the rule "where it pays most"): 600 positions = 5 splits, attention
+    workgroups without rows; 768 = 6 splits, 7 rows each; FL_FUSE_OPROJ=1 (wherever it fits): 1000 = 8 splits, 44 rows
+    each.  Against the two-launch path after a 300-token prefill, step by step and as one greedy decode call."""
+    cfg = synth.CONFIGS["mistral_wide"]
+    w = synth.synth_weights(cfg)
+    ids = synth.prompt_ids(cfg, 306, seed=21)
+    monkeypatch.setenv("FL_FUSE_OPROJ", "0")
+    ref = fa.Model(cfg, w, dtype="bf16")
+    rc = ref.new_cache(cap)
+    ref.forward(rc, ids[:300], 0)
+    want = [ref.forward(rc, ids[i:i + 1], i) for i in range(300, 306)]
+    tok = oracle.argmax(want[-1])
+    want_toks = ref.decode_greedy(rc, tok, 306, 24)
+    monkeypatch.setenv("FL_FUSE_OPROJ", "1" if cap > 768 else "-1")
+    m = fa.Model(cfg, w, dtype="bf16")
+    c = m.new_cache(cap)
+    m.forward(c, ids[:300], 0)
+    for i, wnt in zip(range(300, 306), want):
+        got = m.forward(c, ids[i:i + 1], i)
+        rel = np.linalg.norm(got - wnt) / np.linalg.norm(wnt)
+        assert rel < 1e-2, (i, rel)            # bf16 noise between two summation orders of o_proj (measured ~2e-3)
+        assert int(np.argmax(got)) == int(np.argmax(wnt))
+    got_toks = m.decode_greedy(c, tok, 306, 24)
+    assert len(got_toks) == 24
+    same = int(np.argmin(np.concatenate([got_toks == want_toks, [False]])))
+    assert same >= 8, (got_toks, want_toks)    # bf16 split-order noise may fork the two greedy runs late
+    # ... and it IS the fused launch that ran
+    m.profile_begin()
+    m.forward(c, ids[5:6], 330)
+    names = [k["name"] for k in m.profile_end()]
+    assert any("oproj" in n for n in names), names
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

@@ -1,7 +1,10 @@
 // Cost of an all-to-all hand-off between phases of one persistent launch on MI355X (256 workgroups, one per CU):
 // every workgroup writes its slice of a 16 KB vector, signals, waits for all, then reads the WHOLE vector.
 // Variants: (0) agent-scope release / acquire fences + relaxed counter;  (1) sc1 (write-through) stores, relaxed
-// counter, sc1 loads, no fences.  Prints microseconds per phase; compare with a kernel boundary (~3.5 us + ramp).
+// counter, sc1 loads, no fences;  (2) sc1 data + per-workgroup flags polled in parallel;  (3) / (4) the hand-off a
+// QKV + attention fusion would need: only the 32 workgroups that hold one kv head's rows exchange (768 floats, one
+// counter per group) -- (3) group = blockIdx % 8 (the workgroups the dispatcher places on one XCD), (4) group =
+// blockIdx / 32 (spread over all XCDs).  Prints microseconds per phase; compare with a kernel boundary (~3.5 us + ramp).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -24,6 +27,30 @@ __global__ __launch_bounds__(512) void handoff_kernel(float *vec /* 2 x 4096 */,
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (MODE >= 3) {
+            const int grp = MODE == 3 ? wg % 8 : wg / 32;
+            if (tid == 0) {
+                __hip_atomic_fetch_add(counters + (size_t)p * 8 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                long long t0 = wall_clock64();
+                while (__hip_atomic_load(counters + (size_t)p * 8 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 32u) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (wall_clock64() - t0 > 200000000LL) { *bad = 1; break; }
+                }
+            }
+            __syncthreads();
+            // consume: the group's 32 x 16 floats
+            if (tid < 512) {
+                const int m = tid >> 4, src = MODE == 3 ? m * 8 + grp : grp * 32 + m;
+                xs[tid] = __hip_atomic_load(cur + src * 16 + (tid & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            __syncthreads();
+            acc += xs[(tid * 7 + p) & 511];
+            const int me = MODE == 3 ? wg / 8 : wg % 32, oth = (me + 13) % 32, osrc = MODE == 3 ? oth * 8 + grp : grp * 32 + oth;
+            if (xs[me * 16] != (float)(p + 1) + 0.001f * (wg * 16)) *bad = 2;
+            if (xs[oth * 16 + 3] != (float)(p + 1) + 0.001f * (osrc * 16 + 3)) *bad = 3;
+            __syncthreads();
+            continue;
+        }
         if (MODE == 2) {
             // per-workgroup flags: no read-modify-write, every thread polls one producer's flag
             if (tid == 0) __hip_atomic_store(counters + (size_t)p * nwg + wg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -64,17 +91,19 @@ int main() {
     CHECK(hipMalloc(&vec, 2 * 4096 * 4)); CHECK(hipMalloc(&sink, nwg * 512 * 4));
     CHECK(hipMalloc(&cnt, (size_t)nphase * nwg * 4)); CHECK(hipMalloc(&bad, 4));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    for (int mode = 0; mode < 3; mode++) {
+    for (int mode = 0; mode < 5; mode++) {
         for (int rep = 0; rep < 3; rep++) {
             CHECK(hipMemset(cnt, 0, (size_t)nphase * nwg * 4)); CHECK(hipMemset(bad, 0, 4)); CHECK(hipMemset(vec, 0, 2 * 4096 * 4));
             CHECK(hipEventRecord(e0));
             if (mode == 0) hipLaunchKernelGGL(handoff_kernel<0>, dim3(nwg), dim3(512), 0, 0, vec, cnt, nphase, sink, bad);
             else if (mode == 1) hipLaunchKernelGGL(handoff_kernel<1>, dim3(nwg), dim3(512), 0, 0, vec, cnt, nphase, sink, bad);
-            else hipLaunchKernelGGL(handoff_kernel<2>, dim3(nwg), dim3(512), 0, 0, vec, cnt, nphase, sink, bad);
+            else if (mode == 2) hipLaunchKernelGGL(handoff_kernel<2>, dim3(nwg), dim3(512), 0, 0, vec, cnt, nphase, sink, bad);
+            else if (mode == 3) hipLaunchKernelGGL(handoff_kernel<3>, dim3(nwg), dim3(512), 0, 0, vec, cnt, nphase, sink, bad);
+            else hipLaunchKernelGGL(handoff_kernel<4>, dim3(nwg), dim3(512), 0, 0, vec, cnt, nphase, sink, bad);
             CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
             unsigned b; CHECK(hipMemcpy(&b, bad, 4, hipMemcpyDeviceToHost));
-            printf("mode %d (%s): %.3f us per phase  bad=%u\n", mode, mode == 2 ? "sc1 data + per-workgroup flags, parallel poll" : mode ? "sc1 stores/loads, no fences" : "release/acquire fences", ms * 1e3 / nphase, b);
+            printf("mode %d (%s): %.3f us per phase  bad=%u\n", mode, mode == 4 ? "groups of 32 by blockIdx / 32" : mode == 3 ? "groups of 32 by blockIdx % 8 (one XCD)" : mode == 2 ? "sc1 data + per-workgroup flags, parallel poll" : mode ? "sc1 stores/loads, no fences" : "release/acquire fences", ms * 1e3 / nphase, b);
         }
     }
     // reference: empty kernel boundaries
