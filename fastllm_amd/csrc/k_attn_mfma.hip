@@ -82,16 +82,24 @@ __device__ __forceinline__ void attn_decode_mfma_body(const bf16_t *__restrict__
     KregVglobal ra, rb;
     ra.vT = rb.vT = vb; ra.ldv = rb.ldv = seq_alloc; ra.i = rb.i = i; ra.g4 = rb.g4 = g4;
     int kbase = lo + 32 * wave;
-    if (kbase < hi) ra.load_k(kb, kbase, i, g4);
-    while (kbase < hi) {
+    if (kbase < hi) {
+        // the FIRST tile's K and V^T fragments are requested together (one round trip instead of two): at the context
+        // lengths where a wave has a single tile (S <= 128 * nsplit) that is the whole chain
+        RegKV<D> r0;
+        r0.load(kb, vb, seq_alloc, kbase, i, g4);
         if (kbase + STEP < hi) rb.load_k(kb, kbase + STEP, i, g4);
-        ra.kbase = kbase;
-        attn_tile<D>(s, qf, ra, kbase, 0, lo, hi, scale, lane);
+        attn_tile<D>(s, qf, r0, kbase, 0, lo, hi, scale, lane);
         kbase += STEP;
-        if (kbase >= hi) break;
+    }
+    while (kbase < hi) {
         if (kbase + STEP < hi) ra.load_k(kb, kbase + STEP, i, g4);
         rb.kbase = kbase;
         attn_tile<D>(s, qf, rb, kbase, 0, lo, hi, scale, lane);
+        kbase += STEP;
+        if (kbase >= hi) break;
+        if (kbase + STEP < hi) rb.load_k(kb, kbase + STEP, i, g4);
+        ra.kbase = kbase;
+        attn_tile<D>(s, qf, ra, kbase, 0, lo, hi, scale, lane);
         kbase += STEP;
     }
     }
