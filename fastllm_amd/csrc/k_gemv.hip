@@ -41,6 +41,16 @@ constexpr int kMaxDevices = 64;
 
 template <typename WT> struct RawChunk { uint4v v[sizeof(WT) == 2 ? 1 : 2]; };
 
+#ifndef FL_GEMV_DOT2
+#define FL_GEMV_DOT2 1
+#endif
+constexpr bool kGemvDot2 = FL_GEMV_DOT2 != 0;
+// acc += a.lo * b.lo + a.hi * b.hi on packed bf16 pairs (gfx950 VOP2; hipcc has no selectable builtin for it)
+__device__ inline float dot2c_bf16(unsigned a, unsigned b, float acc) {
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+    return acc;
+}
+
 __device__ inline void load_raw_nt(const bf16_t *p, RawChunk<bf16_t> &r) {
     r.v[0] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(p));
 }
@@ -268,14 +278,24 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
     auto fma_block = [&](const Buf &buf, int c0) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            float xv[8];
-            load8(xs + (c0 + 64 * u) * 8, xv);
+            if constexpr (kGemvDot2 && sizeof(WT) == 2 && sizeof(XT) == 2) {
+                // bf16 x bf16: four v_dot2c_f32_bf16 per 16 bytes of weights (exact products, fp32 accumulate) instead of eight
+                // unpacks + eight FMAs -- the wave is back at its loads sooner
+                const uint4v xr = *reinterpret_cast<const uint4v *>(xs + (c0 + 64 * u) * 8);
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                float wv[8];
-                unpack_raw(buf[r][u], wv);
+                for (int r = 0; r < R; r++)
 #pragma unroll
-                for (int j = 0; j < 8; j++) acc[r] = fmaf(wv[j], xv[j], acc[r]);
+                    for (int j = 0; j < 4; j++) acc[r] = dot2c_bf16(buf[r][u].v[0][j], xr[j], acc[r]);
+            } else {
+                float xv[8];
+                load8(xs + (c0 + 64 * u) * 8, xv);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    float wv[8];
+                    unpack_raw(buf[r][u], wv);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[r] = fmaf(wv[j], xv[j], acc[r]);
+                }
             }
         }
     };
@@ -474,8 +494,14 @@ static int launch_gemv_ru(Launcher &L, const GemvArgs &a) {
     // default (no FL_GEMV_U / fl_tune): four 1-KiB chunks in flight per row, two for the plain and RoPE epilogues at
     // K <= 4096 (Mistral-7B: o_proj 7.96 -> 7.48 us, lm_head 43.8 -> 42.0, QKV 11.95 -> 11.82; down_proj at K = 14336
     // 19.9 vs 20.9 and gate/up 38.2 vs 38.1 stay on four)
-    if (U <= 0) U = (a.epi != EPI_GATEUP && a.K > 2560 && a.K <= 4096) ? 2 : 4;     // (TinyLlama's K = 2048: four is 1 % better)
+    if (U <= 0) {
+        U = (a.epi != EPI_GATEUP && a.K > 2560 && a.K <= 4096) ? 2 : 4;             // (TinyLlama's K = 2048: four is 1 % better)
+        // the QKV projection is short enough for every wave to own ONE row group: with U = K / 512 its whole share is one block,
+        // requested before the norm prologue runs (the SMALL form): Mistral-7B 11.8 -> 10.5 us
+        if (R == 2 && a.epi == EPI_QKV_ROPE && a.pro == PRO_NORM && (a.K == 4096 || a.K == 3584)) U = a.K / 512;
+    }
     if (R == 4 && U == 2) return launch_gemv_t<WT, XT, 4, 2, PRO>(L, a);
+    if (R == 2 && U == 7) return launch_gemv_t<WT, XT, 2, 7, PRO>(L, a);
     if (R == 2 && U == 8) return launch_gemv_t<WT, XT, 2, 8, PRO>(L, a);
     if (R == 2 && U == 2) return launch_gemv_t<WT, XT, 2, 2, PRO>(L, a);
     return launch_gemv_t<WT, XT, 2, 4, PRO>(L, a);
