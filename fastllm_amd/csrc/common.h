@@ -135,4 +135,15 @@ struct SampleState {
     uint32_t key[8];
 };
 
+// acc += a.lo * b.lo + a.hi * b.hi on packed bf16 pairs (gfx950 VOP2; hipcc has no selectable builtin for it)
+__device__ inline float dot2c_bf16(unsigned a, unsigned b, float acc) {
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+    return acc;
+}
+// gfx940+: a VALU instruction that is not the same dot may read a dot's result only three wait states later (the next
+// dot accumulates into it without any).  hipcc inserts such nops for its own instructions but cannot see into inline
+// asm, so every run of dots ends with this (found as wrong sums of the LAST row of a block whose dots ran straight
+// into the wave reduction).
+__device__ inline void dot2c_settle(float &acc) { asm volatile("s_nop 2" : "+v"(acc)); }
+
 }  // namespace fl

@@ -45,11 +45,10 @@ template <typename WT> struct RawChunk { uint4v v[sizeof(WT) == 2 ? 1 : 2]; };
 #define FL_GEMV_DOT2 1
 #endif
 constexpr bool kGemvDot2 = FL_GEMV_DOT2 != 0;
-// acc += a.lo * b.lo + a.hi * b.hi on packed bf16 pairs (gfx950 VOP2; hipcc has no selectable builtin for it)
-__device__ inline float dot2c_bf16(unsigned a, unsigned b, float acc) {
-    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
-    return acc;
-}
+#ifndef FL_GEMV_PIPE
+#define FL_GEMV_PIPE 1
+#endif
+constexpr bool kGemvPipe = FL_GEMV_PIPE != 0 && kGemvDot2;
 
 __device__ inline void load_raw_nt(const bf16_t *p, RawChunk<bf16_t> &r) {
     r.v[0] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(p));
@@ -96,7 +95,30 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
     bool have_pre[NPRE];
 #pragma unroll
     for (int i = 0; i < NPRE; i++) have_pre[i] = gw < ngroups && lane + 64 * (U * (i + 1) - 1) < nchunk;
+    // PIPE (bf16, every launch that is not SMALL): the wave's (row group, K block) items form ONE stream, requested a block
+    // ahead into two register buffers -- while a block is multiplied the next one is in flight, also across row groups and
+    // their epilogues.  Every load of the stream is unconditional (no control flow around loads: hipcc then keeps COUNTED
+    // vmcnt waits): past the end of K a lane re-reads the last chunk (its x is zeroed); the last one or two items are
+    // peeled off the loop, so that the loop itself never requests past the wave's last item.
+    constexpr bool PIPE = kGemvPipe && !SMALL && sizeof(WT) == 2 && sizeof(XT) == 2;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);                       // wave-uniform copies for the stream's bookkeeping
+    const int gw_u = blockIdx.x * nwv + wave_u;
+    const int nb = (nchunk + 64 * U - 1) / (64 * U);                                // K blocks per row group (the last may be partial)
+    const int n_items = gw_u < ngroups ? (ngroups - gw_u + nw - 1) / nw * nb : 0;  // this wave's items
+    int lg = gw_u, lb = 0;                                                          // load stream: next item = (row group, block)
+    auto load_next = [&](Buf &buf) {
+        const int g = min(lg, ngroups - 1);                                         // (a wave without work reads the last group's first block once)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int row = row_of(g, r);
+            const WT *wr = W + (size_t)(row < N ? row : N - 1) * K;
+#pragma unroll
+            for (int u = 0; u < U; u++) load_raw_nt(wr + (size_t)min(lane + 64 * (U * lb + u), nchunk - 1) * 8, buf[r][u]);
+        }
+        if (++lb == nb) { lb = 0; lg += nw; }
+    };
     auto prefetch = [&]() {
+        if constexpr (PIPE) { load_next(pre[0]); return; }
 #pragma unroll
         for (int i = 0; i < NPRE; i++) {
             if (!have_pre[i]) continue;
@@ -298,6 +320,10 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
                 }
             }
         }
+        if constexpr (kGemvDot2 && sizeof(WT) == 2 && sizeof(XT) == 2) {
+#pragma unroll
+            for (int r = 0; r < R; r++) dot2c_settle(acc[r]);
+        }
     };
 
     if constexpr (SMALL) {
@@ -307,6 +333,43 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
                 if (have_pre[i]) fma_block(pre[i], lane + 64 * U * i);
             finish_group(gw);
         }
+        return;
+    }
+    if constexpr (PIPE) {
+        int cg = gw_u, cb = 0;                                                      // consume stream
+        const bool ragged = nchunk % (64 * U) != 0;
+        auto consume = [&](const Buf &buf) {
+            if (epi == EPI_QKV_ROPE && cb == 0 && cg != gw_u) rope_prefetch(cg);
+            const int c0 = lane + 64 * U * cb;
+            if (ragged && cb == nb - 1) {                                           // wave-uniform: the partial last block of K
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int ci = c0 + 64 * u;
+                    uint4v xr = *reinterpret_cast<const uint4v *>(xs + min(ci, nchunk - 1) * 8);
+                    if (ci >= nchunk) xr = uint4v{0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) acc[r] = dot2c_bf16(buf[r][u].v[0][j], xr[j], acc[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++) dot2c_settle(acc[r]);
+            } else {
+                fma_block(buf, c0);
+            }
+            if (++cb == nb) { finish_group(cg); cb = 0; cg += nw; }
+        };
+        Buf nxt;
+        int t = 0;
+#pragma nounroll
+        for (; t + 2 < n_items; t += 2) {
+            load_next(nxt);
+            consume(pre[0]);
+            load_next(pre[0]);
+            consume(nxt);
+        }
+        if (n_items - t == 2) { load_next(nxt); consume(pre[0]); consume(nxt); }
+        else if (n_items - t == 1) consume(pre[0]);
         return;
     }
 #pragma nounroll
@@ -495,7 +558,10 @@ static int launch_gemv_ru(Launcher &L, const GemvArgs &a) {
     // K <= 4096 (Mistral-7B: o_proj 7.96 -> 7.48 us, lm_head 43.8 -> 42.0, QKV 11.95 -> 11.82; down_proj at K = 14336
     // 19.9 vs 20.9 and gate/up 38.2 vs 38.1 stay on four)
     if (U <= 0) {
-        U = (a.epi != EPI_GATEUP && a.K > 2560 && a.K <= 4096) ? 2 : 4;             // (TinyLlama's K = 2048: four is 1 % better)
+        U = (a.epi != EPI_GATEUP && a.K > 2560 && a.K <= 4096) ? 2 : 4;             // fp32 weights (TinyLlama's K = 2048: four is 1 % better)
+        // bf16 (two register buffers of the stream, dot2 arithmetic: 152-166 VGPRs at U = 8, no spills): 8 KiB per row group
+        // and request round from K = 4096 (Mistral-7B: down_proj 19.9 -> 19.05 us, the others equal or better), 4 below
+        if (sizeof(WT) == 2) U = (a.K >> 3) >= 512 ? 8 : 4;
         // the QKV projection is short enough for every wave to own ONE row group: with U = K / 512 its whole share is one block,
         // requested before the norm prologue runs (the SMALL form): Mistral-7B 11.8 -> 10.5 us
         if (R == 2 && a.epi == EPI_QKV_ROPE && a.pro == PRO_NORM && (a.K == 4096 || a.K == 3584)) U = a.K / 512;

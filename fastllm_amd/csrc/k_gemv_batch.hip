@@ -151,22 +151,22 @@ __global__ __launch_bounds__(kBThreads) void gemv_batch_kernel(const GemvBatchAr
 #pragma unroll
         for (int b = 0; b < NB; b++) acc[r][b] = 0.f;
 
-    auto fma_block = [&](const Buf &buf, int c0) {
+    auto fma_block = [&](const Buf &buf, int c0) {                     // bf16 x bf16 on v_dot2c_f32_bf16, as the single-sequence GEMV
 #pragma unroll
         for (int u = 0; u < kBU; u++) {
-            float wv[kBR][8];
-#pragma unroll
-            for (int r = 0; r < kBR; r++) unpack8(buf[r][u], wv[r]);
 #pragma unroll
             for (int b = 0; b < NB; b++) {
-                float xv[8];
-                load8(xs + (size_t)b * Ks + (size_t)(c0 + 64 * u) * 8, xv);
+                const uint4v xr = *reinterpret_cast<const uint4v *>(xs + (size_t)b * Ks + (size_t)(c0 + 64 * u) * 8);
 #pragma unroll
                 for (int r = 0; r < kBR; r++)
 #pragma unroll
-                    for (int j = 0; j < 8; j++) acc[r][b] = fmaf(wv[r][j], xv[j], acc[r][b]);
+                    for (int j = 0; j < 4; j++) acc[r][b] = dot2c_bf16(buf[r][u][j], xr[j], acc[r][b]);
             }
         }
+#pragma unroll
+        for (int r = 0; r < kBR; r++)
+#pragma unroll
+            for (int b = 0; b < NB; b++) dot2c_settle(acc[r][b]);
     };
     auto finish_group = [&](int g) {
         float sum[kBR][NB];
@@ -243,18 +243,21 @@ __global__ __launch_bounds__(kBThreads) void gemv_batch_kernel(const GemvBatchAr
         }
 #pragma nounroll
         for (; c0 < nchunk; c0 += 64) {                                 // K tail, one chunk at a time
-            float wv[kBR][8];
+            uint4v wr[kBR];
 #pragma unroll
-            for (int r = 0; r < kBR; r++) load8_nt(wp[r] + (size_t)c0 * 8, wv[r]);
+            for (int r = 0; r < kBR; r++) wr[r] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(wp[r] + (size_t)c0 * 8));
 #pragma unroll
             for (int b = 0; b < NB; b++) {
-                float xv[8];
-                load8(xs + (size_t)b * Ks + (size_t)c0 * 8, xv);
+                const uint4v xr = *reinterpret_cast<const uint4v *>(xs + (size_t)b * Ks + (size_t)c0 * 8);
 #pragma unroll
                 for (int r = 0; r < kBR; r++)
 #pragma unroll
-                    for (int j = 0; j < 8; j++) acc[r][b] = fmaf(wv[r][j], xv[j], acc[r][b]);
+                    for (int j = 0; j < 4; j++) acc[r][b] = dot2c_bf16(wr[r][j], xr[j], acc[r][b]);
             }
+#pragma unroll
+            for (int r = 0; r < kBR; r++)
+#pragma unroll
+                for (int b = 0; b < NB; b++) dot2c_settle(acc[r][b]);
         }
         finish_group(g);
     }
