@@ -106,39 +106,63 @@ __device__ __forceinline__ bool decode_tail(float *lds, int *is_last, int G, int
     }
     __syncthreads();
     if (!*is_last) return false;
-    // last arriver: stage the (m, l) of all splits in LDS, then combine the o slabs in parallel
-    float *lm = lds, *ll = lds + GMAX * nsplit;                       // 2 * GMAX * nsplit floats (nsplit <= 64)
-    for (int e = threadIdx.x; e < G * nsplit; e += NW * 64) {
-        const int g = e / nsplit, sp = e % nsplit;
-        const size_t idx = (size_t)(hq0 + g) * nsplit + sp;
-        lm[g * nsplit + sp] = part_m[idx]; ll[g * nsplit + sp] = part_l[idx];
-    }
-    __syncthreads();
-    // Long contexts have up to 64 splits and every partial o row is one dependent trip to L2: a thread that walks
-    // them four at a time spends ~0.5 us per split (S = 16 384: 43 us per layer, three quarters of it here).  So the
-    // (head, 4-d) slots are spread over ALL threads -- `parts` threads per slot take the splits round-robin, eight
-    // loads in flight each -- and the parts meet in LDS.  Fixed order (part 0, 1, ...), so results stay reproducible.
+    // last arriver: the (m, l) of all splits go to LDS, the o slabs are combined in parallel.
+    // Long contexts have up to 64 splits and every partial o row is a trip to L2 / HBM.  The (head, 4-d) slots are spread
+    // over ALL threads -- `parts` threads per slot take the splits round-robin -- and the parts meet in LDS.  Fixed order
+    // (part 0, 1, ...), so results stay reproducible.  With at most eight splits per thread (the short contexts) they are
+    // requested at once, unconditionally (past the last split a thread re-reads the last one with weight 0) and BEFORE the
+    // (m, l) staging and its barrier: one round trip in all, where the remainder iterations of the streaming loop below wait
+    // for their loads one by one (7.65 -> 7.45 us at six splits).  Longer contexts keep that loop (hoisting their first
+    // eight loads cost Qwen2-7B at S = 4100 1.4 us per launch).
     const int slots = G * (D / 4), nthr = NW * 64;
     int parts = 1;
     while (parts * 2 * slots <= nthr && parts * 2 * 8 <= nsplit) parts *= 2;      // (a handful of splits: one pass, no LDS round)
-    float *red = ll + GMAX * nsplit;                                  // [parts][slots][5] floats behind lm / ll
     const int slot = threadIdx.x % slots, part = threadIdx.x / slots;
     const bool active = threadIdx.x < parts * slots;
     const int g = slot / (D / 4), j4 = (slot % (D / 4)) * 4;
+    const size_t hb = (size_t)(hq0 + g) * nsplit;
+    auto load_parts = [&](int s0, float4v (&o4)[8]) {
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            o4[u] = *reinterpret_cast<const float4v *>(part_o + (hb + min(s0 + u * parts, nsplit - 1)) * D + j4);
+    };
+    const bool one_batch = nsplit <= 8 * parts;                       // (the short-context case; longer ones keep the streaming loop)
+    float4v o4[8];
+    if (one_batch && active) load_parts(part, o4);
+    float *lm = lds, *ll = lds + GMAX * nsplit;                       // 2 * GMAX * nsplit floats (nsplit <= 64)
+    for (int e = threadIdx.x; e < G * nsplit; e += NW * 64) {
+        const int gg = e / nsplit, sp = e % nsplit;
+        const size_t idx = (size_t)(hq0 + gg) * nsplit + sp;
+        lm[gg * nsplit + sp] = part_m[idx]; ll[gg * nsplit + sp] = part_l[idx];
+    }
+    __syncthreads();
+    float *red = ll + GMAX * nsplit;                                  // [parts][slots][5] floats behind lm / ll
     float M = -INFINITY;
     if (active)
         for (int sp = 0; sp < nsplit; sp++) M = fmaxf(M, lm[g * nsplit + sp]);
     if (active) {
-        const size_t hb = (size_t)(hq0 + g) * nsplit;
         float L = 0.f, O[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int sp = part; sp < nsplit; sp += parts) {
-            const float mm = lm[g * nsplit + sp];
-            const float w = mm == -INFINITY ? 0.f : __expf(mm - M);
-            L = fmaf(ll[g * nsplit + sp], w, L);
-            const float4v o4 = *reinterpret_cast<const float4v *>(part_o + (hb + sp) * D + j4);
+        if (one_batch) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) O[j] = fmaf(o4[j], w, O[j]);
+            for (int u = 0; u < 8; u++) {
+                const int sp = part + u * parts;
+                const bool ok = sp < nsplit;
+                const float mm = lm[g * nsplit + (ok ? sp : 0)];
+                const float w = (!ok || mm == -INFINITY) ? 0.f : __expf(mm - M);
+                L = fmaf(ll[g * nsplit + (ok ? sp : 0)], w, L);
+#pragma unroll
+                for (int j = 0; j < 4; j++) O[j] = fmaf(o4[u][j], w, O[j]);
+            }
+        } else {
+#pragma unroll 8
+            for (int sp = part; sp < nsplit; sp += parts) {
+                const float mm = lm[g * nsplit + sp];
+                const float w = mm == -INFINITY ? 0.f : __expf(mm - M);
+                L = fmaf(ll[g * nsplit + sp], w, L);
+                const float4v o = *reinterpret_cast<const float4v *>(part_o + (hb + sp) * D + j4);
+#pragma unroll
+                for (int j = 0; j < 4; j++) O[j] = fmaf(o[j], w, O[j]);
+            }
         }
         if (parts > 1) {
             float *r = red + ((size_t)part * slots + slot) * 5;
