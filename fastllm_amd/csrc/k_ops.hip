@@ -330,21 +330,24 @@ int launch_rope_kv_batch(Launcher &L, const float *qkv, const SeqRef *seqs_dev, 
 __device__ inline int argmax_last(const float *__restrict__ logits, int V, float *bv, int *bi) {
     const int tid = threadIdx.x;
     float best = -INFINITY; int idx = -1;
-    int i = tid;
-    for (; i + 7 * 1024 < V; i += 8 * 1024) {          // 8 independent loads in flight
-        float v[8];
+    auto take = [&](float v, int ii) { if (idx < 0 || v > best || (v == best && ii > idx)) { best = v; idx = ii; } };
+    // 16 bytes per lane, eight loads per round trip, all unconditional (past the end a thread re-reads the last chunk and
+    // skips it): V = 32000 is ONE round trip.  (Scalar loads with a one-load-per-iteration remainder loop: eleven.)
+    const int nvec = (V % 4 == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) ? V / 4 : 0;
+    for (int c0 = tid; c0 < nvec; c0 += 8 * 1024) {
+        float4v v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = logits[i + u * 1024];
+        for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const float4v *>(logits + 4 * (size_t)min(c0 + u * 1024, nvec - 1));
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int ii = i + u * 1024;
-            if (idx < 0 || v[u] > best || (v[u] == best && ii > idx)) { best = v[u]; idx = ii; }
+            const int c = c0 + u * 1024;
+            if (c < nvec) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) take(v[u][j], 4 * c + j);
+            }
         }
     }
-    for (; i < V; i += 1024) {
-        float v = logits[i];
-        if (idx < 0 || v > best || (v == best && i > idx)) { best = v; idx = i; }
-    }
+    for (int i = 4 * nvec + tid; i < V; i += 1024) take(logits[i], i);      // (a vocabulary that is not a multiple of 4)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         float ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(idx, o, 64);

@@ -724,15 +724,12 @@ static int all_reduce_delta(Model *m, bool pre, int64_t count) {
     return FL_OK;
 }
 
+// where a shard's lm_head launch writes: its slice of a sharded vocabulary (gathered below), else the full logits at once
+// (a 128 KB device-to-device copy per decode step used to stand here)
+static float *lm_head_out(Model *m, Shard &sh) { return m->vocab_parallel ? sh.logits_local : sh.logits_full; }
+
 static int gather_logits(Model *m) {
-    const Dims &D = m->D;
-    if (!m->vocab_parallel) {
-        for (auto &sh : m->shards) {
-            FL_HIP(hipSetDevice(sh.device));
-            FL_HIP(hipMemcpyAsync(sh.logits_full, sh.logits_local, (size_t)D.V * 4, hipMemcpyDeviceToDevice, sh.stream));
-        }
-        return FL_OK;
-    }
+    if (!m->vocab_parallel) return FL_OK;
     if (m->tp_mode == FL_TP_EMULATED) {
         Shard &s0 = m->shards[0];
         FL_HIP(hipSetDevice(s0.device));
@@ -821,7 +818,7 @@ static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
         FL_HIP(hipSetDevice(sh.device));
         Launcher L = make_launcher(m, sh);
         GemvArgs a;
-        a.W = sh.lm_head; a.out = sh.logits_local; a.N = (int)sh.Vs; a.K = (int)D.h; a.epi = EPI_F32; a.pro = PRO_NORM;
+        a.W = sh.lm_head; a.out = lm_head_out(m, sh); a.N = (int)sh.Vs; a.K = (int)D.h; a.epi = EPI_F32; a.pro = PRO_NORM;
         a.x_in = sc.x_res; a.delta = sc.delta; a.norm_w = sh.norm; a.eps = D.eps; a.st = c->shards[i].st;
         FL_TRY(launch_gemv(L, dt, a));
     }
@@ -930,7 +927,7 @@ static int enqueue_prefill_tp_overlap(Model *m, Cache *c, int64_t T) {
         float *xl = sc.x_res + (size_t)(T - 1) * D.h, *dl = sc.delta + (size_t)(T - 1) * D.h;
         void *xnl = (char *)sc.xn + (size_t)(T - 1) * D.h * es;
         FL_TRY(launch_rmsnorm_add(L, dt, xl, dl, sh.norm, D.eps, xnl, sc.inv_rms + (T - 1), 1, D.h, 1, 0));
-        return launch_linear(L, dt, sh.lm_head, xnl, nullptr, sh.logits_local, 1, sh.Vs, D.h, EPI_F32, sc.inv_rms + (T - 1));
+        return launch_linear(L, dt, sh.lm_head, xnl, nullptr, lm_head_out(m, sh), 1, sh.Vs, D.h, EPI_F32, sc.inv_rms + (T - 1));
     }));
     FL_TRY(wait(G0, false));                                           // nothing of this call may still run on the side stream afterwards
     return gather_logits(m);
@@ -1027,7 +1024,7 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
         float *xl = sc.x_res + (size_t)(T - 1) * D.h, *dl = sc.delta + (size_t)(T - 1) * D.h;
         void *xnl = (char *)sc.xn + (size_t)(T - 1) * D.h * m->esize();
         if (!norm_done) FL_TRY(launch_rmsnorm_add(L, dt, xl, dl, sh.norm, D.eps, xnl, sc.inv_rms + (T - 1), 1, D.h, nslab, slab));
-        FL_TRY(launch_linear(L, dt, sh.lm_head, xnl, nullptr, sh.logits_local, 1, sh.Vs, D.h, EPI_F32, sc.inv_rms + (T - 1)));
+        FL_TRY(launch_linear(L, dt, sh.lm_head, xnl, nullptr, lm_head_out(m, sh), 1, sh.Vs, D.h, EPI_F32, sc.inv_rms + (T - 1)));
     }
     FL_TRY(gather_logits(m));
     return FL_OK;
