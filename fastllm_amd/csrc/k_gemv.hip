@@ -134,30 +134,27 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
     float inv_m = 1.0f;
     if constexpr (PRO == PRO_NORM) {
         constexpr int NCH = SMALL ? 1 : 3;           // nthr * NCH * 8 >= K (host-checked)
-        float v[NCH][8], wn[NCH][8];
+        float v[NCH][8], wn[NCH][8], dl[NCH][8];
         const WT *erow = nullptr;
         if (a.embed) erow = reinterpret_cast<const WT *>(a.embed) + (size_t)a.st->token * K;
 #pragma unroll
-        for (int i = 0; i < NCH; i++) {
-            const int c = tid + nthr * i;
+        for (int i = 0; i < NCH; i++) {                  // requests only: nothing here waits (an add of delta in this loop made the
+            const int c = tid + nthr * i;                //  weight stream below start a round trip late)
             if (c < nchunk) {
                 if (erow) load8(erow + c * 8, v[i]); else load8(a.x_in + c * 8, v[i]);
                 load8(a.norm_w + c * 8, wn[i]);
                 if (a.delta) {
-                    float dl[8];
-                    load8(a.delta + c * 8, dl);
-#pragma unroll
-                    for (int j = 0; j < 8; j++) v[i][j] += dl[j];
-                    for (int s0 = 1; s0 < a.delta_nslab; s0 += 7) {        // partial vectors of a K-sliced producer: up to seven per round trip, fixed order
-                        float ds[7][8];
-#pragma unroll
+                    load8(a.delta + c * 8, dl[i]);
+                    for (int s0 = 1; s0 < a.delta_nslab; s0 += 7) {        // partial vectors of a K-sliced producer (the opt-in fused attention
+                        float ds[7][8];                                     // + o_proj launch): up to seven per round trip, fixed order; this path
+#pragma unroll                                                              // does wait before the weights are requested
                         for (int u = 0; u < 7; u++)
                             if (s0 + u < a.delta_nslab) load8(a.delta + (size_t)(s0 + u) * K + c * 8, ds[u]);
 #pragma unroll
                         for (int u = 0; u < 7; u++)
                             if (s0 + u < a.delta_nslab) {
 #pragma unroll
-                                for (int j = 0; j < 8; j++) v[i][j] += ds[u][j];
+                                for (int j = 0; j < 8; j++) dl[i][j] += ds[u][j];
                             }
                     }
                 }
@@ -171,6 +168,10 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
         for (int i = 0; i < NCH; i++) {
             const int c = tid + nthr * i;
             if (c < nchunk) {
+                if (a.delta) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[i][j] += dl[i][j];
+                }
                 float o[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) { ss = fmaf(v[i][j], v[i][j], ss); o[j] = v[i][j] * wn[i][j]; }
