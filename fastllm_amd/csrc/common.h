@@ -146,4 +146,12 @@ __device__ inline float dot2c_bf16(unsigned a, unsigned b, float acc) {
 // into the wave reduction).
 __device__ inline void dot2c_settle(float &acc) { asm volatile("s_nop 2" : "+v"(acc)); }
 
+// rotate-half RoPE of one pair: separately rounded products, as candle's mul / sub / add kernels produce them -- and no
+// contraction into an FMA that a compiler picks one way in this build and another in the next (greedy token streams
+// differed between two builds whose only change was elsewhere in the kernel)
+__device__ inline void rope_rotate(float x0, float x1, float c, float s, float &t0, float &t1) {
+    t0 = __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, s));
+    t1 = __fadd_rn(__fmul_rn(x0, s), __fmul_rn(x1, c));
+}
+
 }  // namespace fl

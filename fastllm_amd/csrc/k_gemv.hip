@@ -226,7 +226,7 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
     // RoPE epilogue operands are requested up front (position from the step state, then this wave's cos/sin
     // pairs) so that their two dependent round trips overlap the weight stream instead of trailing it
     uint32_t rope_p = 0, rope_slot = 0;
-    float rope_c[R / 2], rope_s[R / 2];
+    float rope_c[R / 2], rope_s[R / 2], rope_b0[R / 2], rope_b1[R / 2];            // (bias of the pair's two rows: Qwen2)
     auto rope_prefetch = [&](int g) {
 #pragma unroll
         for (int r = 0; r < R; r += 2) {
@@ -235,6 +235,9 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
             const bool rot = hd < a.H + a.Hkv;
             rope_c[r >> 1] = rot ? a.cos_tab[(size_t)rope_p * half + j] : 1.f;
             rope_s[r >> 1] = rot ? a.sin_tab[(size_t)rope_p * half + j] : 0.f;
+            const int r0w = row_of(g, r), r1w = row_of(g, r + 1);
+            rope_b0[r >> 1] = a.bias && r1w < N ? a.bias[r0w] : 0.f;                // requested with the tables: in the epilogue it was a
+            rope_b1[r >> 1] = a.bias && r1w < N ? a.bias[r1w] : 0.f;                //  round trip at the very end of the launch
         }
     };
     if (epi == EPI_QKV_ROPE) {
@@ -267,17 +270,18 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
             const uint32_t slot = rope_slot;
 #pragma unroll
             for (int r = 0; r < R; r += 2) {
-                const int r0w = row_of(g, r), r1w = row_of(g, r + 1);
+                const int r1w = row_of(g, r + 1);
                 if (r1w >= N) continue;
                 const int q = g * (R / 2) + (r >> 1);
                 const int hd = q / half, j = q - hd * half;
                 float x0 = sum[r], x1 = sum[r + 1];
-                if (a.bias) { x0 += a.bias[r0w]; x1 += a.bias[r1w]; }
+                if (a.bias) { x0 += rope_b0[r >> 1]; x1 += rope_b1[r >> 1]; }
                 XT *dst;
                 size_t stride = 1;                                        // element stride between j and j+1
                 if (hd < a.H + a.Hkv) {                                   // rotate-half RoPE (App. A.4)
                     const float c = rope_c[r >> 1], s = rope_s[r >> 1];
-                    const float t0 = x0 * c - x1 * s, t1 = x0 * s + x1 * c;
+                    float t0, t1;
+                    rope_rotate(x0, x1, c, s, t0, t1);
                     x0 = t0; x1 = t1;
                     dst = hd < a.H ? reinterpret_cast<XT *>(a.q_out) + (size_t)hd * a.d
                                    : reinterpret_cast<XT *>(a.k_cache) + ((size_t)(hd - a.H) * a.max_seq + slot) * a.d;

@@ -200,7 +200,8 @@ __global__ __launch_bounds__(kBThreads) void gemv_batch_kernel(const GemvBatchAr
                 if (hd < a.H + a.Hkv) {                                       // rotate-half RoPE (App. A.4)
                     const uint32_t p = pos < (uint32_t)a.max_pos ? pos : (uint32_t)a.max_pos - 1;
                     const float c = a.cos_tab[(size_t)p * half + j], s = a.sin_tab[(size_t)p * half + j];
-                    const float t0 = x0 * c - x1 * s, t1 = x0 * s + x1 * c;
+                    float t0, t1;
+                    rope_rotate(x0, x1, c, s, t0, t1);
                     x0 = t0; x1 = t1;
                     dst = hd < a.H ? reinterpret_cast<bf16_t *>(a.q_out) + ((size_t)b * a.H + hd) * a.d
                                    : reinterpret_cast<bf16_t *>(sq.k) + a.kv_layer_off * sq.seq_alloc + ((size_t)(hd - a.H) * sq.seq_alloc + slot) * a.d;
@@ -433,7 +434,8 @@ __global__ __launch_bounds__(kBThreads) void gemv_batch_mfma_kernel(const GemvBa
                 if (hd < a.H + a.Hkv) {                                       // rotate-half RoPE (App. A.4)
                     const uint32_t p = pos < (uint32_t)a.max_pos ? pos : (uint32_t)a.max_pos - 1;
                     const float c = a.cos_tab[(size_t)p * half + j], sn = a.sin_tab[(size_t)p * half + j];
-                    const float t0 = x0 * c - x1 * sn, t1 = x0 * sn + x1 * c;
+                    float t0, t1;
+                    rope_rotate(x0, x1, c, sn, t0, t1);
                     x0 = t0; x1 = t1;
                     dst = hd < a.H ? reinterpret_cast<bf16_t *>(a.q_out) + ((size_t)n * a.H + hd) * a.d
                                    : reinterpret_cast<bf16_t *>(sq.k) + a.kv_layer_off * sq.seq_alloc + ((size_t)(hd - a.H) * sq.seq_alloc + slot) * a.d;

@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(const float *__restrict__ 
     if (hd < H + Hkv) {
         const uint32_t p = pos < (uint32_t)max_pos ? pos : (uint32_t)max_pos - 1;   // host validates range
         const float c = cos_tab[(size_t)p * half + j], s = sin_tab[(size_t)p * half + j];
-        const float ra = a * c - b * s, rb = a * s + b * c;
+        float ra, rb;
+        rope_rotate(a, b, c, s, ra, rb);
         if (hd < H) {
             CT *o = q_out + ((size_t)t * H + hd) * d;
             elem<CT>::st(o + j, ra); elem<CT>::st(o + j + half, rb);
@@ -302,7 +303,8 @@ __global__ __launch_bounds__(256) void rope_kv_batch_kernel(const float *__restr
     if (hd < H + Hkv) {
         const uint32_t p = pos < (uint32_t)max_pos ? pos : (uint32_t)max_pos - 1;
         const float c = cos_tab[(size_t)p * half + j], s = sin_tab[(size_t)p * half + j];
-        const float ra = a * c - bb * s, rb = a * s + bb * c;
+        float ra, rb;
+        rope_rotate(a, bb, c, s, ra, rb);
         bf16_t *o = hd < H ? q_out + ((size_t)b * H + hd) * d
                            : reinterpret_cast<bf16_t *>(sq.k) + kv_layer_off * sa + ((size_t)(hd - H) * sa + slot) * d;
         elem<bf16_t>::st(o + j, ra); elem<bf16_t>::st(o + j + half, rb);
