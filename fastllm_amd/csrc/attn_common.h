@@ -48,8 +48,7 @@ __device__ __forceinline__ void combine_lds(const float *lds, int g, int j4, flo
 // Tail of a decode-attention workgroup once its NW wave slabs are in LDS (and a barrier has passed).
 // nsplit == 1: normalise and write the output.  Otherwise publish this split's (m, l, o) slab and
 // let the workgroup that draws the last ticket of its (kv head, q-group) combine all splits:
-//   up to 8 splits in a launch of at most 64 workgroups:  plain stores -> per-wave vmcnt(0) -> barrier -> agent-scope release -> vmcnt(0) -> ticket;
-//   more splits:     write-through (sc1) stores -> per-wave vmcnt(0) -> barrier -> ticket   (no release: that fence
+//   publishers:      write-through (sc1) stores -> per-wave vmcnt(0) -> barrier -> ticket   (no release: that fence
 //                    writes back the XCD's whole L2, and hundreds of split workgroups each paid for one);
 //   last arriver:    agent-scope acquire -> barrier -> plain loads, splits spread over all threads
 // (cdna guide Guideline 16, counter form and R1 store forms; placement-independent).  The ticket word is reset by
@@ -70,7 +69,6 @@ __device__ __forceinline__ bool decode_tail(float *lds, int *is_last, int G, int
         }
         return true;
     }
-    const bool few = nsplit <= 8 && gridDim.x * gridDim.y * gridDim.z <= 64;      // (a batch launch has many publishers even with few splits each)
     for (int e = threadIdx.x; e < G * (D / 4); e += NW * 64) {
         const int g = e / (D / 4), j4 = (e % (D / 4)) * 4;
         float M, L, O[4];
@@ -78,22 +76,15 @@ __device__ __forceinline__ bool decode_tail(float *lds, int *is_last, int G, int
         const size_t idx = (size_t)(hq0 + g) * nsplit + split;
         // write-through (sc1) stores: no release fence is needed before the ticket (cdna guide Guideline 16, R1 store
         // forms).  The fence is a write-back of the XCD's whole L2; one per split workgroup made a long context's
-        // attention (512 workgroups at S = 16 384) wait on 512 of them.
-        if (few) {                                   // a handful of splits: plain stores + one release fence is the cheaper form
-            *reinterpret_cast<float4v *>(part_o + idx * D + j4) = float4v{O[0], O[1], O[2], O[3]};
-            if (j4 == 0) { part_m[idx] = M; part_l[idx] = L; }
-        } else {
-            st_sc1_x4(part_o + idx * D + j4, float4v{O[0], O[1], O[2], O[3]});
-            if (j4 == 0) { st_sc1(part_m + idx, M); st_sc1(part_l + idx, L); }
-        }
+        // attention (512 workgroups at S = 16 384) wait on 512 of them, and at a handful of splits -- where plain stores +
+        // one release fence used to measure faster -- the write-through form is ahead as well since the combine's loads are
+        // batched (7.3 -> 7.0 us at six splits).
+        st_sc1_x4(part_o + idx * D + j4, float4v{O[0], O[1], O[2], O[3]});
+        if (j4 == 0) { st_sc1(part_m + idx, M); st_sc1(part_l + idx, L); }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (few) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
         unsigned *cnt = counters + ticket_idx;
         const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = t == (unsigned)nsplit - 1;
