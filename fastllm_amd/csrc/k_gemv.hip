@@ -71,6 +71,8 @@ template <typename WT, typename XT, int R, int U, int PRO, int MAXT, bool SMALL,
 __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float red[kGemvMaxThreads / 64];
+    __shared__ float cv[kGemvMaxThreads / 64];       // ArgMax candidates of the waves (GemvArgs::amax)
+    __shared__ int ci[kGemvMaxThreads / 64];
     XT *xs = reinterpret_cast<XT *>(lds_raw);
     const WT *__restrict__ W = reinterpret_cast<const WT *>(a.W);
     const int N = a.N, K = a.K;
@@ -247,6 +249,7 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
         if (gw < ngroups) rope_prefetch(gw);
     }
 
+    float best_v = -INFINITY; int best_i = -1;                                      // running ArgMax of this wave's rows (lane 0)
     auto finish_group = [&](int g) {
         float sum[R];
 #pragma unroll
@@ -298,8 +301,26 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int row = row_of(g, r);
-                if (row < N) reinterpret_cast<float *>(a.out)[row] = sum[r] + (a.bias ? a.bias[row] : 0.f);
+                if (row < N) {
+                    const float y = sum[r] + (a.bias ? a.bias[row] : 0.f);
+                    reinterpret_cast<float *>(a.out)[row] = y;
+                    if (a.amax && (best_i < 0 || y > best_v || (y == best_v && row > best_i))) { best_v = y; best_i = row; }   // (lane 0; as argmax_last)
+                }
             }
+        }
+    };
+    // the workgroup's ArgMax candidate (EPI_F32 with GemvArgs::amax): lane 0 of every wave holds the best of its rows
+    auto leave_candidate = [&]() {
+        if constexpr (EPI != EPI_F32 || FUSE_AR) return;
+        if (!a.amax) return;                                                          // (kernel argument: uniform)
+        if (lane == 0) { cv[wave] = best_v; ci[wave] = best_i; }
+        __syncthreads();
+        if (tid == 0) {
+            float bv = cv[0]; int bi = ci[0];
+            for (int w = 1; w < nwv; w++)
+                if (ci[w] >= 0 && (bi < 0 || cv[w] > bv || (cv[w] == bv && ci[w] > bi))) { bv = cv[w]; bi = ci[w]; }
+            a.amax[1 + blockIdx.x] = ArgmaxCand{bv, bi};
+            if (blockIdx.x == 0) a.amax[0] = ArgmaxCand{0.f, (int)gridDim.x};
         }
     };
     auto fma_block = [&](const Buf &buf, int c0) {
@@ -338,6 +359,7 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
                 if (have_pre[i]) fma_block(pre[i], lane + 64 * U * i);
             finish_group(gw);
         }
+        leave_candidate();
         return;
     }
     if constexpr (PIPE) {
@@ -375,6 +397,7 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
         }
         if (n_items - t == 2) { load_next(nxt); consume(pre[0]); consume(nxt); }
         else if (n_items - t == 1) consume(pre[0]);
+        leave_candidate();
         return;
     }
 #pragma nounroll
@@ -456,6 +479,7 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
         }
         finish_group(g);
     }
+    leave_candidate();
 }
 
 static std::atomic<int> g_gemv_r{0}, g_gemv_u{0}, g_force_blocks{0}, g_force_waves{0};
@@ -545,6 +569,7 @@ static int launch_gemv_t(Launcher &L, const GemvArgs &a) {
     const int64_t ngroups = (N + R - 1) / R;
     int blocks = 1, waves = 4;
     pick_geometry(ngroups, lds, &blocks, &waves);
+    if (a.amax && blocks + 1 > kMaxArgmaxCand) FL_FAIL(FL_ERR_BAD_ARGUMENT, "launch_gemv: %d workgroups exceed the ArgMax candidate buffer", blocks);
     if (PRO == PRO_NORM && (int64_t)waves * 64 * 3 * 8 < K) waves = (int)((K + 64 * 3 * 8 - 1) / (64 * 3 * 8));   // staging capacity
     if (waves < 4) waves = 4;
     static const int allow_small = env_int("FL_GEMV_SMALL", 1);

@@ -327,6 +327,25 @@ int launch_rope_kv_batch(Launcher &L, const float *qkv, const SeqRef *seqs_dev, 
 // mod.rs:411-453 (token, pos, len, step, eos) is advanced so that a captured decode graph can be
 // replayed back to back with no host round trip.
 //
+// a workgroup's (value, index) pairs -> the ArgMax in thread 0 (ties -> the larger index; index < 0 = nothing)
+__device__ inline int argmax_reduce(float best, int idx, float *bv, int *bi) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(idx, o, 64);
+        if (oi >= 0 && (idx < 0 || ov > best || (ov == best && oi > idx))) { best = ov; idx = oi; }
+    }
+    if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; w++) {
+            float ov = bv[w]; int oi = bi[w];
+            if (oi >= 0 && (idx < 0 || ov > best || (ov == best && oi > idx))) { best = ov; idx = oi; }
+        }
+    }
+    return idx < 0 ? 0 : idx;                           // valid in thread 0
+}
+
 // ArgMax (temperature None or < 1e-7, App. A.7): iter().enumerate().max_by(total_cmp) -> on exact ties
 // the LAST maximal index wins.
 __device__ inline int argmax_last(const float *__restrict__ logits, int V, float *bv, int *bi) {
@@ -350,20 +369,16 @@ __device__ inline int argmax_last(const float *__restrict__ logits, int V, float
         }
     }
     for (int i = 4 * nvec + tid; i < V; i += 1024) take(logits[i], i);      // (a vocabulary that is not a multiple of 4)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        float ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(idx, o, 64);
-        if (oi >= 0 && (idx < 0 || ov > best || (ov == best && oi > idx))) { best = ov; idx = oi; }
-    }
-    if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 16; w++) {
-            float ov = bv[w]; int oi = bi[w];
-            if (oi >= 0 && (idx < 0 || ov > best || (ov == best && oi > idx))) { best = ov; idx = oi; }
-        }
-    }
-    return idx < 0 ? 0 : idx;                           // valid in thread 0
+    return argmax_reduce(best, idx, bv, bi);
+}
+
+// ArgMax over the candidates the lm_head launch left (GemvArgs::amax: one per workgroup, ties -> the larger index):
+// the same result as argmax_last over the logits they were taken from, without reading the vocabulary again
+__device__ inline int argmax_candidates(const ArgmaxCand *__restrict__ cand, float *bv, int *bi) {
+    const int n = cand[0].i, tid = threadIdx.x;
+    float best = -INFINITY; int idx = -1;
+    if (tid < n) { const ArgmaxCand c = cand[1 + tid]; best = c.v; idx = c.i; }
+    return argmax_reduce(best, idx, bv, bi);
 }
 
 // rand_chacha ChaCha12 block `counter` (64-bit block counter, stream id 0) of the stream keyed by `key`
@@ -701,12 +716,14 @@ __device__ inline int sample_all(const float *__restrict__ logits, int V, Sample
 
 __device__ __forceinline__ void select_advance_body(const float *__restrict__ logits, int V, StepState *__restrict__ st,
                                            SampleState *__restrict__ ss, float *__restrict__ scratch,
-                                           uint32_t *__restrict__ out_tokens, int advance, unsigned char *lds) {
+                                           uint32_t *__restrict__ out_tokens, int advance, unsigned char *lds,
+                                           const ArgmaxCand *__restrict__ cand = nullptr) {
     __shared__ float bv[16], bcast[2];
     __shared__ int bi[16], count;
     const int tid = threadIdx.x;
     int idx;
     if (ss->on) idx = sample_all(logits, V, ss, scratch, bv, lds, bcast, &count);
+    else if (cand) idx = argmax_candidates(cand, bv, bi);
     else idx = argmax_last(logits, V, bv, bi);
     if (tid == 0) {
         const uint32_t tok = (uint32_t)idx;
@@ -722,9 +739,9 @@ constexpr size_t kSelLds = sizeof(OrderedSumLds) > 2 * kSelTile * 4 ? sizeof(Ord
 __global__ __launch_bounds__(1024) void select_advance_kernel(const float *__restrict__ logits, int V,
                                                               StepState *__restrict__ st, SampleState *__restrict__ ss,
                                                               float *__restrict__ scratch, uint32_t *__restrict__ out_tokens,
-                                                              int advance) {
+                                                              int advance, const ArgmaxCand *__restrict__ cand) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kSelLds];
-    select_advance_body(logits, V, st, ss, scratch, out_tokens, advance, lds);
+    select_advance_body(logits, V, st, ss, scratch, out_tokens, advance, lds, cand);
 }
 
 // one workgroup per sequence of a batch: logits [B][V], state and scratch from the SeqRef
@@ -742,9 +759,9 @@ int launch_select_advance_batch(Launcher &L, const float *logits, int64_t V, con
 
 // scratch: V floats (probabilities / cumulative weights of the sampling path)
 int launch_select_advance(Launcher &L, const float *logits, int64_t V, StepState *st, SampleState *ss, float *scratch,
-                          uint32_t *out_tokens, int advance) {
+                          uint32_t *out_tokens, int advance, const ArgmaxCand *cand) {
     return L.launch(KC_ARGMAX, (double)V * 4, 0, select_advance_kernel, dim3(1), dim3(1024), 0, logits, (int)V, st, ss,
-                    scratch, out_tokens, advance);
+                    scratch, out_tokens, advance, cand);
 }
 
 // ------------------------------------------------------------------------------- local shard reduce

@@ -56,6 +56,9 @@ enum { PRO_X = 0, PRO_NORM = 1 };
 
 struct LLTable;
 // Arguments of the decode weight-streaming kernel (k_gemv.hip), passed by value as kernarg.
+struct ArgmaxCand { float v; int i; };   // [0]: {unused, count}; [1 + workgroup]: its best row
+constexpr int kMaxArgmaxCand = 1024;
+
 struct GemvArgs {
     const void *W = nullptr;        // [N,K] compute dtype
     const void *x = nullptr;        // PRO_X: [K] compute dtype
@@ -78,6 +81,10 @@ struct GemvArgs {
     // EPI_F32 of a row-parallel projection in a tensor-parallel group: out = sum over ranks, exchanged in the epilogue
     const LLTable *ll = nullptr;    // device-resident; null = plain local output
     int ll_slot = 0;                // 1 .. LLTable::slots: which all-reduce of the decode step this is
+    // EPI_F32 (the lm_head launch of a decode step): every workgroup also leaves the ArgMax of the rows it computed
+    // ((value, index) pairs; ties -> the larger index, as argmax_last), so that token selection reads gridDim.x candidates
+    // instead of the whole vocabulary; amax[0] is the candidate count.  null = not wanted.
+    ArgmaxCand *amax = nullptr;
 };
 int launch_gemv(Launcher &L, int dtype, const GemvArgs &a);
 bool gemv_norm_supported(int dtype, int64_t N, int64_t K);
@@ -185,7 +192,8 @@ int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st
 // logits[V] -> st->token by ArgMax (ties: last max index) or, when ss->on, by temperature sampling with
 // the seeded ChaCha12 stream; out_tokens[st->step] = token; advances pos/len/step
 int launch_select_advance(Launcher &L, const float *logits, int64_t V, StepState *st, SampleState *ss, float *scratch /* [V] */,
-                          uint32_t *out_tokens, int advance);
+                          uint32_t *out_tokens, int advance,
+                          const ArgmaxCand *cand = nullptr /* the lm_head launch's candidates: ArgMax without reading the vocabulary again */);
 // dst[i] = sum_s src[s][i] for n floats, written to every src (emulated all-reduce)
 int launch_reduce_shards(Launcher &L, float *const *bufs_dev, int nshards, int64_t n);
 

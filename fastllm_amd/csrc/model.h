@@ -79,6 +79,8 @@ struct Shard {
     float *cos_tab = nullptr, *sin_tab = nullptr;   // [max_pos][d/2]
     Scratch dec, pre;
     float *logits_local = nullptr;   // [Vs]
+    ArgmaxCand *amax = nullptr;      // [kMaxArgmaxCand] ArgMax candidates left by the decode step's lm_head launch (GemvArgs::amax)
+    bool amax_valid = false;         // ... and whether the forward enqueued last produced them (host-side, per enqueue)
     float *logits_full = nullptr;    // [V]
     std::vector<void *> allocs;
     std::vector<void *> pre_allocs;  // the prefill scratch set: replaced (and freed) when a longer prompt arrives

@@ -496,6 +496,7 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
         FL_TRY(alloc_scratch(m.get(), sh, sh.dec, 1));
         FL_TRY(dev_alloc(sh.allocs, (void **)&sh.logits_local, (size_t)sh.Vs * 4, &m->hbm_bytes));
         FL_TRY(dev_alloc(sh.allocs, (void **)&sh.logits_full, (size_t)D.V * 4, &m->hbm_bytes));
+        FL_TRY(dev_alloc(sh.allocs, (void **)&sh.amax, sizeof(ArgmaxCand) * kMaxArgmaxCand, &m->hbm_bytes));
     }
     FL_HIP(hipSetDevice(m->shards[0].device));
     FL_HIP(hipHostMalloc((void **)&m->host_logits, (size_t)D.V * 4, hipHostMallocDefault));
@@ -819,6 +820,7 @@ static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
         Launcher L = make_launcher(m, sh);
         GemvArgs a;
         a.W = sh.lm_head; a.out = lm_head_out(m, sh); a.N = (int)sh.Vs; a.K = (int)D.h; a.epi = EPI_F32; a.pro = PRO_NORM;
+        if (!m->vocab_parallel && env_int("FL_ARGMAX_FUSED", 1)) { a.amax = sh.amax; sh.amax_valid = true; }   // token selection reads one candidate per workgroup
         a.x_in = sc.x_res; a.delta = sc.delta; a.norm_w = sh.norm; a.eps = D.eps; a.st = c->shards[i].st;
         FL_TRY(launch_gemv(L, dt, a));
     }
@@ -936,6 +938,7 @@ static int enqueue_prefill_tp_overlap(Model *m, Cache *c, int64_t T) {
 // Enqueue one forward over T tokens on every local shard.  The step state (pos, len, token) of the
 // cache must already be set on the device.  ids_dev == null: the single token comes from the state.
 static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_scratch, int64_t len_hint) {
+    for (auto &sh : m->shards) sh.amax_valid = false;                  // (set by the path whose lm_head launch leaves ArgMax candidates)
     if (T == 1 && !pre && !ids_in_scratch && m->fused_decode) return enqueue_decode_fused(m, c, len_hint);
     if (pre && ids_in_scratch && m->tp > 1 && env_int("FL_TP_OVERLAP", 1) && T >= env_int("FL_TP_OVERLAP_MIN_T", 512) && !m->profiling &&
         (m->tp_mode == FL_TP_MULTI_PROCESS || m->tp_mode == FL_TP_SINGLE_PROCESS))
@@ -1050,7 +1053,8 @@ static int enqueue_argmax(Model *m, Cache *c, int advance) {
         Shard &sh = m->shards[i];
         FL_HIP(hipSetDevice(sh.device));
         Launcher L = make_launcher(m, sh);
-        FL_TRY(launch_select_advance(L, sh.logits_full, m->D.V, c->shards[i].st, c->shards[i].ss, c->shards[i].sel_scratch, c->shards[i].out_tokens, advance));
+        FL_TRY(launch_select_advance(L, sh.logits_full, m->D.V, c->shards[i].st, c->shards[i].ss, c->shards[i].sel_scratch, c->shards[i].out_tokens, advance,
+                                     sh.amax_valid ? sh.amax : nullptr));
     }
     return FL_OK;
 }
