@@ -73,8 +73,15 @@ __device__ __forceinline__ void attn_decode_mfma_body(const bf16_t *__restrict__
         __device__ bf16x8 k_frag(int tile, int dk) const { return k[tile][dk]; }
         __device__ bf16x8 v_frag(int db) const { return ld_bf16x8(vT + (size_t)(db * 16 + i) * ldv + kbase + 8 * g4); }
     };
-    if constexpr (NW > 8) {               // 16-wave workgroups have 128 VGPRs per lane: no room for a second K set
-        for (int kbase = lo + 32 * wave; kbase < hi; kbase += STEP) {
+    if constexpr (NW > 8) {               // 16-wave workgroups have 128 VGPRs per lane: no room for a second K set,
+        int kbase = lo + 32 * wave;       // but the FIRST tile's K and V^T fragments are requested together here too
+        if (kbase < hi) {
+            RegKV<D> r0;
+            r0.load(kb, vb, seq_alloc, kbase, i, g4);
+            attn_tile<D>(s, qf, r0, kbase, 0, lo, hi, scale, lane);
+            kbase += STEP;
+        }
+        for (; kbase < hi; kbase += STEP) {
             const GlobalKV<D> kv{kb, vb, seq_alloc, kbase, i, g4};
             attn_tile<D>(s, qf, kv, kbase, 0, lo, hi, scale, lane);
         }
