@@ -4,11 +4,17 @@
 //
 // Streaming (HBM-bound, cdna guide "GEMV / M <= 16" row): each wave owns R rows at a time and
 // reads them 16 B per lane (1 KiB per wave instruction), non-temporal, straight to VGPRs -- no
-// LDS round trip for read-once bytes.  U chunks x R rows (U*R KiB per wave) are requested before
-// the first FMA of a block (straight-line code, so hipcc emits counted vmcnt waits), 8..12 waves
-// per CU overlap each other's load and FMA phases, and the first block is requested BEFORE x is
-// staged so HBM is busy during the prologue.  fp32 accumulate; 64-lane shuffle reduce.  x is
-// staged once per workgroup in LDS (ds_read_b128).
+// LDS round trip for read-once bytes.  bf16 weights: the wave's (row group, K block) items form
+// ONE stream, a block (U chunks x R rows = 4 or 8 KiB) ahead in a second register buffer, every
+// load unconditional so that hipcc keeps counted vmcnt waits; the arithmetic is v_dot2c_f32_bf16
+// (common.h: inline asm, with the wait the gfx940+ dot-result hazard asks for behind every run
+// of dots; tests/test_dot_hazard.py checks the shipped code objects).  A projection short enough
+// for one row group per wave requests its whole share before the prologue (SMALL).  fp32 weights:
+// straight-line blocks of U chunks x R rows with FMAs, the K tail as one more block.  8..12 waves
+// per CU overlap each other's load and multiply phases, and the first block is requested BEFORE
+// x is staged so HBM is busy during the prologue.  fp32 accumulate; 64-lane shuffle reduce.  x is
+// staged once per workgroup in LDS (ds_read_b128).  Against a bare read stream of the same bytes
+// (tools/micro/stream_ceiling.hip, 6.76 TB/s) the largest launch of a Mistral-7B step is 6 % slower.
 //
 // Geometry: one workgroup per CU (or two), 4..12 waves each, chosen so that every wave gets the
 // same number of row groups (a ragged last round costs 1/rounds of the kernel) and everything is
