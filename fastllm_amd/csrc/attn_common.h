@@ -89,9 +89,11 @@ __device__ __forceinline__ bool decode_tail(float *lds, int *is_last, int G, int
         const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = t == (unsigned)nsplit - 1;
         if (last) {
-            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everyone has arrived
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // everyone has arrived: the word is reset for the next launch BEHIND the acquire's wait (before it, the wait
+            // also sat out this store's trip to memory)
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         *is_last = last;
     }
