@@ -119,6 +119,10 @@ int fl_model_get_info(const fl_model *m, fl_model_info *out) {
         out->weight_bytes_per_token = es * (D.L * (per_layer + small) + D.h + D.V * D.h);
         out->kv_bytes_per_position = es * D.L * D.Hkv * D.d * 2;
         out->hbm_bytes_allocated = mm->hbm_bytes;
+        for (auto &sh : mm->shards) {                           // + the stream-K workspace of each shard's streams (first long prompt)
+            if (hipSetDevice(sh.device) != hipSuccess) continue;
+            out->hbm_bytes_allocated += gemm_8p_workspace_bytes(sh.stream) + gemm_8p_workspace_bytes(sh.comm_stream);
+        }
         out->small_collectives = mm->shards[0].pc.connected ? 2 : mm->tp == 1 ? 0 : mm->tp_mode == FL_TP_EMULATED ? 3 : 1;
         out->fused_all_reduce = fused_all_reduce_ready(mm) ? 1 : 0;
         if (mm->shards[0].comm) {

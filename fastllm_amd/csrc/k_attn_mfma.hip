@@ -615,6 +615,9 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *_
 #pragma unroll
                 for (int r = 0; r < 16; r++) mx[(2 + db * 16 + r) * 64 + lane] = O[db][r];
         }
+        // s_barrier waits for no counter (gfx950 back-off barriers): the hand-over's ds_writes must have landed before the
+        // partner wave may read them
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wave_on && ksub == 0) {
             const float m1 = mx[lane], l1 = mx[64 + lane];

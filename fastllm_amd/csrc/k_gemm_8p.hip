@@ -373,6 +373,15 @@ struct SkSpace { float *part = nullptr; int nwg = 0; };
 static std::mutex g_sk_mu;
 static std::map<std::pair<int, hipStream_t>, SkSpace> g_sk_spaces;    // 128 MiB per stream that runs long-prompt GEMMs, until the stream goes
 
+// bytes of stream-K workspace held for `stream` on the current device (allocated by the first long-prompt forward)
+int64_t gemm_8p_workspace_bytes(hipStream_t stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lock(g_sk_mu);
+    auto it = g_sk_spaces.find({dev, stream});
+    return it == g_sk_spaces.end() ? 0 : (int64_t)it->second.nwg * 2 * P_BM * P_BN * (int64_t)sizeof(float);
+}
+
 // the owner of a stream calls this before destroying it (work on the stream has completed)
 void gemm_8p_release_stream(hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_sk_mu);
@@ -386,12 +395,16 @@ void gemm_8p_release_stream(hipStream_t stream) {
     }
 }
 
+static int cu_count();
 static int streamk_space(hipStream_t stream, int nwg, StreamK *sk) {
     int dev = 0;
     FL_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_sk_mu);
     SkSpace &sp = g_sk_spaces[{dev, stream}];
     if (sp.nwg < nwg) {
+        // sized ONCE for a workgroup per CU (launch_gemm_8p never asks for more): no synchronise-and-free in the middle of a
+        // launch sequence; gemm_8p_workspace_bytes() reports it to fl_model_info
+        nwg = std::max(nwg, cu_count());
         if (sp.part) { FL_HIP(hipStreamSynchronize(stream)); (void)hipFree(sp.part); }
         sp = SkSpace{};
         FL_HIP(hipMalloc(&sp.part, (size_t)nwg * 2 * P_BM * P_BN * sizeof(float)));

@@ -575,7 +575,9 @@ static int launch_gemv_t(Launcher &L, const GemvArgs &a) {
     const int64_t ngroups = (N + R - 1) / R;
     int blocks = 1, waves = 4;
     pick_geometry(ngroups, lds, &blocks, &waves);
-    if (a.amax && blocks + 1 > kMaxArgmaxCand) FL_FAIL(FL_ERR_BAD_ARGUMENT, "launch_gemv: %d workgroups exceed the ArgMax candidate buffer", blocks);
+    if (a.amax && blocks + 1 > kMaxArgmaxCand) {           // (callers ask gemv_leaves_candidates first; a tuned grid may still get here)
+        FL_FAIL(FL_ERR_BAD_ARGUMENT, "launch_gemv: %d workgroups exceed the ArgMax candidate buffer (gemv_leaves_candidates not consulted)", blocks);
+    }
     if (PRO == PRO_NORM && (int64_t)waves * 64 * 3 * 8 < K) waves = (int)((K + 64 * 3 * 8 - 1) / (64 * 3 * 8));   // staging capacity
     if (waves < 4) waves = 4;
     static const int allow_small = env_int("FL_GEMV_SMALL", 1);
@@ -607,6 +609,18 @@ static int launch_gemv_ru(Launcher &L, const GemvArgs &a) {
     if (R == 2 && U == 8) return launch_gemv_t<WT, XT, 2, 8, PRO>(L, a);
     if (R == 2 && U == 2) return launch_gemv_t<WT, XT, 2, 2, PRO>(L, a);
     return launch_gemv_t<WT, XT, 2, 4, PRO>(L, a);
+}
+
+// Would this launch's grid fit the ArgMax candidate buffer (GemvArgs::amax)?  A tuned grid (fl_tune "gemv_blocks") or a
+// device with >= 512 CUs may not: the caller then leaves amax null and token selection scans the logits instead.
+bool gemv_leaves_candidates(int dtype, const GemvArgs &a) {
+    int R = g_gemv_r.load();
+    if (!R) R = env_int("FL_GEMV_R", 2);
+    if (R != 4) R = 2;                                       // (the instantiations launch_gemv_ru picks from)
+    const size_t es = dtype == FL_DTYPE_BF16 ? 2 : 4;
+    int blocks = 1, waves = 4;
+    pick_geometry(((int64_t)a.N + R - 1) / R, ((size_t)a.K * es + 15) & ~(size_t)15, &blocks, &waves);
+    return blocks + 1 <= kMaxArgmaxCand;
 }
 
 int launch_gemv(Launcher &L, int dtype, const GemvArgs &a) {

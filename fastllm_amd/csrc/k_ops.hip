@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void rope_kv_vec_kernel(const float *__restric
         float c[8], sn[8], ra[8], rb[8];
         load8(cos_tab + (size_t)p * half + j0, c); load8(sin_tab + (size_t)p * half + j0, sn);
 #pragma unroll
-        for (int j = 0; j < 8; j++) { ra[j] = a[j] * c[j] - b[j] * sn[j]; rb[j] = a[j] * sn[j] + b[j] * c[j]; }
+        for (int j = 0; j < 8; j++) rope_rotate(a[j], b[j], c[j], sn[j], ra[j], rb[j]);     // (separately rounded products, as every other RoPE site)
         bf16_t *o = hd < H ? q_out + ((size_t)t * H + hd) * d + j0 : kc + ((size_t)(hd - H) * max_seq + len + t) * d + j0;
         store8(o, ra); store8(o + half, rb);
         return;

@@ -87,6 +87,7 @@ struct GemvArgs {
     ArgmaxCand *amax = nullptr;
 };
 int launch_gemv(Launcher &L, int dtype, const GemvArgs &a);
+bool gemv_leaves_candidates(int dtype, const GemvArgs &a);   // the grid launch_gemv would pick fits the candidate buffer
 bool gemv_norm_supported(int dtype, int64_t N, int64_t K);
 void gemv_set_tuning(int R, int U, int maxblocks, int maxblocks_norm);
 
@@ -160,6 +161,7 @@ bool gemm_resid_supported(int dtype, int64_t T, int64_t N, int64_t K, int max_sp
 int gemm_resid_partials(int64_t N);                                                       // partial sums per row (np)
 int launch_gemm_resid(Launcher &L, const void *W, const void *x, int64_t T, int64_t N, int64_t K, const ResidEpi &re);
 int launch_rms_finalize(Launcher &L, const float *part, int np, float eps, float *inv_rms, int64_t T, int64_t h);
+int64_t gemm_8p_workspace_bytes(hipStream_t stream);   // stream-K workspace held for a stream on the current device
 void gemm_8p_release_stream(hipStream_t stream);   // frees the stream-K workspace of a stream that is about to be destroyed
 int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
                    int epi, const float *row_scale, int ksplit, int64_t ldc = 0, bool streamk = false, const ResidEpi *resid = nullptr);

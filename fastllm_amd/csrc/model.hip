@@ -820,7 +820,7 @@ static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
         Launcher L = make_launcher(m, sh);
         GemvArgs a;
         a.W = sh.lm_head; a.out = lm_head_out(m, sh); a.N = (int)sh.Vs; a.K = (int)D.h; a.epi = EPI_F32; a.pro = PRO_NORM;
-        if (!m->vocab_parallel && env_int("FL_ARGMAX_FUSED", 1)) { a.amax = sh.amax; sh.amax_valid = true; }   // token selection reads one candidate per workgroup
+        if (!m->vocab_parallel && env_int("FL_ARGMAX_FUSED", 1) && gemv_leaves_candidates(dt, a)) { a.amax = sh.amax; sh.amax_valid = true; }   // token selection reads one candidate per workgroup
         a.x_in = sc.x_res; a.delta = sc.delta; a.norm_w = sh.norm; a.eps = D.eps; a.st = c->shards[i].st;
         FL_TRY(launch_gemv(L, dt, a));
     }
