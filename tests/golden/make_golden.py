@@ -104,6 +104,54 @@ def run_case(name, T, n_gen, ref_calls=0):
     print(name, "T", T, "gen", n_gen, "->", {k: v.shape for k, v in rec.items() if k != "meta"})
 
 
+def _masked_last_logits(m, cfg, T, seq, pos):
+    """Last-position logits of `seq` (prompt of T tokens + decode tokens) in ONE cache-free pass with an explicit 4-D mask:
+    prompt rows see candle's prefill mask (causal, j + sliding_window >= i; mistral.rs / qwen.rs via App. A.5), decode rows the
+    whole prefix (candle builds no mask at T = 1).  HF's own cached decode would apply the window to the cache, which the
+    reference does not."""
+    n, W = len(seq), cfg["sliding_window"]
+    dt = next(m.parameters()).dtype
+    mask = torch.full((1, 1, n, n), torch.finfo(dt).min, dtype=dt)
+    for i in range(n):
+        lo = 0 if i >= T else max(0, i - W)
+        mask[0, 0, i, lo:i + 1] = 0
+    o = m(torch.tensor([[int(t) for t in seq]]), attention_mask=mask, position_ids=torch.tensor([list(pos)]), use_cache=False)
+    return o.logits[0, -1].float().numpy().astype(np.float32)
+
+
+@torch.no_grad()
+def run_case_windowed_decode(name, T, n_gen, ref_calls):
+    """A fixture whose window bites during the prefill AND that decodes on (round 3: Qwen2, whose window the reference
+    forces on, qwen.rs:49-52).  Same keys as run_case; every vector comes from _masked_last_logits."""
+    cfg = synth.CONFIGS[name]
+    w = synth.synth_weights(cfg)
+    m = hf_model(cfg, synth.as_f32(w))
+    m16 = hf_model(cfg, synth.as_f32(w)).to(torch.bfloat16)
+    ids = synth.prompt_ids(cfg, T)
+    rec = dict(prompt=ids)
+    rec["prefill_logits"] = _masked_last_logits(m, cfg, T, ids, range(T))
+    rec["prefill_half_logits"] = _masked_last_logits(m, cfg, T // 2, ids[:T // 2], range(T // 2))
+    rec["hf_bf16_prefill_logits"] = _masked_last_logits(m16, cfg, T, ids, range(T))
+
+    def decode(n, ref_positions, model, force=None):
+        seq, pos, toks, rows = list(ids), list(range(T)), [], []
+        for k in range(n):
+            lg = _masked_last_logits(model, cfg, T, seq, pos)
+            tok = int(np.argmax(lg)) if force is None else int(force[k])
+            toks.append(tok); rows.append(lg)
+            seq.append(tok); pos.append(k + 1 if ref_positions else T + k)      # quirk C.1: decode call n rotated as position n
+        return np.array(toks, dtype=np.uint32), np.stack(rows)
+    rec["gen_tokens"], rec["gen_logits"] = decode(n_gen, False, m)
+    rec["ref_tokens"], rec["ref_logits"] = decode(ref_calls, True, m)
+    rec["hf_bf16_gen_logits"] = decode(n_gen, False, m16, force=rec["gen_tokens"])[1]
+    meta = dict(name=name, config=cfg, T=T, n_gen=n_gen, ref_calls=ref_calls, seed=0xFA57,
+                weights_sha256=synth.weights_digest(w), transformers=__import__("transformers").__version__,
+                torch=torch.__version__, method="cache-free passes with an explicit 4-D mask")
+    rec["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+    print(name, "T", T, "gen", n_gen, "->", {k: v.shape for k, v in rec.items() if k != "meta"})
+
+
 @torch.no_grad()
 def add_bf16(name):
     """HF in bfloat16 (CPU, eager) on the same weights, prompt and -- teacher-forced -- the fp32 run's greedy tokens: how far
@@ -133,6 +181,9 @@ def add_bf16(name):
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "--qwen2-win":       # round 3: one new fixture, the committed ones stay byte-identical
+        run_case_windowed_decode("qwen2_win", T=16, n_gen=8, ref_calls=8)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--add-bf16":        # round 2: extend the committed fixtures in place
         for n in ("llama_a", "llama_mha", "mistral_a", "mistral_win", "qwen2_a"):
             add_bf16(n)
@@ -144,3 +195,4 @@ if __name__ == "__main__":
     run_case("qwen2_a", T=8, n_gen=16, ref_calls=8)
     for n in ("llama_a", "llama_mha", "mistral_a", "mistral_win", "qwen2_a"):
         add_bf16(n)
+    run_case_windowed_decode("qwen2_win", T=16, n_gen=8, ref_calls=8)

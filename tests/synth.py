@@ -44,6 +44,12 @@ CONFIGS = {
                     num_hidden_layers=2, num_attention_heads=6, num_key_value_heads=2,
                     rms_norm_eps=1e-6, rope_theta=1000000.0, max_position_embeddings=512,
                     sliding_window=4096, qkv_bias=1),
+    # Qwen2 with a window that bites (qwen.rs:49-52 forces use_sliding_window=true): G = 3, q/k/v bias, theta 1e6;
+    # candle sliding_window = 5  <=>  HF sliding_window = 6.  Decode steps attend to the whole cache (App. A.5: no mask at T = 1)
+    "qwen2_win": dict(family="qwen2", hidden_size=384, intermediate_size=512, vocab_size=300,
+                      num_hidden_layers=2, num_attention_heads=6, num_key_value_heads=2,
+                      rms_norm_eps=1e-6, rope_theta=1000000.0, max_position_embeddings=512,
+                      sliding_window=5, qkv_bias=1),
     # MHA (no GQA), num_key_value_heads absent -> defaults to heads (llama.rs:39)
     "llama_mha": dict(family="llama", hidden_size=128, intermediate_size=256, vocab_size=200,
                       num_hidden_layers=3, num_attention_heads=2, num_key_value_heads=None,

@@ -1,0 +1,100 @@
+"""BASELINE.json's configs at their LITERAL lengths against the oracle.
+
+* C1 / C2: TinyLlama-1.1B at full depth, 128-token prompt, 128 greedy tokens (the loop of mod.rs:363-463): the fp32 HIP
+  path's ids equal the oracle's ids and every step's logits are within 1e-3; the bf16 HIP path (what the bench times) is
+  compared margin-aware with the same fp32 run.
+* C3's lengths on Mistral-7B's width: 4 layers, 512-token prompt, 64 greedy tokens, same two statements.
+The oracle is the checker only; every HIP result comes through the C ABI.
+"""
+import sys
+import os
+import time
+
+import numpy as np
+import pytest
+
+import synth
+from oracle import oracle
+from test_gpu_fullsize import pooled_weights
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_literal(fa, cfg, w, T, n_gen, what):
+    ids = synth.prompt_ids(cfg, T, seed=1234)
+    om = oracle.OracleModel(cfg, w)
+    t0 = time.time()
+    otoks, ologits = om.generate(om.new_cache(T + n_gen + 8), ids, n_gen, want_logits=True)
+    print("\n%s: oracle %d-token prompt + %d greedy tokens in %.1f s on %d threads" % (what, T, n_gen, time.time() - t0, om.threads()))
+    om.close()
+    assert len(otoks) == n_gen
+
+    # fp32 HIP path: the device-side greedy loop gives the same ids ...
+    g32 = fa.Model(cfg, w, dtype="f32")
+    c = g32.new_cache(T + n_gen + 8)
+    first = g32.forward_argmax(c, ids, 0)
+    rest = g32.decode_greedy(c, first, T, n_gen - 1)
+    gtoks = np.concatenate([[first], rest]).astype(np.uint32)
+    np.testing.assert_array_equal(gtoks, otoks, err_msg=what + ": fp32 greedy ids")
+    # ... and every step's logits are within 1e-3 (fl_forward per step, fed the same ids)
+    c2 = g32.new_cache(T + n_gen + 8)
+    worst = 0.0
+    lg = g32.forward(c2, ids, 0)
+    for i in range(n_gen):
+        worst = max(worst, float(np.abs(lg - ologits[i]).max()))
+        np.testing.assert_allclose(lg, ologits[i], atol=1e-3, rtol=0, err_msg="%s: fp32 logits of step %d" % (what, i))
+        assert oracle.argmax(lg) == int(otoks[i])
+        if i + 1 < n_gen:
+            lg = g32.forward(c2, [int(otoks[i])], T + i)
+    print("%s: fp32 HIP ids == oracle ids over %d tokens; worst |logit diff| %.2e" % (what, n_gen, worst))
+    g32.close()
+
+    # bf16 HIP path (production dtype): same ids wherever the fp32 run decides by more than the bf16 noise; teacher-forced
+    # logits within the bf16 band of the fp32 run at every step
+    g16 = fa.Model(cfg, w, dtype="bf16")
+    c = g16.new_cache(T + n_gen + 8)
+    first = g16.forward_argmax(c, ids, 0)
+    btoks = np.concatenate([[first], g16.decode_greedy(c, first, T, n_gen - 1)]).astype(np.uint32)
+    c2 = g16.new_cache(T + n_gen + 8)
+    lg = g16.forward(c2, ids, 0)
+    rels, noise = [], 0.0
+    for i in range(n_gen):
+        n = np.linalg.norm(ologits[i])
+        rels.append(float(np.linalg.norm(lg - ologits[i]) / n))
+        noise = max(noise, float(np.abs(lg - ologits[i]).max()))
+        assert rels[-1] <= 2e-2, "%s: bf16 logits of step %d: rel L2 %.4f" % (what, i, rels[-1])
+        if i + 1 < n_gen:
+            lg = g16.forward(c2, [int(otoks[i])], T + i)
+    agree = 0
+    for i in range(n_gen):
+        if btoks[i] != otoks[i]:
+            top2 = np.sort(ologits[i])[-2:]
+            assert top2[1] - top2[0] <= 2 * noise, "%s: bf16 token %d differs with fp32 margin %g (bf16 noise %g)" % (what, i, top2[1] - top2[0], noise)
+            break                                  # after a legitimate divergence the two sequences are different problems
+        agree += 1
+    print("%s: bf16 HIP ids agree with the oracle for %d / %d tokens; rel L2 to fp32 %.2e .. %.2e" % (what, agree, n_gen, min(rels), max(rels)))
+    g16.close()
+
+
+def test_tinyllama_128_prompt_128_gen_vs_oracle():
+    """BASELINE.json configs[0] / [1] verbatim."""
+    import fastllm_amd as fa
+    from fastllm_amd.configs import MODEL_CONFIGS
+    cfg = MODEL_CONFIGS["tinyllama-1.1b"]
+    run_literal(fa, cfg, pooled_weights(cfg), 128, 128, "TinyLlama-1.1B 128/128")
+
+
+def test_mistral_7b_width_512_prompt_64_gen_vs_oracle():
+    """configs[2]'s prompt length on Mistral-7B's layer shape (4 of its 32 layers: the oracle runs this in seconds)."""
+    import torch
+    import fastllm_amd as fa
+    from fastllm_amd.configs import MODEL_CONFIGS
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = dict(MODEL_CONFIGS["mistral-7b"], num_hidden_layers=4)
+    wts = bench.synth_device_weights(torch, cfg, torch.device("cuda", 0), seed=21)
+    w = {k: v.view(torch.int16).cpu().numpy().view(np.uint16) for k, v in wts.items()}
+    del wts
+    torch.cuda.empty_cache()
+    run_literal(fa, cfg, w, 512, 64, "Mistral-7B width, 4 layers, 512/64")

@@ -18,7 +18,7 @@ from oracle import oracle
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["llama_a", "llama_mha", "mistral_a", "mistral_win", "qwen2_a"]
+CASES = ["llama_a", "llama_mha", "mistral_a", "mistral_win", "qwen2_a", "qwen2_win"]
 
 
 @pytest.fixture(scope="module")

@@ -13,7 +13,7 @@ import pytest
 import synth
 from oracle import oracle
 
-CASES = ["llama_a", "llama_mha", "mistral_a", "mistral_win", "qwen2_a"]
+CASES = ["llama_a", "llama_mha", "mistral_a", "mistral_win", "qwen2_a", "qwen2_win"]
 TOL = 2e-4     # fp32 vs fp32, different summation order
 
 
