@@ -292,6 +292,7 @@ int fl_tune(const char *key, int value) {
         else if (!strcmp(key, "gemv_u")) gemv_set_tuning(0, value, -1, -1);
         else if (!strcmp(key, "gemv_blocks")) gemv_set_tuning(0, 0, value, -1);        // 0 = automatic
         else if (!strcmp(key, "gemv_waves")) gemv_set_tuning(0, 0, -1, value);          // 0 = automatic
+        else if (!strcmp(key, "engine_grid")) engine_set_grid(value);                   // 0 = one workgroup per CU (tests: a grid that cannot be resident)
         else FL_FAIL(FL_ERR_BAD_ARGUMENT, "unknown tuning key %s", key);
         return FL_OK;
     });

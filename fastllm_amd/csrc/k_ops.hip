@@ -739,8 +739,10 @@ constexpr size_t kSelLds = sizeof(OrderedSumLds) > 2 * kSelTile * 4 ? sizeof(Ord
 __global__ __launch_bounds__(1024) void select_advance_kernel(const float *__restrict__ logits, int V,
                                                               StepState *__restrict__ st, SampleState *__restrict__ ss,
                                                               float *__restrict__ scratch, uint32_t *__restrict__ out_tokens,
-                                                              int advance, const ArgmaxCand *__restrict__ cand) {
+                                                              int advance, const ArgmaxCand *__restrict__ cand, uint32_t *epoch_bump) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kSelLds];
+    // the persistent decode engine's tag epoch (k_engine.hip): one step per forward, so no two launches ever share a tag
+    if (epoch_bump && threadIdx.x == 0) *epoch_bump += 1;
     select_advance_body(logits, V, st, ss, scratch, out_tokens, advance, lds, cand);
 }
 
@@ -759,9 +761,9 @@ int launch_select_advance_batch(Launcher &L, const float *logits, int64_t V, con
 
 // scratch: V floats (probabilities / cumulative weights of the sampling path)
 int launch_select_advance(Launcher &L, const float *logits, int64_t V, StepState *st, SampleState *ss, float *scratch,
-                          uint32_t *out_tokens, int advance, const ArgmaxCand *cand) {
+                          uint32_t *out_tokens, int advance, const ArgmaxCand *cand, uint32_t *epoch_bump) {
     return L.launch(KC_ARGMAX, (double)V * 4, 0, select_advance_kernel, dim3(1), dim3(1024), 0, logits, (int)V, st, ss,
-                    scratch, out_tokens, advance, cand);
+                    scratch, out_tokens, advance, cand, epoch_bump);
 }
 
 // ------------------------------------------------------------------------------- local shard reduce

@@ -91,6 +91,47 @@ bool gemv_leaves_candidates(int dtype, const GemvArgs &a);   // the grid launch_
 bool gemv_norm_supported(int dtype, int64_t N, int64_t K);
 void gemv_set_tuning(int R, int U, int maxblocks, int maxblocks_norm);
 
+// ---- the persistent decode engine (k_engine.hip): a chain of projections in one launch ---------------------------
+constexpr int ENG_GATHER_WAVES = 4, ENG_STREAM_WAVES = 8, ENG_MAX_OPS = 4;
+enum { ENG_IN_X = 0, ENG_IN_NORM = 1, ENG_IN_ACT = 2 };                 // plain bf16 vector of the previous launch | fp32 delta edge + residual + RMSNorm weight | packed silu(g)*u edge
+enum { ENG_OUT_EDGE_F32 = 0, ENG_OUT_EDGE_ACT = 1, ENG_OUT_QKV = 2, ENG_OUT_LOGITS = 3 };
+struct EngOp {
+    const void *W = nullptr;            // [N,K] bf16
+    int N = 0, K = 0, in = ENG_IN_X, out = ENG_OUT_EDGE_F32;
+    int R = 2;                          // rows per wave item (launch_engine: 1 for row-parallel ops with few rows per CU)
+    const void *x = nullptr;            // ENG_IN_X: bf16 [K]
+    const float *norm_w = nullptr;      // ENG_IN_NORM: weight of the RMSNorm in front of this op
+    const unsigned long long *in_edge = nullptr;   // granules {value, tag} written by the previous op of this launch
+    unsigned long long *out_edge = nullptr;
+    float *res_out = nullptr;           // ENG_IN_NORM: workgroup 0 also leaves the updated residual stream here (the next launch's x_res_in)
+    void *dst = nullptr;                // ENG_OUT_LOGITS: float [N]
+    const float *bias = nullptr;        // ENG_OUT_QKV / ENG_OUT_LOGITS
+    int tag_in = 0, tag_out = 0;        // 1..255, unique per (launch of the step, edge)
+};
+struct EngArgs {
+    EngOp op[ENG_MAX_OPS];
+    int nops = 0, h = 0;
+    const float *x_res_in = nullptr;    // [h] residual stream in front of the first op's layer (null: no op of the chain norms)
+    float eps = 0.f;
+    const StepState *st = nullptr;
+    StepState *st_rw = nullptr;         // error word of a wait that gave up
+    const uint32_t *epoch = nullptr;    // device word advanced once per decode step (select_advance): tags never repeat
+    long long timeout_ticks = 0;        // wall_clock64 ticks (100 MHz)
+    // ENG_OUT_QKV: RoPE + KV append as in GemvArgs
+    const float *cos_tab = nullptr, *sin_tab = nullptr;
+    void *q_out = nullptr, *k_cache = nullptr, *v_cache = nullptr;
+    int H = 0, Hkv = 0, d = 0, max_seq = 0, max_pos = 0, v_ld = 0;
+    ArgmaxCand *amax = nullptr;         // ENG_OUT_LOGITS: one ArgMax candidate per workgroup (as GemvArgs::amax)
+    unsigned long long *stamps = nullptr;   // diagnostics: [workgroup][32] wall_clock64 stamps (FL_ENGINE_STAMPS)
+    int grid = 0;                       // 0: one workgroup per CU
+    int xs0_bytes = 0, xs1_bytes = 0;   // (filled by launch_engine)
+    int pf_blocks = 1;                  // 8-KiB blocks a streamer requests ahead of an op's input (FL_ENGINE_PF)
+    int gather_delay = 0;               // s_sleep(1) rounds between "this CU's streamers are done" and the first sweep (FL_ENGINE_DELAY)
+};
+bool engine_shape_ok(int64_t h, int64_t Hd, int64_t I, int64_t N_last);
+int launch_engine(Launcher &L, const EngArgs &a);
+void engine_set_grid(int workgroups);   // fl_tune("engine_grid"): 0 = one per CU
+
 // ---- batched decode (k_gemv_batch.hip): B <= 8 sequences share one read of the weights ------------
 // Per-sequence device state and buffers of a batch member (a view of its cache).
 struct SeqRef {
@@ -195,7 +236,8 @@ int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st
 // the seeded ChaCha12 stream; out_tokens[st->step] = token; advances pos/len/step
 int launch_select_advance(Launcher &L, const float *logits, int64_t V, StepState *st, SampleState *ss, float *scratch /* [V] */,
                           uint32_t *out_tokens, int advance,
-                          const ArgmaxCand *cand = nullptr /* the lm_head launch's candidates: ArgMax without reading the vocabulary again */);
+                          const ArgmaxCand *cand = nullptr /* the lm_head launch's candidates: ArgMax without reading the vocabulary again */,
+                          uint32_t *epoch_bump = nullptr /* the decode engine's tag epoch: += 1 per forward */);
 // dst[i] = sum_s src[s][i] for n floats, written to every src (emulated all-reduce)
 int launch_reduce_shards(Launcher &L, float *const *bufs_dev, int nshards, int64_t n);
 

@@ -82,6 +82,9 @@ struct Shard {
     ArgmaxCand *amax = nullptr;      // [kMaxArgmaxCand] ArgMax candidates left by the decode step's lm_head launch (GemvArgs::amax)
     bool amax_valid = false;         // ... and whether the forward enqueued last produced them (host-side, per enqueue)
     float *logits_full = nullptr;    // [V]
+    // the persistent decode engine (k_engine.hip): granule edges of one launch and the tag epoch
+    unsigned long long *eng_edge[3] = {};   // o_proj deltas [h] | silu(g)*u pairs [Ip/2] | down_proj deltas [h]
+    uint32_t *eng_epoch = nullptr;
     std::vector<void *> allocs;
     std::vector<void *> pre_allocs;  // the prefill scratch set: replaced (and freed) when a longer prompt arrives
     int64_t pre_bytes = 0;
@@ -103,6 +106,7 @@ struct Model {
     uint32_t *host_tokens = nullptr;
     bool use_graph = true;
     bool fused_decode = true;    // norm / RoPE / KV-append fused into the GEMV kernels
+    int engine = -1;             // persistent decode engine (k_engine.hip): 0 off, 1 on, -1 automatic
     int fuse_oproj = 0;          // decode attention + o_proj in one launch (k_attn_oproj.hip): 0 never (default), 1 wherever it fits, -1 where it pays most
     StepState *host_state = nullptr;   // pinned: device step state read back for the error word
     std::vector<ProfRecord> prof;

@@ -497,11 +497,22 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
         FL_TRY(dev_alloc(sh.allocs, (void **)&sh.logits_local, (size_t)sh.Vs * 4, &m->hbm_bytes));
         FL_TRY(dev_alloc(sh.allocs, (void **)&sh.logits_full, (size_t)D.V * 4, &m->hbm_bytes));
         FL_TRY(dev_alloc(sh.allocs, (void **)&sh.amax, sizeof(ArgmaxCand) * kMaxArgmaxCand, &m->hbm_bytes));
+        // the persistent decode engine's granule edges and tag epoch (k_engine.hip); tags never repeat, so they are zeroed once
+        if (compute_dtype == FL_DTYPE_BF16 && engine_shape_ok(D.h, sh.Hs * D.d, sh.Ip, sh.Vs) && D.L <= 63) {
+            const size_t ne[3] = {(size_t)D.h, (size_t)sh.Ip / 2, (size_t)D.h};
+            for (int e = 0; e < 3; e++) {
+                FL_TRY(dev_alloc(sh.allocs, (void **)&sh.eng_edge[e], ne[e] * 8, &m->hbm_bytes));
+                FL_HIP(hipMemsetAsync(sh.eng_edge[e], 0, ne[e] * 8, sh.stream));
+            }
+            FL_TRY(dev_alloc(sh.allocs, (void **)&sh.eng_epoch, 16, &m->hbm_bytes));
+            FL_HIP(hipMemsetAsync(sh.eng_epoch, 0, 16, sh.stream));
+        }
     }
     FL_HIP(hipSetDevice(m->shards[0].device));
     FL_HIP(hipHostMalloc((void **)&m->host_logits, (size_t)D.V * 4, hipHostMallocDefault));
     FL_HIP(hipHostMalloc((void **)&m->host_tokens, kOutTokensCap * 4, hipHostMallocDefault));
     FL_HIP(hipHostMalloc((void **)&m->host_state, sizeof(StepState), hipHostMallocDefault));
+    m->engine = env_int("FL_ENGINE", 0);                  // persistent decode engine (k_engine.hip): 1 = wherever it runs (opt-in: it measured slower)
     m->fuse_oproj = env_int("FL_FUSE_OPROJ", 0);          // 0.0-1.5 % at best (profiles/r02/README.md): off unless asked for; -1 = where it pays most
 
     // communicators
@@ -760,7 +771,79 @@ static int gather_logits(Model *m) {
 
 static bool fused_all_reduce(Model *m, Cache *c) { return !c->fuse_oproj && fused_all_reduce_ready(m); }
 
+// The decode step on the persistent engine (k_engine.hip): per layer the attention launch and ONE launch that chains
+// o_proj -> gate/up -> down_proj -> the next layer's QKV projection (the last layer: lm_head) -- 2 L + 1 launches instead of 5 L + 1.
+// One shard, no tensor parallelism (stage 1), bf16, MFMA attention; FL_ENGINE=1 turns it on (default off: see below).
+static bool engine_usable(Model *m, Cache *c) {
+    const int want = m->engine;
+    if (want == 0 || m->shards.size() != 1 || m->tp != 1 || m->dtype != FL_DTYPE_BF16 || !m->fused_decode || c->fuse_oproj || !c->v_transposed) return false;
+    Shard &sh = m->shards[0];
+    if (!sh.eng_epoch || sh.pc.shares_device || m->D.L < 1) return false;
+    if (!gemv_norm_supported(m->dtype, (sh.Hs + 2 * sh.Hkvs) * m->D.d, m->D.h)) return false;
+    // opt-in: measured 5 % SLOWER than the five launches it replaces on TinyLlama-1.1B (24.4 us against 23.2 us per layer for
+    // o_proj .. QKV; profiles/r03/README.md has the in-kernel stamps: every chip-wide edge costs 2.2-3 us, a kernel boundary
+    // + ramp 2.5-3, and the prefetch across an edge only moves the pipeline's fill bubble behind the barrier)
+    return want == 1;
+}
+
+static int enqueue_decode_engine(Model *m, Cache *c, int64_t len_hint) {
+    const Dims &D = m->D;
+    const int dt = m->dtype;
+    Shard &sh = m->shards[0]; Scratch &sc = sh.dec; CacheShard &cs = c->shards[0];
+    FL_HIP(hipSetDevice(sh.device));
+    Launcher L = make_launcher(m, sh);
+    static const long long timeout_ticks = (long long)env_int("FL_ENGINE_TIMEOUT_MS", 2000) * 100000ll;
+    auto kv_of = [&](int64_t l, void **kc, void **vc) {
+        const size_t kv_layer = (size_t)l * sh.Hkvs * c->seq_alloc * D.d * m->esize();
+        *kc = (char *)cs.k + kv_layer; *vc = (char *)cs.v + kv_layer;
+    };
+    for (int64_t l = 0; l < D.L; l++) {
+        LayerW &ly = sh.layers[l];
+        void *kc, *vc;
+        kv_of(l, &kc, &vc);
+        if (l == 0) {                                  // the first QKV projection reads the token's embedding row: the launch of k_gemv.hip
+            GemvArgs a;
+            a.W = ly.wqkv; a.bias = ly.bqkv; a.N = (int)((sh.Hs + 2 * sh.Hkvs) * D.d); a.K = (int)D.h;
+            a.epi = EPI_QKV_ROPE; a.pro = PRO_NORM; a.norm_w = ly.ln1; a.eps = D.eps; a.st = cs.st;
+            a.embed = sh.embed; a.x_out = sc.x_res2;
+            a.cos_tab = sh.cos_tab; a.sin_tab = sh.sin_tab; a.q_out = sc.q; a.k_cache = kc; a.v_cache = vc;
+            a.H = (int)sh.Hs; a.Hkv = (int)sh.Hkvs; a.d = (int)D.d; a.max_seq = (int)c->seq_alloc; a.max_pos = (int)D.max_pos;
+            a.v_ld = (int)c->seq_alloc;
+            FL_TRY(launch_gemv(L, dt, a));
+        }
+        AttnScratch as{cs.part_m, cs.part_l, cs.part_o, cs.counters, c->nsplit, len_hint + 1};
+        FL_TRY(launch_attn_decode_mfma(L, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->seq_alloc, D.scale));
+        const bool last = l + 1 == D.L;
+        float *res_in = (l & 1) ? sc.x_res : sc.x_res2, *res_out = (l & 1) ? sc.x_res2 : sc.x_res;
+        EngArgs e;
+        e.nops = 4; e.h = (int)D.h; e.x_res_in = res_in; e.eps = D.eps; e.st = cs.st; e.st_rw = cs.st; e.epoch = sh.eng_epoch;
+        e.timeout_ticks = timeout_ticks;
+        const int t0 = (int)(4 * l);
+        EngOp &o0 = e.op[0], &o1 = e.op[1], &o2 = e.op[2], &o3 = e.op[3];
+        o0.W = ly.wo; o0.N = (int)D.h; o0.K = (int)(sh.Hs * D.d); o0.in = ENG_IN_X; o0.x = sc.ao; o0.out = ENG_OUT_EDGE_F32; o0.out_edge = sh.eng_edge[0]; o0.tag_out = t0 + 1;
+        o1.W = ly.wgu; o1.N = (int)(2 * sh.Ip); o1.K = (int)D.h; o1.in = ENG_IN_NORM; o1.norm_w = ly.ln2; o1.in_edge = sh.eng_edge[0]; o1.tag_in = t0 + 1;
+        o1.out = ENG_OUT_EDGE_ACT; o1.out_edge = sh.eng_edge[1]; o1.tag_out = t0 + 2;
+        o2.W = ly.wd; o2.N = (int)D.h; o2.K = (int)sh.Ip; o2.in = ENG_IN_ACT; o2.in_edge = sh.eng_edge[1]; o2.tag_in = t0 + 2;
+        o2.out = ENG_OUT_EDGE_F32; o2.out_edge = sh.eng_edge[2]; o2.tag_out = t0 + 3;
+        o3.K = (int)D.h; o3.in = ENG_IN_NORM; o3.in_edge = sh.eng_edge[2]; o3.tag_in = t0 + 3;
+        if (!last) {
+            LayerW &nx = sh.layers[l + 1];
+            void *kn, *vn;
+            kv_of(l + 1, &kn, &vn);
+            o3.W = nx.wqkv; o3.N = (int)((sh.Hs + 2 * sh.Hkvs) * D.d); o3.norm_w = nx.ln1; o3.bias = nx.bqkv; o3.out = ENG_OUT_QKV; o3.res_out = res_out;
+            e.cos_tab = sh.cos_tab; e.sin_tab = sh.sin_tab; e.q_out = sc.q; e.k_cache = kn; e.v_cache = vn;
+            e.H = (int)sh.Hs; e.Hkv = (int)sh.Hkvs; e.d = (int)D.d; e.max_seq = (int)c->seq_alloc; e.max_pos = (int)D.max_pos; e.v_ld = (int)c->seq_alloc;
+        } else {
+            o3.W = sh.lm_head; o3.N = (int)sh.Vs; o3.norm_w = sh.norm; o3.out = ENG_OUT_LOGITS; o3.dst = sh.logits_full;
+            if (env_int("FL_ARGMAX_FUSED", 1)) { e.amax = sh.amax; sh.amax_valid = true; }
+        }
+        FL_TRY(launch_engine(L, e));
+    }
+    return FL_OK;
+}
+
 static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
+    if (engine_usable(m, c)) return enqueue_decode_engine(m, c, len_hint);
     const Dims &D = m->D;
     const int dt = m->dtype;
     const size_t ns = m->shards.size();
@@ -1054,7 +1137,7 @@ static int enqueue_argmax(Model *m, Cache *c, int advance) {
         FL_HIP(hipSetDevice(sh.device));
         Launcher L = make_launcher(m, sh);
         FL_TRY(launch_select_advance(L, sh.logits_full, m->D.V, c->shards[i].st, c->shards[i].ss, c->shards[i].sel_scratch, c->shards[i].out_tokens, advance,
-                                     sh.amax_valid ? sh.amax : nullptr));
+                                     sh.amax_valid ? sh.amax : nullptr, sh.eng_epoch));
     }
     return FL_OK;
 }
