@@ -37,6 +37,14 @@ def main():
             if np.all(np.isnan(col)):
                 continue
             print("  op %d  %-36s %7.2f | %7.2f" % (o, names[slot], np.nanmedian(np.nanmedian(col, axis=1)), np.nanmedian(np.nanmax(col, axis=1))))
+    for o in range(nops):
+        col = arr[:, :, 16 + o]
+        if not np.all(np.isnan(col)):
+            print("  op %d  %-36s %7.2f | %7.2f" % (o, "loader 0 requests the op's first block", np.nanmedian(np.nanmedian(col, axis=1)), np.nanmedian(np.nanmax(col, axis=1))))
+    for slot, what in ((20, "loader 0: all requested"), (21, "loader 0: all landed"), (22, "loader 0: us blocked on a full ring"), (23, "loader 0: us in thin mode waits")):
+        col = arr[:, :, slot]
+        if not np.all(np.isnan(col)):
+            print("        %-36s %7.2f | %7.2f" % (what, np.nanmedian(np.nanmedian(col, axis=1)), np.nanmedian(np.nanmax(col, axis=1))))
     end = arr[:, :, 31]
     print("  end   %-36s %7.2f | %7.2f" % ("workgroup exit", np.nanmedian(np.nanmedian(end, axis=1)), np.nanmedian(np.nanmax(end, axis=1))))
 
