@@ -250,6 +250,7 @@ def main():
     # The level that ran is reported in the JSON line (config.tp_fallback_level).
     os.environ.setdefault("FL_AR_TIMEOUT_MS", "5000")
     fallback_level, model = 0, None
+    fallback_log = []                                # why a level was abandoned: (level, rank, error) of every rank that failed it
     for level in range(int(os.environ.get("FL_BENCH_START_LEVEL", "0")), 3):      # (tests start at a later level)
         if level >= 1:
             os.environ["FL_TP_FUSED_AR"] = "0"
@@ -259,7 +260,7 @@ def main():
         model = build_model()
         if world == 1:
             break
-        failed, hc = 0, None
+        failed, hc, why = 0, None, None
         try:
             hp = np.random.RandomState(7).randint(0, cfg["vocab_size"], size=max(T, 8)).astype(np.uint32)
             hc = model.new_cache(len(hp) + 16)
@@ -269,13 +270,17 @@ def main():
             model.decode_greedy(hc, hf, len(hp), 4)
             model.synchronize()
         except Exception as e:                                                # noqa: the point is to survive it
-            failed = 1
+            failed, why = 1, repr(e)
             log("rank %d: tensor-parallel health check failed at level %d: %r" % (rank, level, e))
         finally:
             if hc is not None:
                 hc.close()
         ft = torch.tensor([failed], dtype=torch.int32)
         dist.all_reduce(ft, op=dist.ReduceOp.MAX)
+        if int(ft[0]) != 0:
+            whys = [None] * world
+            dist.all_gather_object(whys, why)
+            fallback_log += [{"level": level, "rank": r, "error": w} for r, w in enumerate(whys) if w]
         if int(ft[0]) == 0:
             fallback_level = level
             break
@@ -294,6 +299,23 @@ def main():
     if info.fused_all_reduce:
         collectives += "; decode all-reduces fused into the o_proj/down_proj GEMV epilogues (comm_ll.h)"
     log("decode collectives:", collectives)
+    # the decode step's all-reduce ([h] fp32 after o_proj / down_proj) timed alone on this group's links, one form at a time
+    # (fl_comm_probe; max over ranks): what a step's 2 L collectives cost by the form that carries them
+    allreduce_us = None
+    if world > 1:
+        allreduce_us = {}
+        for form, name in ((0, "rccl"), (1, "oneshot_kernel"), (2, "fused_in_gemv_epilogue")):
+            try:
+                us = model.comm_probe(form, cfg["hidden_size"], 32)
+            except Exception as e:                                            # noqa: a probe must not take the bench down
+                log("rank %d: comm_probe(%s) failed: %r" % (rank, name, e))
+                us = None
+            vals = [None] * world
+            dist.all_gather_object(vals, us)
+            allreduce_us[name] = None if any(v is None for v in vals) else round(max(vals), 2)
+        allreduce_us["n_floats"] = cfg["hidden_size"]
+        allreduce_us["per_step"] = 2 * cfg["num_hidden_layers"]
+        log("decode all-reduce, us per call:", allreduce_us)
 
     # ---- parity gate: no timing counts before the HIP path has matched the oracle on this box ----
     parity = None
@@ -433,6 +455,14 @@ def main():
         except Exception as e:                                               # the headline line must not depend on it
             log("batched decode leg failed:", repr(e))
 
+    # every rank's own kernel times (a tensor-parallel step is as slow as its slowest rank's launches + collectives)
+    per_rank = None
+    if world > 1:
+        mine = {"rank": rank, "kernel_us_per_step": round(sum(s_["total_ms"] for s_ in stats) * 1e3 / n_prof, 1),
+                "kernels": [{"name": s_["name"], "launches_per_step": s_["launches"] / n_prof,
+                             "us_per_launch": round(s_["total_ms"] * 1e3 / s_["launches"], 2)} for s_ in stats]}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank == 0:
         tok_s = K / elapsed
         kv_mid = T + K // 2
@@ -465,7 +495,9 @@ def main():
             "config": {"workload": "%s bf16 greedy decode, %d-token prompt, %d generated tokens, batch 1, TP=%d"
                                    % (args.model, T, K, world), "kv_len": "%d..%d" % (T, T + K),
                        "parallelism": "tp%d" % world, "collectives": collectives, "tp_fallback_level": fallback_level,
-                       "rccl_ranks": int(info.rccl_ranks)},
+                       "rccl_ranks": int(info.rccl_ranks), "tp_fallback_log": fallback_log},
+            "allreduce_us": allreduce_us,
+            "per_rank": per_rank,
             "roofline": roof,
             "cpu_baseline": cpu,
             "e2e_hbm": {"bytes_per_token": b_tok, "achieved_GBps": round(tok_s * b_tok / world / 1e9, 1),

@@ -106,6 +106,7 @@ def lib():
         L.fl_profile_begin.argtypes = [vp]
         L.fl_profile_end.argtypes = [vp, C.POINTER(FlKernelStat), sz, C.POINTER(sz)]
         L.fl_tune.argtypes = [C.c_char_p, C.c_int]
+        L.fl_comm_probe.argtypes = [vp, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
         L.fl_op_linear.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int32,
                                    C.POINTER(C.c_double)]
         _LIB = L
@@ -269,6 +270,13 @@ class Model:
         blob = b"".join(bytes(h) for h in handles)
         buf = C.create_string_buffer(blob, len(blob))
         _check(lib().fl_comm_ipc_connect(self._h, buf))
+
+    def comm_probe(self, form, n, iters=64):
+        """us per decode-sized all-reduce on this group's links: form 0 RCCL, 1 one-shot kernel, 2 fused into the GEMV epilogue
+        (None: not available).  Collective: every rank calls it."""
+        us = C.c_double(-1.0)
+        _check(lib().fl_comm_probe(self._h, form, n, iters, C.byref(us)))
+        return None if us.value < 0 else us.value
 
     def profile_begin(self):
         _check(lib().fl_profile_begin(self._h))

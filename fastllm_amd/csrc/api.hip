@@ -234,6 +234,13 @@ int fl_synchronize(fl_model *m) {
     });
 }
 
+int fl_comm_probe(fl_model *m, int32_t form, int64_t n, int32_t iters, double *us_per_call) {
+    return guarded([&]() -> int {
+        if (!m) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null model");
+        return comm_probe(M(m), form, n, iters, us_per_call);
+    });
+}
+
 int fl_tp_slice(const fl_config *cfg, const char *tensor_name, int32_t tp_rank, int32_t tp_size, int64_t out[4]) {
     return guarded([&]() -> int {
         if (!tensor_name || !out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");

@@ -206,6 +206,58 @@ int comm_bootstrap_over_rccl(Model *m) {
     return finish(FL_OK);
 }
 
+// fl_comm_probe: `iters` all-reduces of n floats back to back on the shard's stream, HIP events around the batch.
+int comm_probe(Model *m, int form, int64_t n, int iters, double *us_per_call) {
+    if (!m || !us_per_call || iters < 1 || iters > 100000 || n < 1) FL_FAIL(FL_ERR_BAD_ARGUMENT, "comm_probe: bad arguments");
+    *us_per_call = -1.0;
+    if (m->tp_mode != FL_TP_MULTI_PROCESS || m->shards.size() != 1) return FL_OK;            // one process per GPU only
+    std::lock_guard<std::mutex> lock(m->mu);
+    Shard &sh = m->shards[0];
+    PeerComm &pc = sh.pc;
+    if (n > m->D.h) FL_FAIL(FL_ERR_BAD_ARGUMENT, "comm_probe: at most hidden_size values");
+    if ((form == 0 && !sh.comm) || (form == 1 && (!pc.connected || n > pc.nmax)) || (form == 2 && (!pc.connected || !pc.ll_ok || pc.shares_device)) || form < 0 || form > 2)
+        return FL_OK;
+    FL_HIP(hipSetDevice(sh.device));
+    float *buf = sh.dec.delta;                                   // [h] fp32 scratch of the decode step
+    FL_HIP(hipMemsetAsync(buf, 0, (size_t)n * 4, sh.stream));
+    hipEvent_t e0, e1, e2;
+    FL_HIP(hipEventCreate(&e0)); FL_HIP(hipEventCreate(&e1)); FL_HIP(hipEventCreate(&e2));
+    Launcher L = make_launcher(m, sh);
+    L.prof = nullptr;
+    int rc = FL_OK;
+    auto one = [&](int f, int slot) -> int {
+        if (f == 0) { FL_NCCL(ncclAllReduce(buf, buf, (size_t)n, ncclFloat, ncclSum, sh.comm, sh.stream)); return FL_OK; }
+        if (f == 1) return oneshot(m, sh, false, buf, buf, n, 0);
+        return launch_ll_allreduce(L, pc.ll_dev, slot, buf, buf, n);
+    };
+    const int slots = (int)(2 * m->D.L);
+    for (int w = 0; w < 2 && rc == FL_OK; w++) {                 // w = 0: warm-up
+        FL_HIP(hipEventRecord(e0, sh.stream));
+        if (form == 2) {
+            // a decode step's pattern: 2 L exchanges (slots 1 .. 2 L), then one one-shot collective moves the epoch
+            for (int i = 0; i < iters && rc == FL_OK; i++) {
+                for (int s2 = 1; s2 <= slots && rc == FL_OK; s2++) rc = one(2, s2);
+                if (rc == FL_OK) rc = one(1, 0);
+            }
+            FL_HIP(hipEventRecord(e1, sh.stream));
+            for (int i = 0; i < iters && rc == FL_OK; i++) rc = one(1, 0);
+            FL_HIP(hipEventRecord(e2, sh.stream));
+        } else {
+            for (int i = 0; i < iters && rc == FL_OK; i++) rc = one(form, 0);
+            FL_HIP(hipEventRecord(e1, sh.stream));
+            FL_HIP(hipEventRecord(e2, sh.stream));
+        }
+        FL_HIP(hipStreamSynchronize(sh.stream));
+    }
+    float ms01 = 0.f, ms12 = 0.f;
+    if (rc == FL_OK) { FL_HIP(hipEventElapsedTime(&ms01, e0, e1)); FL_HIP(hipEventElapsedTime(&ms12, e1, e2)); }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    FL_TRY(rc);
+    if (pc.err && *pc.err) FL_FAIL(FL_ERR_RCCL, "comm_probe: a wait gave up (code 0x%x)", *pc.err);
+    *us_per_call = form == 2 ? (double)(ms01 - ms12) * 1e3 / ((double)iters * slots) : (double)ms01 * 1e3 / iters;
+    return FL_OK;
+}
+
 int comm_check(Model *m) {
     for (auto &sh : m->shards)
         if (sh.pc.err && *sh.pc.err) FL_FAIL(FL_ERR_RCCL, "one-shot collective gave up waiting for a peer (code 0x%x): the tensor-parallel group is broken", *sh.pc.err);

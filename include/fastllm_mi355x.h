@@ -256,6 +256,13 @@ typedef struct fl_kernel_stat {
 int fl_profile_begin(fl_model *m);
 int fl_profile_end(fl_model *m, fl_kernel_stat *stats, size_t cap, size_t *n_stats);
 
+/* Times the small all-reduce of a decode step (n fp32 values, n <= hidden_size) on the links the group really has, one form at a
+ * time: form 0 = ncclAllReduce (RCCL), 1 = the one-shot kernel over peer-mapped HBM (k_comm.hip), 2 = the exchange that rides in
+ * the GEMV epilogues (comm_ll.h; timed through its stand-alone exerciser, one-shot epoch steps subtracted).  Collective: every
+ * rank of the group calls it with the same arguments.  *us_per_call < 0: that form is not available in this group.
+ * (the decode all-reduce after o_proj / down_proj; bench.py --gpus N reports the three side by side.) */
+int fl_comm_probe(fl_model *m, int32_t form, int64_t n, int32_t iters, double *us_per_call);
+
 /* Tuning knobs of the decode weight-streaming kernel (sweeps in tools/; not needed in normal use):
  * "gemv_r" rows per wave pass (2|4), "gemv_u" 512-element chunks per pipeline block (2|4|8),
  * "gemv_blocks" / "gemv_waves": force the grid and the waves per workgroup (0 = automatic). */
