@@ -53,36 +53,35 @@ impl<const FAMILY: i32> std::fmt::Debug for Mi355xWithConfig<FAMILY> {
     }
 }
 
-/// Caller-owned KV cache plus the reference's per-call counter (cache.rs:5-42).
+/// Caller-owned KV cache plus the per-request call counter the trait asks for (`ModelCache`, cache.rs:5-13: bump, clear,
+/// read, downcast).  The counter counts `forward` calls since the last `reset`; the KV handle is cleared with it.
 pub struct Mi355xCache {
     kv: mi::Cache,
-    seqlen_offset: usize,
+    calls: usize,
 }
 
 impl std::fmt::Debug for Mi355xCache {
     fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
-        write!(f, "Mi355xCache {{ len: {}, seqlen_offset: {} }}", self.kv.len(), self.seqlen_offset)
+        f.debug_struct("Mi355xCache").field("cached_positions", &self.kv.len()).field("calls", &self.calls).finish()
     }
 }
 
 impl ModelCache for Mi355xCache {
     fn increment_offset(&mut self) {
-        self.seqlen_offset += 1;
-        tracing::debug!("Cache seqlen_offset incremented to {}", self.seqlen_offset);
+        self.calls = self.calls.saturating_add(1);
     }
 
     fn reset(&mut self) {
-        self.seqlen_offset = 0;
         self.kv.reset();
-        tracing::debug!("Cache reset");
+        self.calls = 0;
     }
 
     fn get_offset(&self) -> usize {
-        self.seqlen_offset
+        self.calls
     }
 
     fn as_any_mut(&mut self) -> &mut dyn Any {
-        self
+        self as &mut dyn Any
     }
 }
 
@@ -175,7 +174,7 @@ impl<const FAMILY: i32> ModelInitializer for Mi355xWithConfig<FAMILY> {
             info.hbm_bytes_allocated as f64 / 1e9,
             max_seq
         );
-        let cache = Mi355xCache { kv: model.new_cache(max_seq).map_err(|e| anyhow!("{}", e))?, seqlen_offset: 0 };
+        let cache = Mi355xCache { kv: model.new_cache(max_seq).map_err(|e| anyhow!("{}", e))?, calls: 0 };
         Ok((Self { model }, cache))
     }
 
@@ -183,7 +182,7 @@ impl<const FAMILY: i32> ModelInitializer for Mi355xWithConfig<FAMILY> {
         let guard = current().lock().unwrap();
         let (model, max_seq) = guard.as_ref().ok_or_else(|| anyhow!("MI355X backend: initialize_cache before initialize_model"))?;
         let kv = model.new_cache(*max_seq).map_err(|e| anyhow!("MI355X backend: KV cache allocation failed: {}", e))?;
-        Ok(Mi355xCache { kv, seqlen_offset: 0 })
+        Ok(Mi355xCache { kv, calls: 0 })
     }
 
     fn forward(&self, input: &Tensor, pos: usize, cache: &mut Self::Cache) -> Result<Tensor> {
@@ -192,10 +191,10 @@ impl<const FAMILY: i32> ModelInitializer for Mi355xWithConfig<FAMILY> {
         let rope_pos = if FAMILY == LLAMA {
             pos
         } else {
-            if cache.seqlen_offset == 0 {
+            if cache.calls == 0 {
                 cache.kv.reset(); // clear_kv_cache (mistral.rs:218-221, qwen.rs:146-149)
             }
-            cache.seqlen_offset
+            cache.calls
         };
         let logits = self
             .model
