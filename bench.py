@@ -483,10 +483,18 @@ def main():
                 tj = json.load(open(tfs[-1]))
                 traffic = round(tj["hbm_bytes_per_launch"])
                 tsrc = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, separate runs, gfx950 x2 read correction)" % os.path.relpath(tfs[-1], ROOT)
+            # the same figure as rocprofv3 saw it when the committed profile was collected (tools/rocprof_gemv.py)
+            rocprof = None
+            rfs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "rocprof_gemv.json")))
+            if rfs and args.model == "mistral-7b" and world == 1:
+                rj = json.load(open(rfs[-1]))
+                rocprof = {"avg_launch_us": rj["avg_launch_us"], "achieved": rj["achieved_GBps"], "frac": rj["frac"],
+                           "source": os.path.relpath(rfs[-1], ROOT) + " (rocprofv3 --kernel-trace --stats of bench.py, collected with the committed profile)"}
             roof = {"bound": "hbm", "kernel": "gemv_kernel<bf16> (QKV/O/gate-up/down/lm_head weight stream)",
                     "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
                     "traffic": traffic, "traffic_source": tsrc, "launches_per_step": gemv["launches"] // n_prof,
-                    "bytes_per_launch": round(gemv["bytes"] / gemv["launches"]), "avg_launch_us": round(avg_ms * 1e3, 2)}
+                    "bytes_per_launch": round(gemv["bytes"] / gemv["launches"]), "avg_launch_us": round(avg_ms * 1e3, 2),
+                    "rocprof": rocprof}
         total_prof_ms = sum(s["total_ms"] for s in stats)
         out = {
             "metric": "decode_tokens_per_sec", "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world,
