@@ -56,6 +56,24 @@ def test_linear_plain(fa, T, N, K, dtype):
     np.testing.assert_allclose(y, ref, atol=tol, rtol=1e-5)
 
 
+@pytest.mark.parametrize("T,N,K", [(1, 6144, 4096), (1, 4096, 14336), (1, 3584, 4736), (8, 4096, 4096), (64, 2048, 5632), (128, 11264, 2048),
+                                   (512, 6144, 4096), (512, 4096, 14336), (512, 28672, 4096), (1100, 4096, 4096), (2050, 16400, 128),
+                                   (4100, 4608, 3584), (4096, 3584, 2048)])
+def test_linear_bit_exact_on_small_integers(fa, T, N, K):
+    """Production bf16 kernels (stream GEMV, short-prompt GEMM, 256x256 with K slices / peeled stream-K tails, 256x128, 128x128)
+    on integer-valued operands: every product and every partial sum is an integer below 2^24, so fp32 accumulation is EXACT in
+    any order and the result must equal the integer reference bit for bit -- a tiling, indexing or K-slice error cannot hide in a
+    tolerance."""
+    rs = np.random.RandomState(T * 31 + N * 7 + K)
+    x = rs.randint(-3, 4, size=(T, K)).astype(np.float32)
+    w = rs.randint(-3, 4, size=(N, K)).astype(np.float32)
+    assert K * 9 < 2 ** 24
+    y = fa.op_linear(synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w), None)
+    ref = x.astype(np.int64) @ w.astype(np.int64).T
+    np.testing.assert_array_equal(y.astype(np.int64), ref)
+    assert (y == ref.astype(np.float32)).all()
+
+
 @pytest.mark.parametrize("T,I,K", [(1, 352, 256), (1, 14336, 4096), (1, 40, 64), (9, 352, 256), (200, 704, 512),
                                    (128, 1792, 1024), (3, 24, 48), (1025, 13000, 192)])
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
