@@ -298,6 +298,20 @@ int launch_attn_oproj(Launcher &L, const void *q, const void *k_cache, const voi
                       int nsplit, int attn_waves /* 1..8: 32 keys each per split and step */, int64_t kv_len_hint, const void *Wo, float *slabs /* [Hkv][h] */, int64_t H, int64_t Hkv, int64_t d,
                       int64_t h, int64_t seq_alloc, float scale);
 
+// decode attention + o_proj in one launch for SHORT caches (k_attn_rep.hip): every workgroup computes the attention of all heads
+// itself (K / V from L2) while its rows of W_o stream in; out = W_o . attention (fp32 [N]), or summed over the ranks (ll)
+struct AttnRepArgs {
+    const void *q = nullptr, *kc = nullptr, *vT = nullptr;     // q [H*d] bf16; K cache [Hkv][seq_alloc][d]; V^T cache [Hkv][d][seq_alloc]
+    const StepState *st = nullptr;
+    const void *Wo = nullptr;                                  // [N, K = H*d] bf16
+    float *out = nullptr;
+    int H = 0, Hkv = 0, seq_alloc = 0, N = 0, K = 0;
+    float scale = 0.f;
+    const LLTable *ll = nullptr; int ll_slot = 0;
+};
+bool attn_oproj_rep_supported(int64_t H, int64_t Hkv, int64_t d, int64_t h, int64_t max_seq);
+int launch_attn_oproj_rep(Launcher &L, const AttnRepArgs &a);
+
 // ---- weight conversion at model build ---------------------------------------------------------
 // dst[row_map(r)][c] = cvt(src[r0+r][c0+c]); row_mode 0: dst_row0+r, 1: gate rows, 2: up rows
 int launch_convert_slice(Launcher &L, int src_dtype, const void *src, int64_t src_ld, int64_t r0, int64_t c0,

@@ -137,6 +137,7 @@ struct Cache {
     size_t max_seq = 0, len = 0;
     size_t seq_alloc = 0;        // max_seq rounded up to 32: row stride of K / column stride of V^T
     bool v_transposed = false;   // bf16 MFMA attention: value cache stored [Hkvs][d][seq_alloc]
+    bool rep_attn = false;       // short cache: decode attention replicated inside the o_proj launch (k_attn_rep.hip)
     bool fuse_oproj = false;     // this cache's decode steps use the fused attention+o_proj launch
     int ao_nsplit = 0, ao_waves = 4;   // ... with this many key splits per kv head, 32 * ao_waves keys per split and step
     int nsplit = 1;

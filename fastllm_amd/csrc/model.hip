@@ -632,6 +632,10 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
             c->ao_nsplit = ns8; c->ao_waves = aw;
         }
     }
+    // short caches: attention replicated in every workgroup of the o_proj launch (k_attn_rep.hip): one launch and one dependent
+    // step fewer per layer; FL_ATTN_REP=0 keeps the two launches
+    c->rep_attn = env_int("FL_ATTN_REP", 1) != 0 && m->fused_decode && c->v_transposed && !c->fuse_oproj && m->dtype == FL_DTYPE_BF16 &&
+                  attn_oproj_rep_supported(m->shards[0].Hs, m->shards[0].Hkvs, D.d, D.h, (int64_t)c->seq_alloc);
     c->shards.resize(m->shards.size());
     for (size_t i = 0; i < m->shards.size(); i++) {
         Shard &sh = m->shards[i]; CacheShard &cs = c->shards[i];
@@ -875,6 +879,12 @@ static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
             if (c->fuse_oproj) {
                 FL_TRY(launch_attn_oproj(L, sc.q, kc, vc, cs.st, cs.st, cs.ao_part, cs.heads_done + l * sh.Hkvs, c->ao_nsplit, c->ao_waves, len_hint + 1, ly.wo,
                                          sc.delta, sh.Hs, sh.Hkvs, D.d, D.h, (int64_t)c->seq_alloc, D.scale));
+            } else if (c->rep_attn) {
+                AttnRepArgs ra;
+                ra.q = sc.q; ra.kc = kc; ra.vT = vc; ra.st = cs.st; ra.Wo = ly.wo; ra.out = sc.delta;
+                ra.H = (int)sh.Hs; ra.Hkv = (int)sh.Hkvs; ra.seq_alloc = (int)c->seq_alloc; ra.N = (int)D.h; ra.K = (int)(sh.Hs * D.d); ra.scale = D.scale;
+                if (far) { ra.ll = sh.pc.ll_dev; ra.ll_slot = (int)(2 * l + 1); }
+                FL_TRY(launch_attn_oproj_rep(L, ra));
             } else {
                 if (c->v_transposed) FL_TRY(launch_attn_decode_mfma(L, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->seq_alloc, D.scale));
                 else FL_TRY(launch_attn_decode(L, dt, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, (int64_t)c->seq_alloc, D.scale));
