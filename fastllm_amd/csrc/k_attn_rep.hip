@@ -73,12 +73,11 @@ __global__ __launch_bounds__(R_NW * 64) void attn_oproj_rep_kernel(const AttnRep
     for (int t0 = sl; t0 * 32 < S; t0 += nslice * TB) {
         RegKV<D> r[TB];
 #pragma unroll
-        for (int j = 0; j < TB; j++) {
-            // unconditional requests (a branch around a load makes hipcc wait for it where it stands: one round trip per tile
-            // instead of one per burst -- 10.5 us at 140 cached positions against 6.4 at 50); a tile past S reads the cache's
-            // last allocated tile and is not used
-            const int kbase = min((t0 + j * nslice) * 32, a.seq_alloc - 32);
-            r[j].load(kb, vb, a.seq_alloc, kbase, i, g4);
+        for (int j = 0; j < TB; j++) {                       // (keys past S inside the cache's allocation are read and masked)
+            // a tile is requested only if it exists: the unconditional form (every burst TB tiles, clamped) measured SLOWER at
+            // every length but one -- the launch's time follows the bytes a CU requests, not the number of round trips
+            const int kbase = (t0 + j * nslice) * 32;
+            if (kbase < S) r[j].load(kb, vb, a.seq_alloc, kbase, i, g4);
         }
 #pragma unroll
         for (int j = 0; j < TB; j++) {
@@ -142,7 +141,7 @@ __global__ __launch_bounds__(R_NW * 64) void attn_oproj_rep_kernel(const AttnRep
 }
 
 // Would launch_attn_oproj_rep take this shape, with a cache of this capacity?
-bool attn_oproj_rep_supported(int64_t H, int64_t Hkv, int64_t d, int64_t h, int64_t max_seq) {
+bool attn_oproj_rep_supported(int64_t H, int64_t Hkv, int64_t d, int64_t h, int64_t max_seq, bool any_size) {
     if (Hkv < 1 || H % Hkv || R_NW % Hkv) return false;
     const int64_t G = H / Hkv, K = H * d;
     if ((d != 64 && d != 128) || G > 8 || K % 8 || K > 512 * R_KC || h < 1) return false;
@@ -151,6 +150,7 @@ bool attn_oproj_rep_supported(int64_t H, int64_t Hkv, int64_t d, int64_t h, int6
     // requests, not the L2, are the limit), so the launch costs 6.5 us at 64 KB of K / V per layer, 10.3 at 160 KB, 13.7 at 330 KB,
     // against 8.6 us for the two launches it replaces: it pays up to ~96 KB (TinyLlama: 96 cached positions; one rank of an
     // 8-way Mistral-7B: 192), and that is where the host uses it.
+    if (any_size) return (tiles + nslice - 1) / nslice <= 32;          // (FL_ATTN_REP=2: probes)
     return (tiles + nslice - 1) / nslice <= 8 && 2 * Hkv * max_seq * d * 2 <= 96 * 1024;
 }
 
@@ -167,7 +167,7 @@ static int launch_rep_t(Launcher &L, const AttnRepArgs &a, int blocks, size_t ld
 int launch_attn_oproj_rep(Launcher &L, const AttnRepArgs &a) {
     if (!a.q || !a.kc || !a.vT || !a.st || !a.Wo || !a.out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "attn_oproj_rep: null argument");
     const int D = a.K / std::max(1, a.H);
-    if (a.H <= 0 || a.K != a.H * D || !attn_oproj_rep_supported(a.H, a.Hkv, D, a.N, 32)) FL_FAIL(FL_ERR_UNSUPPORTED, "attn_oproj_rep: unsupported shape");
+    if (a.H <= 0 || a.K != a.H * D || !attn_oproj_rep_supported(a.H, a.Hkv, D, a.N, 32, false)) FL_FAIL(FL_ERR_UNSUPPORTED, "attn_oproj_rep: unsupported shape");
     if (a.ll && a.ll_slot <= 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "attn_oproj_rep: fused all-reduce needs its slot");
     // rows per wave: one while that fills the chip's CUs, else two
     const int rpw = a.N > 256 * R_NW ? 2 : 1;

@@ -309,7 +309,7 @@ struct AttnRepArgs {
     float scale = 0.f;
     const LLTable *ll = nullptr; int ll_slot = 0;
 };
-bool attn_oproj_rep_supported(int64_t H, int64_t Hkv, int64_t d, int64_t h, int64_t max_seq);
+bool attn_oproj_rep_supported(int64_t H, int64_t Hkv, int64_t d, int64_t h, int64_t max_seq, bool any_size = false);
 int launch_attn_oproj_rep(Launcher &L, const AttnRepArgs &a);
 
 // ---- weight conversion at model build ---------------------------------------------------------

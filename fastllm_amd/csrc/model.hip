@@ -635,7 +635,7 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
     // short caches: attention replicated in every workgroup of the o_proj launch (k_attn_rep.hip): one launch and one dependent
     // step fewer per layer; FL_ATTN_REP=0 keeps the two launches
     c->rep_attn = env_int("FL_ATTN_REP", 1) != 0 && m->fused_decode && c->v_transposed && !c->fuse_oproj && m->dtype == FL_DTYPE_BF16 &&
-                  attn_oproj_rep_supported(m->shards[0].Hs, m->shards[0].Hkvs, D.d, D.h, (int64_t)c->seq_alloc);
+                  attn_oproj_rep_supported(m->shards[0].Hs, m->shards[0].Hkvs, D.d, D.h, (int64_t)c->seq_alloc, env_int("FL_ATTN_REP", 1) == 2);
     c->shards.resize(m->shards.size());
     for (size_t i = 0; i < m->shards.size(); i++) {
         Shard &sh = m->shards[i]; CacheShard &cs = c->shards[i];
