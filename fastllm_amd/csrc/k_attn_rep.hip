@@ -124,11 +124,13 @@ __global__ __launch_bounds__(R_NW * 64) void attn_oproj_rep_kernel(const AttnRep
             for (int r = 0; r < RPW; r++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) acc[r] = dot2c_bf16(w[r][u][j], xr[j], acc[r]);
+#pragma unroll
+            for (int r = 0; r < RPW; r++) dot2c_settle(acc[r]);       // (a branch follows: the dot-result hazard window must close here)
         }
     }
     float sum[RPW];
 #pragma unroll
-    for (int r = 0; r < RPW; r++) { dot2c_settle(acc[r]); sum[r] = wave_sum(acc[r]); }
+    for (int r = 0; r < RPW; r++) sum[r] = wave_sum(acc[r]);
     if (a.ll) {                                              // row-parallel projection of a tensor-parallel group: summed over the ranks here
         if (row0 < N) ll_allreduce_rows<RPW>(a.ll, a.ll_slot, row0, N, sum, a.out, lane);
         return;

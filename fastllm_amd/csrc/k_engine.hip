@@ -331,6 +331,8 @@ __device__ inline void eng_stream(const EngArgs &a, const EngOp &op, int o, EngC
 #pragma unroll
                     for (int j = 0; j < 4; j++) acc[r] = dot2c_bf16(buf[r][u].v[j], xr[j], acc[r]);
             }
+#pragma unroll
+            for (int r = 0; r < R; r++) dot2c_settle(acc[r]);             // (inside the branch: the hazard window closes before the join)
         } else {
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -340,9 +342,9 @@ __device__ inline void eng_stream(const EngArgs &a, const EngOp &op, int o, EngC
 #pragma unroll
                     for (int j = 0; j < 4; j++) acc[r] = dot2c_bf16(buf[r][u].v[j], xr[j], acc[r]);
             }
-        }
 #pragma unroll
-        for (int r = 0; r < R; r++) dot2c_settle(acc[r]);
+            for (int r = 0; r < R; r++) dot2c_settle(acc[r]);
+        }
         if (++cb == nb) { finish_group(cg); cb = 0; cg += nw; }
     };
     int t = 0;
