@@ -15,6 +15,7 @@
 //   llama::ConfigFile, LlamaCache, LlamaWithConfig         same names (llama.rs:18-159)
 //   mistral::ConfigFile, MistralCache, MistralWithConfig   same names (mistral.rs:16-247)
 //   QwenCache, QwenWithConfig                              same names (qwen.rs:13-184)
+//   generate_stream / generate_tokens_inner (mod.rs:137-340)   Model<M>::generate_stream_ids (per-stream cache, token callback)
 //   Model<M>::generate (mod.rs:363-463)                    Model<M>::generate_ids (token ids in/out;
 //                                                          the tokenizer is outside the hot path)
 //
@@ -534,6 +535,35 @@ struct Model {                                // mod.rs:342-361
             pos += 1;                                                      // mod.rs:452
         }
         return output_ids;
+    }
+
+    // ModelWrapper::generate_stream + generate_tokens_inner (mod.rs:137-238, 268-340) on token ids: the model is CLONED (a
+    // reference-count bump, mod.rs:155), the stream gets a FRESH cache of its own (mod.rs:156: this object's `cache` is not
+    // touched, so several streams may run on one model at once, each from its own thread -- the reference spawns a task per
+    // stream), a seed-0 LogitsProcessor (mod.rs:157-158), and every sampled token goes to `on_token` before the next forward
+    // (mod.rs:323-325); `on_token` returning false is the dropped receiver (`tx.send(..).is_err()` -> break).  EOS stops the
+    // stream before the token is emitted (mod.rs:312-316).  Returns the number of forwards executed (the one behind the last
+    // emitted token included, as in the reference's loop).
+    template <class OnToken>
+    size_t generate_stream_ids(const std::vector<uint32_t> &prompt, size_t max_tokens, float temperature,
+                               std::optional<uint32_t> eos, OnToken &&on_token) const {
+        M shared = model;                                                  // Arc::new(RwLock::new(model.model.clone()))
+        typename M::Cache own = M::initialize_cache(device, dtype);       // one cache per stream
+        LogitsProcessor logits_processor(0, (double)temperature);
+        if (prompt.empty()) throw Error(FL_ERR_BAD_ARGUMENT, "Tokenization error: empty prompt");
+        Tensor input = Tensor::from_ids(prompt);                           // mod.rs:283-291
+        size_t pos = 0, n_forwards = 0;
+        Tensor logits = shared.forward(input, pos, own); n_forwards++;     // mod.rs:296-298
+        pos += prompt.size();
+        for (size_t i = 0; i < max_tokens; i++) {                          // mod.rs:303
+            const uint32_t next = logits_processor.sample(logits.f32(), (size_t)logits.elem_count());   // mod.rs:305-310
+            if (eos && next == *eos) break;                                // mod.rs:312-316
+            if (!on_token(next)) break;                                    // mod.rs:323-325
+            Tensor next_input = Tensor::from_ids({next});                  // mod.rs:328-331
+            logits = shared.forward(next_input, pos, own); n_forwards++;   // mod.rs:333-335
+            pos += 1;
+        }
+        return n_forwards;
     }
 };
 

@@ -149,6 +149,26 @@ int flh_generate(void *hv, const uint32_t *prompt, size_t T, size_t max_tokens, 
     });
 }
 
+// ModelWrapper::generate_stream / generate_tokens_inner on token ids (mod.rs:137-238, 268-340): a stream of its own on the shared
+// model -- fresh cache, seed-0 sampler, one callback per token; the callback returning 0 is the dropped receiver.
+// Thread-safe for concurrent calls on one handle (each call owns its cache).
+int flh_generate_stream(void *hv, const uint32_t *prompt, size_t T, size_t max_tokens, float temperature, int64_t eos,
+                        int (*on_token)(uint32_t token, void *user), void *user, size_t *forwards) {
+    return guard([&] {
+        const Handle *h = static_cast<const Handle *>(hv);
+        if (!on_token) throw Error(FL_ERR_BAD_ARGUMENT, "null token callback");
+        std::vector<uint32_t> p(prompt, prompt + T);
+        std::optional<uint32_t> e = eos >= 0 ? std::optional<uint32_t>((uint32_t)eos) : std::nullopt;
+        auto cb = [&](uint32_t t) { return on_token(t, user) != 0; };
+        size_t fw = 0;
+        if (h->llama) fw = h->llama->generate_stream_ids(p, max_tokens, temperature, e, cb);
+        else if (h->mistral) fw = h->mistral->generate_stream_ids(p, max_tokens, temperature, e, cb);
+        else fw = h->qwen->generate_stream_ids(p, max_tokens, temperature, e, cb);
+        if (forwards) *forwards = fw;
+        return 0;
+    });
+}
+
 // LogitsProcessor::new(seed, temperature, None) / .sample (mod.rs:373-374,425-428); has_temperature 0 = None
 int flh_logits_processor_new(uint64_t seed, int has_temperature, double temperature, void **out) {
     return guard([&] {

@@ -143,3 +143,71 @@ def test_rccl_plumbing_single_rank(monkeypatch, oneshot, graph):
     c0 = plain.new_cache(32)
     plain.forward(c0, ids[:9], 0); plain.forward(c0, ids[9:], 9)
     np.testing.assert_array_equal(m.decode_greedy(c, 3, 10, 5), plain.decode_greedy(c0, 3, 10, 5))
+
+
+TOKEN_CB = C.CFUNCTYPE(C.c_int, C.c_uint32, C.c_void_p)
+
+
+def generate_stream(host, h, prompt, n, eos=-1, temperature=0.0, stop_after=None):
+    """flh_generate_stream: tokens as the callback receives them; stop_after = the receiver hangs up after that many"""
+    prompt = np.ascontiguousarray(prompt, dtype=np.uint32)
+    got = []
+
+    def on_token(tok, _user):
+        got.append(int(tok))
+        return 0 if stop_after is not None and len(got) >= stop_after else 1
+    cb = TOKEN_CB(on_token)
+    fw = C.c_size_t(0)
+    host.flh_generate_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, C.c_int64, TOKEN_CB, C.c_void_p, C.POINTER(C.c_size_t)]
+    rc = host.flh_generate_stream(h, prompt.ctypes.data, prompt.size, n, temperature, eos, cb, None, C.byref(fw))
+    assert rc == 0, host.flh_last_error()
+    return np.array(got, dtype=np.uint32), fw.value
+
+
+@pytest.mark.parametrize("name", ["llama_a", "mistral_a", "qwen2_a"])
+def test_generate_stream_matches_generate_and_the_oracle(host, name, monkeypatch):
+    """generate_stream / generate_tokens_inner (mod.rs:137-238, 268-340): the stream's tokens are generate()'s tokens, one
+    callback per token before the next forward; a receiver that hangs up ends the loop before another forward; EOS ends it
+    before the token is emitted."""
+    monkeypatch.setenv("FASTLLM_POS_MODE", "reference")
+    monkeypatch.setenv("FASTLLM_MAX_SEQ", "64")
+    h, cfg, w = make(host, name, dtype=0)
+    om = oracle.OracleModel(cfg, synth.as_f32(w))
+    prompt = synth.prompt_ids(cfg, 8)
+    want = om.generate(om.new_cache(64), prompt, 12, pos_mode="reference")
+    got, fw = generate_stream(host, h, prompt, 12)
+    np.testing.assert_array_equal(got, want)
+    assert fw == 1 + 12
+    np.testing.assert_array_equal(generate(host, h, prompt, 12)[0], want)          # the blocking path is untouched by a stream
+    part, fw = generate_stream(host, h, prompt, 12, stop_after=5)
+    np.testing.assert_array_equal(part, want[:5])
+    assert fw == 1 + 4                                                             # no forward behind the token nobody received
+    eos = int(want[3])
+    cut, fw = generate_stream(host, h, prompt, 12, eos=eos)
+    first = int(np.flatnonzero(want == eos)[0])
+    np.testing.assert_array_equal(cut, want[:first])
+    assert fw == 1 + first
+    host.flh_model_destroy(h)
+
+
+def test_concurrent_streams_share_one_model(host, monkeypatch):
+    """The reference spawns one task per stream over a clone of the model (mod.rs:155-160): two streams from two threads on ONE
+    handle, different prompts, each with its own cache -- the same tokens as one after the other."""
+    import threading
+    monkeypatch.setenv("FASTLLM_POS_MODE", "tokens")
+    monkeypatch.setenv("FASTLLM_MAX_SEQ", "96")
+    h, cfg, w = make(host, "mistral_a", dtype=1)
+    prompts = [synth.prompt_ids(cfg, 8, seed=s) for s in (3, 4, 5, 6)]
+    alone = [generate_stream(host, h, p, 40)[0] for p in prompts]
+    res = [None] * len(prompts)
+
+    def run(i):
+        res[i] = generate_stream(host, h, prompts[i], 40)[0]
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(len(prompts))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for a, b in zip(alone, res):
+        np.testing.assert_array_equal(a, b)
+    host.flh_model_destroy(h)
