@@ -441,7 +441,11 @@ int launch_engine(Launcher &L, const EngArgs &a_in) {
         const EngOp &op = a.op[o];
         if (op.N <= 0 || op.K < 8 || op.K % 8 || !op.W) FL_FAIL(FL_ERR_BAD_ARGUMENT, "engine: bad shape of op %d", o);
         if (op.in == ENG_IN_X ? !op.x : !op.in_edge) FL_FAIL(FL_ERR_BAD_ARGUMENT, "engine: op %d has no input", o);
-        if (op.in == ENG_IN_NORM && (!op.norm_w || op.K != a.h)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "engine: op %d: the norm prologue runs over the residual stream", o);
+        if (op.in == ENG_IN_NORM && (!op.norm_w || op.K != a.h || !a.x_res_in || o == 0)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "engine: op %d: the norm prologue runs over the residual stream behind an edge", o);
+        if (op.in == ENG_IN_ACT && (o == 0 || a.op[o - 1].out != ENG_OUT_EDGE_ACT || a.op[o - 1].N != 2 * op.K)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "engine: op %d: the activation edge follows a gate/up op of twice its width", o);
+        if (o > 0 && op.in == ENG_IN_X) FL_FAIL(FL_ERR_BAD_ARGUMENT, "engine: only the first op reads a plain vector");
+        if (o > 0 && op.in == ENG_IN_NORM && (a.op[o - 1].out != ENG_OUT_EDGE_F32 || a.op[o - 1].N != op.K || a.op[o - 1].out_edge != op.in_edge || a.op[o - 1].tag_out != op.tag_in))
+            FL_FAIL(FL_ERR_BAD_ARGUMENT, "engine: op %d does not read the edge its predecessor writes", o);
         if ((op.out == ENG_OUT_EDGE_F32 || op.out == ENG_OUT_EDGE_ACT) && !op.out_edge) FL_FAIL(FL_ERR_BAD_ARGUMENT, "engine: op %d has no output edge", o);
         if (op.out == ENG_OUT_EDGE_ACT && op.N % 32) FL_FAIL(FL_ERR_BAD_ARGUMENT, "engine: gate/up rows must be a multiple of 32");
         if (op.out == ENG_OUT_QKV && (a.d <= 0 || a.d % 2 || op.N != (a.H + 2 * a.Hkv) * a.d)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "engine: bad qkv shape");
