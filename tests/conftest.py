@@ -28,11 +28,12 @@ def golden_dir():
 
 
 def pytest_collection_finish(session):
-    """tests/test_gpu_fullsize_7b.py generates its weights in HBM with torch (as bench.py does).  torch brings
+    """tests/test_gpu_fullsize_7b.py and test_gpu_literal_configs.py generate weights in HBM with torch (as bench.py does).  torch brings
     its own copy of the HIP runtime, which only sees the GPU if it initialises BEFORE the product library's
     (linked against /opt/rocm) does -- the order bench.py has -- so when that module is selected, let torch
     go first."""
-    if any(getattr(item, "fspath", None) is not None and item.fspath.basename == "test_gpu_fullsize_7b.py" for item in session.items):
+    torch_first = ("test_gpu_fullsize_7b.py", "test_gpu_literal_configs.py")
+    if any(getattr(item, "fspath", None) is not None and item.fspath.basename in torch_first for item in session.items):
         try:
             import torch
             torch.cuda.is_available()
