@@ -12,8 +12,10 @@
 //     at about the same time;
 //   * a wave's K tiles never change, so its activation fragments (B rows x its K tiles) are loaded ONCE, into registers
 //     (8 VGPRs per K tile), and no activation byte sits in LDS: all of it is ring;
-//   * every wave owns a ring of 8 x 2 KB LDS stages filled by `global_load_lds` (non-temporal: each weight byte is
-//     read once by one CU), seven K tiles (14 KB per wave, 112 KB per CU) ahead behind a COUNTED vmcnt; the ring is
+//   * every wave owns 16 KB of ring filled by `global_load_lds` (non-temporal: each weight byte is read once by one CU):
+//     four stages of 16 rows x 128 k where K allows (round 3: a 1-KB instruction then carries 4 rows x 256 contiguous bytes
+//     instead of 8 x 128 -- longer runs per row are served better: gate/up 40.5 -> 39.6 us, lm_head 51.2 -> 47.4 at 8 streams),
+//     else eight of 16 rows x 64 k; all but one stage in flight behind a COUNTED vmcnt; the ring is
 //     wave-private, so the loop has no barrier at all, and it runs on across unit boundaries;
 //   * per unit the 8 partial 16x8 tiles meet in LDS (4 KB, double-buffered: one barrier per unit) and one wave, in
 //     rotation, sums them in wave order and runs the epilogue.
@@ -48,9 +50,9 @@ template <int N> __device__ inline void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 // at most `n` (0 .. MAXN, wave-uniform) of this wave's youngest loads may still be in flight
-template <int MAXN> __device__ inline void wait_vm_upto(int n) {
+template <int MAXN, int STEP = 2> __device__ inline void wait_vm_upto(int n) {
     if constexpr (MAXN <= 0) { wait_vm<0>(); }
-    else { if (n >= MAXN) wait_vm<MAXN>(); else wait_vm_upto<MAXN - 2>(n); }
+    else { if (n >= MAXN) wait_vm<MAXN>(); else wait_vm_upto<MAXN - STEP, STEP>(n); }
 }
 
 // global row of slot i (0..15) of unit u
@@ -65,8 +67,14 @@ __device__ inline int unit_row(const GemvBatchArgs &a, int u, int i) {
 }
 
 // NKT: K tiles per wave (compile-time: the activation fragments live in registers).
-template <int NKT, int EPI>
+// KT: k per tile, 64 or 128 -- a stage is 16 rows x KT k (2 or 4 KB), so one 1-KB LDS-DMA instruction carries 8 rows x 128 B or
+// 4 rows x 256 B: the longer the contiguous run per row, the better the HBM serves it (round 3; FL_DMA_KT).
+template <int NKT, int EPI, int KT>
 __global__ __launch_bounds__(D_THREADS) void gemv_dma_kernel(const GemvBatchArgs a) {
+    constexpr int STAGE_BYTES = 16 * KT * 2, STAGES = (D_STAGES * D_STAGE_BYTES) / STAGE_BYTES;   // 16 KB of ring per wave either way
+    constexpr int DPS = STAGE_BYTES / 1024;                     // LDS-DMA instructions per stage
+    constexpr int RPI = 16 / DPS, LPR = 64 / RPI;               // rows per instruction, lanes (16-byte chunks) per row
+    constexpr int SUB = KT / 32;                                // MFMA k steps per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // [8 waves][8 stages][2 KB] | red | inv
     float *red = reinterpret_cast<float *>(lds + D_RING_BYTES);              // [2][8 waves][32 lanes][4]
     float *inv_lds = red + D_RED_FLOATS;                                      // [8]
@@ -77,14 +85,15 @@ __global__ __launch_bounds__(D_THREADS) void gemv_dma_kernel(const GemvBatchArgs
     const int m16 = lane & 15, kg = lane >> 4;
     const int ks_slice = blockIdx.y;
     // K slice of this workgroup in 64-wide tiles
-    const int nt_all = K >> 6;
+    const int nt_all = K / KT;
     const int per = (nt_all + a.nks - 1) / a.nks;
     const int t0s = min(nt_all, ks_slice * per), nts = min(nt_all, t0s + per) - t0s;       // first tile, tiles of the slice
     const int nunits = EPI == EPI_F32 ? (N + 15) / 16 : N / 16;
     const int my_units = (int)blockIdx.x < nunits ? (nunits - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-    unsigned char *ring = lds + (size_t)wave * D_STAGES * D_STAGE_BYTES;
+    unsigned char *ring = lds + (size_t)wave * STAGES * STAGE_BYTES;
 
-    // wave-uniform: does local tile t of this wave exist?  (tile index within the slice: t * 8 + wave)
+    // wave-uniform: does local tile t of this wave exist?  (tile index within the slice: t * 8 + wave.  A contiguous range of
+    // tiles per wave instead measured the same within noise: gate/up 39.7 -> 39.3 us, lm_head 47.1 -> 49.1)
     auto tile_ok = [&](int t) { return t * D_WAVES + wave < nts; };
     int my_tiles = 0;
 #pragma unroll
@@ -98,28 +107,29 @@ __global__ __launch_bounds__(D_THREADS) void gemv_dma_kernel(const GemvBatchArgs
         const int u = (int)blockIdx.x + iu * (int)gridDim.x;
         const int kt = t0s + it * D_WAVES + wave;
         if (++it == my_tiles) { it = 0; iu++; }
-        unsigned char *st = ring + (f & (D_STAGES - 1)) * D_STAGE_BYTES;
+        unsigned char *st = ring + (f & (STAGES - 1)) * STAGE_BYTES;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int slot = 8 * h + (lane >> 3), pc = lane & 7, c = pc ^ ((slot >> 1) & 7);
+        for (int h = 0; h < DPS; h++) {
+            const int slot = RPI * h + lane / LPR, pc = lane % LPR;
+            const int c = KT == 64 ? pc ^ ((slot >> 1) & 7) : pc ^ (slot & 15);      // the read side's XOR swizzle, applied to the source
             int row = unit_row<EPI>(a, u, slot);
             if (row > N - 1) row = N - 1;
-            glds16d(W + (size_t)row * K + (size_t)kt * 64 + c * 8, st + h * 1024);
+            glds16d(W + (size_t)row * K + (size_t)kt * KT + c * 8, st + h * 1024);
         }
     };
     int issued = 0;
-    for (; issued < D_STAGES - 1 && issued < total; issued++) issue(issued);
+    for (; issued < STAGES - 1 && issued < total; issued++) issue(issued);
 
     // ---- activation fragments of this wave's K tiles: lane (token m16, k group kg) ----
-    uint4v xf[NKT][2];
+    uint4v xf[NKT][SUB];
     const bf16_t *__restrict__ x = reinterpret_cast<const bf16_t *>(a.x);
 #pragma unroll
     for (int t = 0; t < NKT; t++) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
+        for (int s2 = 0; s2 < SUB; s2++) {
             xf[t][s2] = uint4v{0, 0, 0, 0};
             if (tile_ok(t) && m16 < B)
-                xf[t][s2] = *reinterpret_cast<const uint4v *>(x + (size_t)m16 * K + (size_t)(t0s + t * D_WAVES + wave) * 64 + s2 * 32 + kg * 8);
+                xf[t][s2] = *reinterpret_cast<const uint4v *>(x + (size_t)m16 * K + (size_t)(t0s + t * D_WAVES + wave) * KT + s2 * 32 + kg * 8);
         }
     }
     if (tid < 8) inv_lds[tid] = (a.x_scale && tid < B) ? a.x_scale[tid] : 1.0f;
@@ -166,19 +176,19 @@ __global__ __launch_bounds__(D_THREADS) void gemv_dma_kernel(const GemvBatchArgs
         for (int t = 0; t < NKT; t++) {
             if (!tile_ok(t)) continue;
             // task f has landed when at most the (issued - f - 1) younger tasks' loads (2 each) are outstanding
-            wait_vm_upto<2 * (D_STAGES - 2)>(2 * (issued - f - 1));
-            const unsigned char *st = ring + (f & (D_STAGES - 1)) * D_STAGE_BYTES;
-            bf16x8d wf[2];
+            wait_vm_upto<DPS * (STAGES - 2), DPS>(DPS * (issued - f - 1));
+            const unsigned char *st = ring + (f & (STAGES - 1)) * STAGE_BYTES;
+            bf16x8d wf[SUB];
 #pragma unroll
-            for (int s2 = 0; s2 < 2; s2++) {
+            for (int s2 = 0; s2 < SUB; s2++) {
                 const int chunk = s2 * 4 + kg;
-                wf[s2] = *reinterpret_cast<const bf16x8d *>(st + m16 * 128 + ((chunk ^ ((m16 >> 1) & 7)) << 4));
+                wf[s2] = *reinterpret_cast<const bf16x8d *>(st + m16 * (KT * 2) + ((chunk ^ (KT == 64 ? (m16 >> 1) & 7 : m16 & 15)) << 4));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the stage may be refilled from here on
             __builtin_amdgcn_sched_barrier(0);
             if (issued < total) { issue(issued); issued++; }           // into the stage task f - 1 used: its reads are done
 #pragma unroll
-            for (int s2 = 0; s2 < 2; s2++)
+            for (int s2 = 0; s2 < SUB; s2++)
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8d, xf[t][s2]), wf[s2], acc, 0, 0, 0);
             f++;
         }
@@ -210,11 +220,16 @@ static int cu_count_d() {
 }
 
 // K tiles per wave for a slice count; 0 = the shape does not fit the kernel
+static int dma_kt(int64_t K) {                                  // k per ring stage: 128 (256-byte row segments) where K allows it
+    static const int want = [] { const char *e = getenv("FL_DMA_KT"); return e && *e ? atoi(e) : 128; }();
+    return want == 128 && K % 128 == 0 ? 128 : 64;
+}
 static int dma_tiles_per_wave(int64_t K, int nks) {
     if (K % 64) return 0;
-    const int64_t nt = K / 64, per = (nt + nks - 1) / nks;
+    const int kt = dma_kt(K);
+    const int64_t nt = K / kt, per = (nt + nks - 1) / nks;
     const int64_t pw = (per + D_WAVES - 1) / D_WAVES;
-    return pw <= 16 ? (int)pw : 0;
+    return pw <= 1024 / kt ? (int)pw : 0;                       // 16 tiles of 64 k or 8 of 128: 128 VGPRs of activation fragments
 }
 
 bool gemv_dma_supported(int B, int64_t N, int64_t K, int epi, int d) {
@@ -236,9 +251,9 @@ int gemv_dma_ksplit(int64_t K, int64_t N, int epi) {
     return nks;
 }
 
-template <int NKT, int EPI>
+template <int NKT, int EPI, int KT>
 static int launch_dma_e(Launcher &L, const GemvBatchArgs &a) {
-    auto kern = gemv_dma_kernel<NKT, EPI>;
+    auto kern = gemv_dma_kernel<NKT, EPI, KT>;
     const size_t lds = (size_t)D_RING_BYTES + (size_t)(D_RED_FLOATS + 8) * 4;
     FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
     const int64_t nunits = EPI == EPI_F32 ? (a.N + 15) / 16 : a.N / 16;
@@ -251,9 +266,9 @@ static int launch_dma_e(Launcher &L, const GemvBatchArgs &a) {
     return LL.launch(KC_GEMV, (double)a.N * a.K * 2, 2.0 * a.N * a.K * a.B, kern, dim3((unsigned)blocks, (unsigned)a.nks), dim3(D_THREADS), lds, a);
 }
 
-template <int NKT>
+template <int NKT, int KT>
 static int launch_dma_n(Launcher &L, const GemvBatchArgs &a) {
-    return a.epi == EPI_GATEUP ? launch_dma_e<NKT, EPI_GATEUP>(L, a) : launch_dma_e<NKT, EPI_F32>(L, a);
+    return a.epi == EPI_GATEUP ? launch_dma_e<NKT, EPI_GATEUP, KT>(L, a) : launch_dma_e<NKT, EPI_F32, KT>(L, a);
 }
 
 int launch_gemv_dma(Launcher &L, const GemvBatchArgs &a) {
@@ -262,10 +277,16 @@ int launch_gemv_dma(Launcher &L, const GemvBatchArgs &a) {
     if (a.nks < 1 || (a.nks > 1 && a.epi != EPI_F32)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "launch_gemv_dma: K slices only for the plain fp32 projection");
     const int pw = dma_tiles_per_wave(a.K, a.nks);
     if (pw == 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "launch_gemv_dma: too few K slices (a wave holds at most 16 K tiles of activations)");
-    if (pw <= 4) return launch_dma_n<4>(L, a);
-    if (pw <= 8) return launch_dma_n<8>(L, a);
-    if (pw <= 12) return launch_dma_n<12>(L, a);
-    return launch_dma_n<16>(L, a);
+    if (dma_kt(a.K) == 128) {
+        if (pw <= 2) return launch_dma_n<2, 128>(L, a);
+        if (pw <= 4) return launch_dma_n<4, 128>(L, a);
+        if (pw <= 6) return launch_dma_n<6, 128>(L, a);
+        return launch_dma_n<8, 128>(L, a);
+    }
+    if (pw <= 4) return launch_dma_n<4, 64>(L, a);
+    if (pw <= 8) return launch_dma_n<8, 64>(L, a);
+    if (pw <= 12) return launch_dma_n<12, 64>(L, a);
+    return launch_dma_n<16, 64>(L, a);
 }
 
 }  // namespace fl
