@@ -4,7 +4,8 @@
 // weight read; here one read of W serves all B streams).
 //
 // Same streaming scheme as k_gemv.hip: a wave owns R = 2 rows at a time, reads them 16 B per lane,
-// non-temporal, straight to VGPRs in straight-line blocks of U = 4 chunks (counted vmcnt waits), fp32
+// non-temporal, straight to VGPRs as ONE double-buffered stream of U = 4 chunk blocks with unconditional loads (counted
+// vmcnt waits; round 3: one and two streams 3.03 / 3.10 -> 2.93 / 3.01 ms per step on Mistral-7B), fp32
 // accumulate, 64-lane butterfly.  What changes is the activation side: the B vectors sit in LDS as
 // [B][Ks] and every weight chunk is multiplied with all of them (8 unpacks + 8*B FMAs per 16-byte load,
 // still far below the VALU rate needed to keep up with HBM at B = 8).  The per-lane accumulation order
@@ -27,9 +28,10 @@
 
 namespace fl {
 
-constexpr int kBR = 2, kBU = 4, kBThreads = 512;
+constexpr int kBR = 2, kBThreads = 512;
 
-template <int NB, int PRO, int EPI>
+// kBU: 1-KiB chunks per row and block: 8 from K = 4096 (16 KiB per request round and wave, as the single-sequence kernel), else 4
+template <int NB, int PRO, int EPI, int kBU>
 __global__ __launch_bounds__(kBThreads) void gemv_batch_kernel(const GemvBatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float red[kBThreads / 64][NB];
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(kBThreads) void gemv_batch_kernel(const GemvBatchAr
     const int Ks = per * 8;                                            // LDS row stride (elements)
     const int half = a.d >> 1;
     const int ngroups = (N + kBR - 1) / kBR;
-    const int gw = blockIdx.x * nwv + wave, nw = gridDim.x * nwv;
+    const int nw = gridDim.x * nwv;
 
     auto row_of = [&](int g, int r) -> int {
         if (epi == EPI_GATEUP) { int q = g; return (q >> 4) * 32 + (q & 15) + (r << 4); }
@@ -56,19 +58,31 @@ __global__ __launch_bounds__(kBThreads) void gemv_batch_kernel(const GemvBatchAr
         return g * kBR + r;
     };
     typedef uint4v Buf[kBR][kBU];
-    // first block of this wave's first row group: requested before the activations are staged
+    // The wave's (row group, K block) items form ONE stream, requested a block ahead into two register buffers -- the form of the
+    // single-sequence kernel (k_gemv.hip, round 2), ported in round 3: while a block is multiplied the next one is in flight, also
+    // across row groups and their epilogues.  Every load of the stream is unconditional (past the end of K a lane re-reads the last
+    // chunk and its x is zeroed; a wave without work reads the last group's first block once): control flow around loads makes
+    // hipcc fall back from counted vmcnt waits to vmcnt(0).  The first block is requested before the activations are staged.
     Buf pre;
-    const bool have_pre = gw < ngroups && lane + 64 * (kBU - 1) < nchunk;
-    auto prefetch = [&]() {
-        if (!have_pre) return;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int gw_u = blockIdx.x * nwv + wave_u;
+    const int nb = max(1, (nchunk + 64 * kBU - 1) / (64 * kBU));                       // K blocks per row group (the last may be partial)
+    const int n_items = gw_u < ngroups ? (ngroups - gw_u + nw - 1) / nw * nb : 0;
+    const bool ragged = nchunk % (64 * kBU) != 0;
+    int lg = gw_u, lb = 0;                                                             // load stream: next item = (row group, block)
+    auto load_next = [&](Buf &buf) {
+        const int g = min(lg, ngroups - 1);
 #pragma unroll
         for (int r = 0; r < kBR; r++) {
-            const int row = row_of(gw, r);
+            const int row = row_of(g, r);
             const bf16_t *wp = W + (size_t)(row < N ? row : N - 1) * K + (size_t)cs0 * 8;
 #pragma unroll
-            for (int u = 0; u < kBU; u++) pre[r][u] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(wp + (size_t)(lane + 64 * u) * 8));
+            for (int u = 0; u < kBU; u++)
+                buf[r][u] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(wp + (size_t)min(lane + 64 * (kBU * lb + u), max(nchunk, 1) - 1) * 8));
         }
+        if (++lb == nb) { lb = 0; lg += nw; }
     };
+    auto prefetch = [&]() { load_next(pre); };
     float inv_m[NB];
 #pragma unroll
     for (int b = 0; b < NB; b++) inv_m[b] = 1.0f;
@@ -223,45 +237,43 @@ __global__ __launch_bounds__(kBThreads) void gemv_batch_kernel(const GemvBatchAr
         }
     };
 
-#pragma nounroll
-    for (int g = gw; g < ngroups; g += nw) {
-        const bf16_t *wp[kBR];
+    int cg = gw_u, cb = 0;                                                             // consume stream
+    auto consume = [&](const Buf &buf) {
+        const int c0 = lane + 64 * kBU * cb;
+        if (ragged && cb == nb - 1) {                                                  // wave-uniform: the partial last block of K
 #pragma unroll
-        for (int r = 0; r < kBR; r++) {
-            const int row = row_of(g, r);
-            wp[r] = W + (size_t)(row < N ? row : N - 1) * K + (size_t)cs0 * 8;
-        }
-        int c0 = lane;
-        if (g == gw && have_pre) { fma_block(pre, c0); c0 += 64 * kBU; }
-#pragma nounroll
-        for (; c0 + 64 * (kBU - 1) < nchunk; c0 += 64 * kBU) {         // full blocks: straight-line, counted waits
-            Buf w;
+            for (int u = 0; u < kBU; u++) {
+                const int ci = c0 + 64 * u;
 #pragma unroll
-            for (int u = 0; u < kBU; u++)
+                for (int b = 0; b < NB; b++) {
+                    uint4v xr = *reinterpret_cast<const uint4v *>(xs + (size_t)b * Ks + (size_t)min(ci, max(nchunk, 1) - 1) * 8);
+                    if (ci >= nchunk) xr = uint4v{0u, 0u, 0u, 0u};
 #pragma unroll
-                for (int r = 0; r < kBR; r++) w[r][u] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(wp[r] + (size_t)(c0 + 64 * u) * 8));
-            fma_block(w, c0);
-        }
-#pragma nounroll
-        for (; c0 < nchunk; c0 += 64) {                                 // K tail, one chunk at a time
-            uint4v wr[kBR];
+                    for (int r = 0; r < kBR; r++)
 #pragma unroll
-            for (int r = 0; r < kBR; r++) wr[r] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(wp[r] + (size_t)c0 * 8));
-#pragma unroll
-            for (int b = 0; b < NB; b++) {
-                const uint4v xr = *reinterpret_cast<const uint4v *>(xs + (size_t)b * Ks + (size_t)c0 * 8);
-#pragma unroll
-                for (int r = 0; r < kBR; r++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) acc[r][b] = dot2c_bf16(wr[r][j], xr[j], acc[r][b]);
+                        for (int j = 0; j < 4; j++) acc[r][b] = dot2c_bf16(buf[r][u][j], xr[j], acc[r][b]);
+                }
             }
 #pragma unroll
             for (int r = 0; r < kBR; r++)
 #pragma unroll
                 for (int b = 0; b < NB; b++) dot2c_settle(acc[r][b]);
+        } else {
+            fma_block(buf, c0);
         }
-        finish_group(g);
+        if (++cb == nb) { finish_group(cg); cb = 0; cg += nw; }
+    };
+    Buf nxt;
+    int t = 0;
+#pragma nounroll
+    for (; t + 2 < n_items; t += 2) {
+        load_next(nxt);
+        consume(pre);
+        load_next(pre);
+        consume(nxt);
     }
+    if (n_items - t == 2) { load_next(nxt); consume(pre); consume(nxt); }
+    else if (n_items - t == 1) consume(pre);
 }
 
 // ------------------------------------------------------------------------------- MFMA variant (B >= 3)
@@ -583,9 +595,9 @@ int gemv_batch_ksplit(int B, int64_t K, int64_t N, int epi) {
     return nks;
 }
 
-template <int NB, int PRO, int EPI>
-static int launch_gemv_batch_e(Launcher &L, const GemvBatchArgs &a) {
-    auto kern = gemv_batch_kernel<NB, PRO, EPI>;
+template <int NB, int PRO, int EPI, int U>
+static int launch_gemv_batch_u(Launcher &L, const GemvBatchArgs &a) {
+    auto kern = gemv_batch_kernel<NB, PRO, EPI, U>;
     const int64_t per = (((a.K / 8) + a.nks - 1) / a.nks + 63) & ~(int64_t)63;
     const size_t lds = (size_t)NB * per * 8 * 2;
     FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
@@ -596,6 +608,17 @@ static int launch_gemv_batch_e(Launcher &L, const GemvBatchArgs &a) {
     snprintf(tag, sizeof tag, "b%d:%dx%d%s%s", a.B, a.N, a.K, PRO == PRO_NORM ? ",norm" : "", a.epi == EPI_GATEUP ? ",glu" : (a.epi == EPI_QKV_ROPE ? ",rope" : ""));
     Launcher LL = L; LL.tag = tag;
     return LL.launch(KC_GEMV, (double)a.N * a.K * 2, 2.0 * a.N * a.K * a.B, kern, dim3((unsigned)blocks, (unsigned)a.nks), dim3(kBThreads), lds, a);
+}
+
+template <int NB, int PRO, int EPI>
+static int launch_gemv_batch_e(Launcher &L, const GemvBatchArgs &a) {
+    // FL_BATCH_U=8: 16-KiB blocks as the single-sequence kernel uses from K = 4096 -- measured no better here (one and two streams:
+    // 2.97 / 3.04 ms per step against 2.93 / 3.01 with 8-KiB blocks), so 4 is the default; NB <= 2 only (registers)
+    static const int u_env = getenv("FL_BATCH_U") ? atoi(getenv("FL_BATCH_U")) : 0;
+    if constexpr (NB <= 2) {
+        if (u_env == 8) return launch_gemv_batch_u<NB, PRO, EPI, 8>(L, a);
+    }
+    return launch_gemv_batch_u<NB, PRO, EPI, 4>(L, a);
 }
 
 template <int NB, int PRO>
