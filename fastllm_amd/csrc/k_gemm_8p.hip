@@ -334,6 +334,231 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__
     }
 }
 
+// ---- the same tile on FOUR waves (2 x 2), one per SIMD, 128 x 128 outputs each -------------------------------------------
+// Why: at eight waves a K tile costs 192 KB of ds_read_b128 per CU against 2048 cycles of MFMA -- 75 % of the LDS port -- and
+// every phase pays two barriers for the hand-over between the two wave groups.  With 128 x 128 per wave (the 256 accumulator
+// registers live in the AGPR half of a 512-register wave) the same tile reads 128 KB (0.25 fragment per MFMA) and a wave
+// covers its own loads: while the 32 MFMAs of one output quadrant issue, the wave requests the 8 fragments the NEXT phase
+// needs (into the register set the previous phase freed) and re-stages, by LDS-DMA, the half tile the previous phase read.
+//   tile t (even):  phase   computes   with        requests            re-stages (read one phase ago)
+//                   1       (m0,n0)    fa , fb0    fb1 <- B1(t)        B0(t+2)
+//                   2       (m0,n1)    fa , fb1    fa2 <- A1(t)        B1(t+2)
+//                   3       (m1,n1)    fa2, fb1    fa  <- A0(t+1)      A1(t+2)
+//                   4       (m1,n0)    fa2, fb0    fb1 <- B1(t+1)      A0(t+3)
+//   odd tiles run the mirror image (n0 <-> n1, fb0 <-> fb1, B0 <-> B1), so four fragment sets (128 VGPRs) suffice.
+// One s_barrier per phase.  Before it every wave has waited for its fragment reads (lgkmcnt(0): the half may be re-staged
+// behind the barrier) and for all but its 24 youngest DMA pieces (vmcnt(24): a half tile is read seven phases after it was
+// requested, six halves of four pieces per wave stay in flight).  Past the last K tile the re-stage requests go on, clamped to
+// the last tile (into halves nobody reads again), so the count holds to the end; vmcnt(0) + barrier before the epilogue.
+// One 1-KiB DMA piece: lane offsets (32-bit, precomputed) on a wave-uniform base, M0 = LDS byte address of the piece.  Three
+// instructions; the builtin's form costs a 64-bit vector add and keeps 64-bit lane addresses (32 more registers).  hipcc does
+// not count it: every wait for these pieces is an explicit vmcnt below.
+__device__ inline void stage_piece4(const void *base, unsigned off, unsigned m0v) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(m0v) : "memory");
+}
+
+// The 256 accumulator registers are a[0:255], owned by the asm statements below (hipcc's allocator, given 64 accumulator tiles
+// next to 128 fragment registers, shuffles them through v_accvgpr moves and scratch: 568 moves and 150 scratch accesses per
+// two K tiles).  Tile (n half h, row block i, column block j) lives in a[16 (8 h + i) + 4 j ..+3].  The compiler sees none of
+// them: build check = no v_accvgpr_* outside these statements and no scratch in the kernel (tests/test_build_audit.py).
+#define W4_AGPRS "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143","a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159","a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191","a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207","a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223","a224","a225","a226","a227","a228","a229","a230","a231","a232","a233","a234","a235","a236","a237","a238","a239","a240","a241","a242","a243","a244","a245","a246","a247","a248","a249","a250","a251","a252","a253","a254","a255"
+typedef int int4w __attribute__((ext_vector_type(4)));
+__device__ inline int4w frag4(const unsigned char *half, int row, int chunk) {
+    const int pc = chunk ^ ((row >> 1) & 7);
+    return *reinterpret_cast<const int4w *>(half + row * 128 + pc * 16);
+}
+template <int A0>                                                       // acc tile a[A0:A0+3] += X-fragment . W-fragment over K = 32
+__device__ inline void w4_mfma(int4w x, int4w w) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" : : "v"(x), "v"(w), "i"(A0), "i"(A0 + 3));
+}
+template <int A0> __device__ inline void w4_zero16() {                  // a[A0:A0+15] = 0
+    asm volatile("v_accvgpr_write_b32 a[%c0], 0\n\tv_accvgpr_write_b32 a[%c1], 0\n\tv_accvgpr_write_b32 a[%c2], 0\n\tv_accvgpr_write_b32 a[%c3], 0\n\t"
+                 "v_accvgpr_write_b32 a[%c4], 0\n\tv_accvgpr_write_b32 a[%c5], 0\n\tv_accvgpr_write_b32 a[%c6], 0\n\tv_accvgpr_write_b32 a[%c7], 0\n\t"
+                 "v_accvgpr_write_b32 a[%c8], 0\n\tv_accvgpr_write_b32 a[%c9], 0\n\tv_accvgpr_write_b32 a[%c10], 0\n\tv_accvgpr_write_b32 a[%c11], 0\n\t"
+                 "v_accvgpr_write_b32 a[%c12], 0\n\tv_accvgpr_write_b32 a[%c13], 0\n\tv_accvgpr_write_b32 a[%c14], 0\n\tv_accvgpr_write_b32 a[%c15], 0"
+                 : : "i"(A0), "i"(A0 + 1), "i"(A0 + 2), "i"(A0 + 3), "i"(A0 + 4), "i"(A0 + 5), "i"(A0 + 6), "i"(A0 + 7), "i"(A0 + 8),
+                     "i"(A0 + 9), "i"(A0 + 10), "i"(A0 + 11), "i"(A0 + 12), "i"(A0 + 13), "i"(A0 + 14), "i"(A0 + 15));
+}
+template <int A0> __device__ inline float4v w4_read() {                 // (behind the s_nop that ends the K loop)
+    float a, b, c, d;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
+                 : "=v"(a), "=v"(b), "=v"(c), "=v"(d) : "i"(A0), "i"(A0 + 1), "i"(A0 + 2), "i"(A0 + 3));
+    return float4v{a, b, c, d};
+}
+template <int... Is, class F> __device__ inline void w4_for_impl(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F> __device__ inline void w4_for(F &&f) { w4_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+template <bool SK, int DIAG = 0>
+__global__ __launch_bounds__(256) void gemm_4w_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
+                                                      const float *__restrict__ bias, void *__restrict__ out,
+                                                      int T, int N, int K, int epi, int tiles_m, int tiles_n,
+                                                      const float *__restrict__ row_scale, int ksplit, int ldc,
+                                                      StreamK sk, ResidEpi re) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [parity][A0 A1 B0 B1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wn = wave & 1;
+    const int m16 = lane & 15, kg = lane >> 4;
+    asm volatile("" : : : W4_AGPRS);                                    // the kernel descriptor allocates a[0:255]
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+    const int wid = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
+    const int nk_all = K / P_BK;
+    const int U = tiles_m * tiles_n * nk_all;
+    auto cut = [&](int w) { return (int)((long long)U * w / nwg); };
+    int u = SK ? cut(wid) : 0;
+    const int u_end = SK ? cut(wid + 1) : 0;
+
+    for (;;) {
+        int li, kt0, nk;
+        if (SK) {
+            if (u >= u_end) break;
+            li = u / nk_all; kt0 = u - li * nk_all;
+            nk = min(nk_all - kt0, u_end - u);
+            u += nk;
+        } else {
+            const int kz = blockIdx.y;
+            li = wid;
+            kt0 = (int)((long long)nk_all * kz / ksplit); nk = (int)((long long)nk_all * (kz + 1) / ksplit) - kt0;
+        }
+        const int tn = li / tiles_m, tm = li % tiles_m;
+        const int m0 = tm * P_BM, n0 = tn * P_BN;
+        const bf16_t *Xs = X + (size_t)kt0 * P_BK, *Ws = W + (size_t)kt0 * P_BK;
+
+        // byte offsets of this lane's 16 bytes in each of its four 1-KiB pieces of the four half-tile kinds (k = 0)
+        unsigned offA[2][4], offB[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const int r = (wave * 4 + s) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+                offA[h][s] = (unsigned)(((size_t)min(m0 + a_row(h, r), T - 1) * K + c * 8) * 2);
+                offB[h][s] = (unsigned)(((size_t)min(n0 + a_row(h, r), N - 1) * K + c * 8) * 2);
+            }
+        w4_for<16>([&](auto c) { w4_zero16<decltype(c)::value * 16>(); });
+
+        auto hbuf = [&](int tile, int which) -> unsigned char * { return lds + ((tile & 1) * 4 + which) * P_HALF; };   // 0 A0, 1 A1, 2 B0, 3 B1
+        auto ktile = [&](int tile) { return min(tile, nk - 1) * P_BK; };
+        const unsigned lds0 = (unsigned)(size_t)lds + wave * 4096;      // this wave's first piece of half tile 0 (LDS byte address)
+        auto m0of = [&](int tile, int which, int s) { return lds0 + ((tile & 1) * 4 + which) * P_HALF + s * 1024; };
+        auto stA = [&](int h, int tile, int s) { stage_piece4(Xs + ktile(tile), offA[h][s], m0of(tile, h, s)); };
+        auto stB = [&](int h, int tile, int s) { stage_piece4(Ws + ktile(tile), offB[h][s], m0of(tile, 2 + h, s)); };
+
+        // prologue: tiles 0 and 1 whole, in the order they are read
+#pragma unroll
+        for (int s = 0; s < 4; s++) stA(0, 0, s);
+#pragma unroll
+        for (int s = 0; s < 4; s++) stB(0, 0, s);
+#pragma unroll
+        for (int s = 0; s < 4; s++) stB(1, 0, s);
+#pragma unroll
+        for (int s = 0; s < 4; s++) stA(1, 0, s);
+#pragma unroll
+        for (int s = 0; s < 4; s++) stA(0, 1, s);
+#pragma unroll
+        for (int s = 0; s < 4; s++) stB(1, 1, s);
+#pragma unroll
+        for (int s = 0; s < 4; s++) stB(0, 1, s);
+#pragma unroll
+        for (int s = 0; s < 4; s++) stA(1, 1, s);
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");               // A0(0), B0(0) of this wave have landed
+        __builtin_amdgcn_s_barrier();
+
+        int4w fa[4][2], fa2[4][2], fb0[4][2], fb1[4][2];
+        const int arow = wr * 64 + m16, brow = wn * 64 + m16;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                fa[i][ks] = frag4(hbuf(0, 0), arow + i * 16, ks * 4 + kg);
+                fb0[i][ks] = frag4(hbuf(0, 2), brow + i * 16, ks * 4 + kg);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                   // everybody has read A0(0), B0(0)
+#pragma unroll
+        for (int s = 0; s < 4; s++) stA(0, 2, s);                       // ("phase 8 of tile -1")
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+
+        // one phase: the 32 MFMAs of quadrant (NH, MI0) with 8 fragment requests and 4 DMA pieces between them, in this order
+#define W4_FENCE __builtin_amdgcn_sched_barrier(0);
+#define W4_PHASE(NH, MI0, FA, FB, RD, RHALF, RROW, ST_A, ST_H, ST_T)                                        \
+        if constexpr (!(DIAG & 4)) __builtin_amdgcn_s_barrier();                                            \
+        W4_FENCE                                                                                            \
+        w4_for<4>([&](auto qc) {                                                                            \
+            constexpr int q = decltype(qc)::value, a0 = 16 * (8 * (NH) + (MI0) + q);                        \
+            w4_mfma<a0>(FA[q][0], FB[0][0]); W4_FENCE                                                       \
+            if constexpr (!(DIAG & 2)) RD[q][0] = frag4(RHALF, RROW + q * 16, kg);                          \
+            W4_FENCE                                                                                        \
+            w4_mfma<a0>(FA[q][1], FB[0][1]); W4_FENCE                                                       \
+            w4_mfma<a0 + 4>(FA[q][0], FB[1][0]); W4_FENCE                                                   \
+            if constexpr (!(DIAG & 2)) RD[q][1] = frag4(RHALF, RROW + q * 16, 4 + kg);                      \
+            W4_FENCE                                                                                        \
+            w4_mfma<a0 + 4>(FA[q][1], FB[1][1]); W4_FENCE                                                   \
+            w4_mfma<a0 + 8>(FA[q][0], FB[2][0]); W4_FENCE                                                   \
+            if constexpr (!(DIAG & 1)) { if (ST_A) stA(ST_H, ST_T, q); else stB(ST_H, ST_T, q); }           \
+            W4_FENCE                                                                                        \
+            w4_mfma<a0 + 8>(FA[q][1], FB[2][1]); W4_FENCE                                                   \
+            w4_mfma<a0 + 12>(FA[q][0], FB[3][0]); W4_FENCE                                                  \
+            w4_mfma<a0 + 12>(FA[q][1], FB[3][1]); W4_FENCE                                                  \
+        });                                                                                                 \
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                                                   \
+        __builtin_amdgcn_s_waitcnt(0xC07F);      /* lgkmcnt(0), as a builtin: hipcc then knows the fragments are in */ \
+        W4_FENCE
+
+#define W4_TILE(TT, NX, NY, FBX, FBY)                                                                       \
+        {                                                                                                   \
+            const int tt = (TT);                                                                            \
+            W4_PHASE(NX, 0, fa, FBX, FBY, hbuf(tt, 2 + NY), brow, false, NX, tt + 2)                        \
+            W4_PHASE(NY, 0, fa, FBY, fa2, hbuf(tt, 1), arow, false, NY, tt + 2)                             \
+            W4_PHASE(NY, 4, fa2, FBY, fa, hbuf(tt + 1, 0), arow, true, 1, tt + 2)                           \
+            W4_PHASE(NX, 4, fa2, FBX, FBY, hbuf(tt + 1, 2 + NY), brow, true, 0, tt + 3)                     \
+        }
+
+        int t = 0;
+        for (; t + 1 < nk; t += 2) {
+            W4_TILE(t, 0, 1, fb0, fb1)
+            W4_TILE(t + 1, 1, 0, fb1, fb0)
+        }
+        if (t < nk) W4_TILE(t, 0, 1, fb0, fb1)
+#undef W4_TILE
+#undef W4_PHASE
+#undef W4_FENCE
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the clamped re-stages past the last tile; the last MFMAs' results
+        __builtin_amdgcn_s_barrier();                                   // LDS is free
+
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));
+        if (!SK || nk == nk_all) {
+            void *outz = out;
+            if (!SK && ksplit > 1) outz = reinterpret_cast<float *>(out) + (size_t)blockIdx.y * T * N;
+            float *rs_lds = reinterpret_cast<float *>(lds);
+            rs_lds[tid_e] = row_scale ? row_scale[min(m0 + tid_e, T - 1)] : 1.0f;       // 256 threads, 256 rows
+            __syncthreads();
+            const bool whole = m0 + P_BM <= T && n0 + P_BN <= N;
+            w4_for<2>([&](auto hc) {
+                constexpr int h = decltype(hc)::value;
+                EpiCtx ctx;
+                epi_ctx_init(ctx, outz, bias, rs_lds, T, N, epi, ldc, m0, n0, tn, wr, wn * 2 + h, tid_e, re);
+                w4_for<8>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, a0 = 16 * (8 * h + i);
+                    const float4v v[4] = {w4_read<a0>(), w4_read<a0 + 4>(), w4_read<a0 + 8>(), w4_read<a0 + 12>()};
+                    if (whole) store_rows<false>(ctx, i, v);
+                    else store_rows<true>(ctx, i, v);
+                });
+            });
+        } else {
+            // the eight-wave kernel's lane-major layout (the fix-up kernel reads it): wave (wr, wc = 2 wn + h) of that kernel
+            float4v *pw = reinterpret_cast<float4v *>(sk.part + ((size_t)wid * 2 + (kt0 > 0 ? 0 : 1)) * (P_BM * P_BN));
+            w4_for<64>([&](auto c) {
+                constexpr int e = decltype(c)::value, h = e >> 5, i = (e >> 2) & 7, j = e & 3;
+                pw[(size_t)(i * 4 + j) * 512 + (wr * 4 + wn * 2 + h) * 64 + (tid_e & 63)] = w4_read<16 * (8 * h + i) + 4 * j>();
+            });
+        }
+        if (!SK) break;
+        __syncthreads();
+    }
+}
+
 // Fix-up of a stream-K launch (same stream, right behind it): workgroup (tile, 32-row block i) adds the published pieces
 // of a split tile in K order -- each thread the elements its lane held in the GEMM -- and runs the epilogue.
 __global__ __launch_bounds__(512) void gemm_8p_fixup_kernel(const float *__restrict__ bias, void *__restrict__ out, int T, int N, int K, int epi,
@@ -458,6 +683,26 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         return LF.launch(KC_GEMM_MFMA, 0.0, 0.0, gemm_8p_fixup_kernel, dim3((unsigned)(tiles_m * tiles_n * 8)), dim3(512), 0, bias, y, (int)T, (int)N,
                          (int)K, epi, tiles_m, tiles_n, row_scale, (int)ldc, (int)grid.x, sk, re);
     };
+    static const int four = [] { const char *e = getenv("FL_GEMM_4W"); return e ? atoi(e) : 0; }();
+    if (four && !getenv("FL_8P_STAMPS")) {                          // the four-wave form of the same tile (same grid, workspace and fix-up)
+        auto k4 = streamk ? gemm_4w_kernel<true> : gemm_4w_kernel<false>;
+        static const int diag = [] { const char *e = getenv("FL_GEMM_4W_DIAG"); return e ? atoi(e) : 0; }();
+        if (!streamk && diag) {                                     // timing ablations (wrong results): 1 no DMA, 2 no fragment reads, 4 no barrier
+            switch (diag) {
+                case 1: k4 = gemm_4w_kernel<false, 1>; break;
+                case 2: k4 = gemm_4w_kernel<false, 2>; break;
+                case 3: k4 = gemm_4w_kernel<false, 3>; break;
+                case 4: k4 = gemm_4w_kernel<false, 4>; break;
+                case 7: k4 = gemm_4w_kernel<false, 7>; break;
+            }
+        }
+        FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(k4), P_LDS));
+        snprintf(tag, sizeof tag, "4w,%lldx%lld%s%s", (long long)N, (long long)K, streamk ? ",streamK" : ksplit > 1 ? ",splitK" : "", resid ? ",resid" : "");
+        LL.tag = tag;
+        FL_TRY(LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, k4, grid, dim3(256), P_LDS, (const bf16_t *)W, (const bf16_t *)x,
+                         bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, sk, re));
+        return fixup();
+    }
     const bool stamp = getenv("FL_8P_STAMPS") != nullptr;           // diagnostics only: synchronous, appends one record per launch
     auto kern = streamk ? (stamp ? gemm_8p_kernel<true, true> : gemm_8p_kernel<false, true>) : (stamp ? gemm_8p_kernel<true, false> : gemm_8p_kernel<false, false>);
     FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), P_LDS));
