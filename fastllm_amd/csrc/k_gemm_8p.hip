@@ -388,7 +388,7 @@ template <int A0> __device__ inline float4v w4_read() {                 // (behi
 template <int... Is, class F> __device__ inline void w4_for_impl(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, class F> __device__ inline void w4_for(F &&f) { w4_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
-template <bool SK, int DIAG = 0>
+template <bool SK>
 __global__ __launch_bounds__(256) void gemm_4w_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
                                                       const float *__restrict__ bias, void *__restrict__ out,
                                                       int T, int N, int K, int epi, int tiles_m, int tiles_n,
@@ -482,20 +482,20 @@ __global__ __launch_bounds__(256) void gemm_4w_kernel(const bf16_t *__restrict__
         // one phase: the 32 MFMAs of quadrant (NH, MI0) with 8 fragment requests and 4 DMA pieces between them, in this order
 #define W4_FENCE __builtin_amdgcn_sched_barrier(0);
 #define W4_PHASE(NH, MI0, FA, FB, RD, RHALF, RROW, ST_A, ST_H, ST_T)                                        \
-        if constexpr (!(DIAG & 4)) __builtin_amdgcn_s_barrier();                                            \
+        __builtin_amdgcn_s_barrier();                                                                       \
         W4_FENCE                                                                                            \
         w4_for<4>([&](auto qc) {                                                                            \
             constexpr int q = decltype(qc)::value, a0 = 16 * (8 * (NH) + (MI0) + q);                        \
             w4_mfma<a0>(FA[q][0], FB[0][0]); W4_FENCE                                                       \
-            if constexpr (!(DIAG & 2)) RD[q][0] = frag4(RHALF, RROW + q * 16, kg);                          \
+            RD[q][0] = frag4(RHALF, RROW + q * 16, kg);                                                     \
             W4_FENCE                                                                                        \
             w4_mfma<a0>(FA[q][1], FB[0][1]); W4_FENCE                                                       \
             w4_mfma<a0 + 4>(FA[q][0], FB[1][0]); W4_FENCE                                                   \
-            if constexpr (!(DIAG & 2)) RD[q][1] = frag4(RHALF, RROW + q * 16, 4 + kg);                      \
+            RD[q][1] = frag4(RHALF, RROW + q * 16, 4 + kg);                                                 \
             W4_FENCE                                                                                        \
             w4_mfma<a0 + 4>(FA[q][1], FB[1][1]); W4_FENCE                                                   \
             w4_mfma<a0 + 8>(FA[q][0], FB[2][0]); W4_FENCE                                                   \
-            if constexpr (!(DIAG & 1)) { if (ST_A) stA(ST_H, ST_T, q); else stB(ST_H, ST_T, q); }           \
+            if (ST_A) stA(ST_H, ST_T, q); else stB(ST_H, ST_T, q);                                          \
             W4_FENCE                                                                                        \
             w4_mfma<a0 + 8>(FA[q][1], FB[2][1]); W4_FENCE                                                   \
             w4_mfma<a0 + 12>(FA[q][0], FB[3][0]); W4_FENCE                                                  \
@@ -683,19 +683,12 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         return LF.launch(KC_GEMM_MFMA, 0.0, 0.0, gemm_8p_fixup_kernel, dim3((unsigned)(tiles_m * tiles_n * 8)), dim3(512), 0, bias, y, (int)T, (int)N,
                          (int)K, epi, tiles_m, tiles_n, row_scale, (int)ldc, (int)grid.x, sk, re);
     };
-    static const int four = [] { const char *e = getenv("FL_GEMM_4W"); return e ? atoi(e) : 0; }();
-    if (four && !getenv("FL_8P_STAMPS")) {                          // the four-wave form of the same tile (same grid, workspace and fix-up)
+    static const int four = [] { const char *e = getenv("FL_GEMM_4W"); return e ? atoi(e) : 1; }();
+    // the four-wave form of the same tile (same grid, workspace and fix-up).  FL_GEMM_4W: 0 never, 1 (default) where its longer
+    // prologue (32 pieces per wave up front, 9 us of fixed cost against 6) is paid for -- stream-K pieces and K slices of ten or
+    // more steps (Mistral-7B o_proj at T = 512, eight steps per slice: 28.3 us on eight waves, 31.3 on four) --, 2 always
+    if (four && !getenv("FL_8P_STAMPS") && (four > 1 || streamk || (K / P_BK) / ksplit >= 10)) {
         auto k4 = streamk ? gemm_4w_kernel<true> : gemm_4w_kernel<false>;
-        static const int diag = [] { const char *e = getenv("FL_GEMM_4W_DIAG"); return e ? atoi(e) : 0; }();
-        if (!streamk && diag) {                                     // timing ablations (wrong results): 1 no DMA, 2 no fragment reads, 4 no barrier
-            switch (diag) {
-                case 1: k4 = gemm_4w_kernel<false, 1>; break;
-                case 2: k4 = gemm_4w_kernel<false, 2>; break;
-                case 3: k4 = gemm_4w_kernel<false, 3>; break;
-                case 4: k4 = gemm_4w_kernel<false, 4>; break;
-                case 7: k4 = gemm_4w_kernel<false, 7>; break;
-            }
-        }
         FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(k4), P_LDS));
         snprintf(tag, sizeof tag, "4w,%lldx%lld%s%s", (long long)N, (long long)K, streamk ? ",streamK" : ksplit > 1 ? ",splitK" : "", resid ? ",resid" : "");
         LL.tag = tag;
