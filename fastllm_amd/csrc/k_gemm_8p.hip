@@ -350,6 +350,14 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__
 // behind the barrier) and for all but its 24 youngest DMA pieces (vmcnt(24): a half tile is read seven phases after it was
 // requested, six halves of four pieces per wave stay in flight).  Past the last K tile the re-stage requests go on, clamped to
 // the last tile (into halves nobody reads again), so the count holds to the end; vmcnt(0) + barrier before the epilogue.
+// Where the time goes (Mistral-7B gate/up shape at T = 4096, random operands, TFLOP/s; timing-only builds, round 3):
+//   eight-wave kernel 1168 | this one 1298-1337 | without its DMA pieces 1546 | without its fragment reads 1417 | neither 1695
+//   (= the MFMA stream alone at the clock the chip holds on this data) | without the barrier 1302 | without the vmcnt 1293.
+// The fillers cost ISSUE time: a wave's MFMAs leave 8 of every 16 cycles free, a ds_read_b128 takes ~14 and a DMA piece ~33
+// (a plain global_load_dwordx4 in its place costs the same: 1287).  Tried and slower: the pieces in back-to-back pairs (1297),
+// one wave issuing all four of a row block (1177), a copy of the loop per wave with the piece in a different gap (1182), the
+// 32x32x16 MFMA shape with the same fillers in its 24-cycle gaps (1261: the chip holds a lower clock on that shape).
+// hipBLASLt on the same operands: 1430-1470 (tools/gemm_vs_library.py).
 // One 1-KiB DMA piece: lane offsets (32-bit, precomputed) on a wave-uniform base, M0 = LDS byte address of the piece.  Three
 // instructions; the builtin's form costs a 64-bit vector add and keeps 64-bit lane addresses (32 more registers).  hipcc does
 // not count it: every wait for these pieces is an explicit vmcnt below.
@@ -393,7 +401,7 @@ __global__ __launch_bounds__(256) void gemm_4w_kernel(const bf16_t *__restrict__
                                                       const float *__restrict__ bias, void *__restrict__ out,
                                                       int T, int N, int K, int epi, int tiles_m, int tiles_n,
                                                       const float *__restrict__ row_scale, int ksplit, int ldc,
-                                                      StreamK sk, ResidEpi re) {
+                                                      StreamK sk, ResidEpi re, int group_m) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [parity][A0 A1 B0 B1]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wn = wave & 1;
@@ -421,7 +429,10 @@ __global__ __launch_bounds__(256) void gemm_4w_kernel(const bf16_t *__restrict__
             li = wid;
             kt0 = (int)((long long)nk_all * kz / ksplit); nk = (int)((long long)nk_all * (kz + 1) / ksplit) - kt0;
         }
-        const int tn = li / tiles_m, tm = li % tiles_m;
+        // tile order: groups of group_m row tiles, columns next, so that the 32 tiles an XCD works on together are a
+        // group_m x (32 / group_m) block -- fewer distinct X / W panels per K step in its L2 than a 16 x 2 strip
+        const int per_g = group_m * tiles_n, g0 = (li / per_g) * group_m, gm = min(tiles_m - g0, group_m), lr = li % per_g;
+        const int tm = g0 + lr % gm, tn = lr / gm;
         const int m0 = tm * P_BM, n0 = tn * P_BN;
         const bf16_t *Xs = X + (size_t)kt0 * P_BK, *Ws = W + (size_t)kt0 * P_BK;
 
@@ -692,8 +703,10 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(k4), P_LDS));
         snprintf(tag, sizeof tag, "4w,%lldx%lld%s%s", (long long)N, (long long)K, streamk ? ",streamK" : ksplit > 1 ? ",splitK" : "", resid ? ",resid" : "");
         LL.tag = tag;
+        static const int group_env = [] { const char *e = getenv("FL_GEMM_GROUPM"); return e ? atoi(e) : 0; }();
+        const int group_m = std::max(1, std::min(tiles_m, group_env > 0 ? group_env : 4));   // 4: +3-4 % at T = 4096 over the 16 x 2 strip (8: +2-3, 2: +1)
         FL_TRY(LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, k4, grid, dim3(256), P_LDS, (const bf16_t *)W, (const bf16_t *)x,
-                         bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, sk, re));
+                         bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, sk, re, group_m));
         return fixup();
     }
     const bool stamp = getenv("FL_8P_STAMPS") != nullptr;           // diagnostics only: synchronous, appends one record per launch

@@ -108,3 +108,49 @@ def test_no_instruction_touches_a_dot_result_too_early(tmp_path):
         bad += b
     assert total > 1000, "expected the GEMV kernels' dots in the library, found %d" % total
     assert not bad, "dot results touched inside three wait states:\n" + "\n".join("%s\n    %s\n    %s" % x for x in bad[:20])
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump of the ROCm toolchain not found")
+def test_four_wave_gemm_owns_its_accumulator_registers(tmp_path):
+    """k_gemm_8p.hip's gemm_4w_kernel keeps its 64 accumulator tiles in a[0:255] through inline asm; hipcc does not know.
+    The shipped code must therefore hold no scratch access (a spill could land in those registers' shadow), no compiler copy
+    INTO an accumulator register (v_accvgpr_write from a VGPR, v_accvgpr_mov), and every read of the accumulators after an MFMA
+    must come behind the kernel's own s_nop padding (>= 16 wait states: the 4-pass MFMA's result latency)."""
+    blob = open(LIB, "rb").read()
+    found = 0
+    for n, co in enumerate(gfx950_code_objects(blob)):
+        p = tmp_path / ("g%d.elf" % n)
+        p.write_bytes(co)
+        txt = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", str(p)], capture_output=True, text=True, check=True).stdout
+        if "gemm_4w_kernel" not in txt:
+            continue
+        func, since_mfma, nmfma = None, None, 0
+        for line in txt.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+            if m:
+                func = m.group(1) if "gemm_4w_kernel" in m.group(1) else None
+                if func:
+                    found += 1
+                since_mfma = None
+                continue
+            m = re.match(r"^\s+(\S+)\s*(.*?)\s*//", line)
+            if not func or not m:
+                continue
+            op, args = m.group(1), m.group(2)
+            assert not op.startswith("scratch_"), "%s: scratch access\n%s" % (func, line)
+            assert not op.startswith("v_accvgpr_mov"), "%s: compiler copy between accumulator registers\n%s" % (func, line)
+            if op.startswith("v_accvgpr_write"):
+                assert re.search(r",\s*0$", args), "%s: a VGPR written into an accumulator register\n%s" % (func, line)
+            if op.startswith("v_mfma"):
+                assert re.match(r"a\[\d+:\d+\]", args), "%s: MFMA outside the accumulator file\n%s" % (func, line)
+                since_mfma, nmfma = 0, nmfma + 1
+            elif since_mfma is not None:
+                if op.startswith("s_nop"):
+                    since_mfma += int(args.split()[0], 0) + 1
+                elif op.startswith("v_accvgpr_read"):
+                    assert since_mfma >= 16, "%s: accumulator read %d wait states behind an MFMA\n%s" % (func, since_mfma, line)
+                    since_mfma = None                                  # the rest of this epilogue is covered
+                else:
+                    since_mfma += 1
+        assert nmfma >= 2 * 256, "expected both instantiations' K loops, found %d MFMAs" % nmfma
+    assert found >= 2, "gemm_4w_kernel not found in the library"
