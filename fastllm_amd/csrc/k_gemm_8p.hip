@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void gemm_4w_kernel(const bf16_t *__restrict__
 // of a split tile in K order -- each thread the elements its lane held in the GEMM -- and runs the epilogue.
 __global__ __launch_bounds__(512) void gemm_8p_fixup_kernel(const float *__restrict__ bias, void *__restrict__ out, int T, int N, int K, int epi,
                                                             int tiles_m, int tiles_n, const float *__restrict__ row_scale, int ldc, int nwg,
-                                                            StreamK sk, ResidEpi re) {
+                                                            StreamK sk, ResidEpi re, int group_m) {
     __shared__ __attribute__((aligned(16))) float rs_lds[P_BM];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 2, wc = wave & 3;
     const int li = blockIdx.x >> 3, i = blockIdx.x & 7;
@@ -587,7 +587,9 @@ __global__ __launch_bounds__(512) void gemm_8p_fixup_kernel(const float *__restr
     int nseg = 1;
     while (cut(w0 + nseg) < t1) nseg++;
     if (nseg == 1) return;                                            // the tile was computed whole: its owner ran the epilogue
-    const int tn = li / tiles_m, tm = li % tiles_m, m0 = tm * P_BM, n0 = tn * P_BN;
+    // (the GEMM's tile order: group_m = tiles_m is the eight-wave kernel's plain column-major walk)
+    const int per_g = group_m * tiles_n, g0 = (li / per_g) * group_m, gm = min(tiles_m - g0, group_m), lr = li % per_g;
+    const int tm = g0 + lr % gm, tn = lr / gm, m0 = tm * P_BM, n0 = tn * P_BN;
     if (tid < P_BM) rs_lds[tid] = row_scale ? row_scale[min(m0 + tid, T - 1)] : 1.0f;
     __syncthreads();
     float4v v[4] = {float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}};
@@ -688,11 +690,12 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         FL_TRY(streamk_space(L.stream, nwg, &sk));
         grid = dim3((unsigned)nwg, 1);
     }
+    int group_m = tiles_m;                                          // tile order of the launch (the four-wave kernel groups row tiles)
     auto fixup = [&]() -> int {                                     // behind a stream-K launch: the split tiles' sums and epilogues
         if (!streamk) return FL_OK;
         Launcher LF = L; LF.tag = "8p,fixup";
         return LF.launch(KC_GEMM_MFMA, 0.0, 0.0, gemm_8p_fixup_kernel, dim3((unsigned)(tiles_m * tiles_n * 8)), dim3(512), 0, bias, y, (int)T, (int)N,
-                         (int)K, epi, tiles_m, tiles_n, row_scale, (int)ldc, (int)grid.x, sk, re);
+                         (int)K, epi, tiles_m, tiles_n, row_scale, (int)ldc, (int)grid.x, sk, re, group_m);
     };
     static const int four = [] { const char *e = getenv("FL_GEMM_4W"); return e ? atoi(e) : 1; }();
     // the four-wave form of the same tile (same grid, workspace and fix-up).  FL_GEMM_4W: 0 never, 1 (default) where its longer
@@ -704,7 +707,7 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         snprintf(tag, sizeof tag, "4w,%lldx%lld%s%s", (long long)N, (long long)K, streamk ? ",streamK" : ksplit > 1 ? ",splitK" : "", resid ? ",resid" : "");
         LL.tag = tag;
         static const int group_env = [] { const char *e = getenv("FL_GEMM_GROUPM"); return e ? atoi(e) : 0; }();
-        const int group_m = std::max(1, std::min(tiles_m, group_env > 0 ? group_env : 4));   // 4: +3-4 % at T = 4096 over the 16 x 2 strip (8: +2-3, 2: +1)
+        group_m = std::max(1, std::min(tiles_m, group_env > 0 ? group_env : 4));   // 4: +3-4 % at T = 4096 over the 16 x 2 strip (8: +2-3, 2: +1)
         FL_TRY(LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, k4, grid, dim3(256), P_LDS, (const bf16_t *)W, (const bf16_t *)x,
                          bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, sk, re, group_m));
         return fixup();

@@ -207,7 +207,8 @@ def test_linear_peeled_columns(fa, T, N, K, epi, bias):
 # partials and a per-tile ticket).  The product uses it for the peeled tail of a long prompt's GEMM (above); FL_GEMM_STREAMK=3
 # runs whole matrices through it: aligned pieces, pieces that straddle tiles (41 K steps cut in two), ragged edges, gate/up
 @pytest.mark.parametrize("T,N,K,epi,bias", [(2048, 3584, 4096, 0, False), (1024, 6144, 2624, 0, True), (2000, 3000, 1088, 0, True),
-                                            (1024, 2176, 2624, 1, False), (300, 520, 512, 0, False)])
+                                            (1024, 2176, 2624, 1, False), (300, 520, 512, 0, False),
+                                            (1400, 1500, 1088, 0, True)])   # six row tiles: a group of four and a group of two (the four-wave kernel's tile order)
 def test_linear_streamk_whole(fa, monkeypatch, T, N, K, epi, bias):
     monkeypatch.setenv("FL_GEMM_STREAMK", "3")
     x, w = _rand((T, K), 61), _rand((N if not epi else 2 * N, K), 62, 0.05)
