@@ -116,15 +116,48 @@ __device__ __forceinline__ void attn_decode_mfma_body(const bf16_t *__restrict__
     decode_tail<bf16_t, D, GMAX, NW>(lds, is_last, G, hq0, hk, split, nsplit, part_m, part_l, part_o, counters, out);
 }
 
+// Prefetch workgroups (blockIdx.y >= nsplit): every 128-byte line of the next launch's weights is touched once and dropped,
+// while the attention workgroups wait on their own round trips and HBM idles.  The lines land in the Infinity Cache and in
+// the L2 of the XCD that touched them -- so a prefetch workgroup takes the chunks [j chunk, (j + 1) chunk) whose consumer
+// workgroup (j mod its grid; workgroups go round the XCDs in launch order) will run on ITS XCD (HW_REG_XCC_ID).  They take no
+// part in the splits' combine.  Yardstick: the o_proj GEMV with its weights cache-resident (FL_OP_HOT=1, tools/skinny_probe.py)
+// runs in 4.5 us instead of 7.7 (Mistral-7B), TinyLlama's 2048 x 2048 in ~3 instead of 4.4.
+__device__ __forceinline__ void prefetch_chunks(float *dump, const void *pf, unsigned chunk_lines, unsigned nchunks, unsigned row_lines, unsigned row_take, unsigned w, unsigned P, unsigned nthr, unsigned delay) {
+    if (delay) { for (unsigned d = 0; d < delay; d++) __builtin_amdgcn_s_sleep(16); }   // (x 1024 cycles: let the attention's own K / V requests go first)
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    const unsigned Px = max(1u, (P + 7) >> 3), r = (w >> 3) % Px;
+    const unsigned char *base = reinterpret_cast<const unsigned char *>(pf);
+    for (unsigned j = xcc + 8u * r; j < nchunks; j += 8u * Px) {
+        const unsigned char *cb = base + (size_t)j * chunk_lines * 128;
+        // (the first row_take of every row's row_lines lines: each consumer wave then has the same share left to fetch)
+        const unsigned rows = chunk_lines / row_lines;
+        for (unsigned l = threadIdx.x; l < rows * row_take; l += nthr) {
+            const unsigned rr = l / row_take, ll = l - rr * row_take;
+            // an LDS-DMA dword per lane: no register destination (an asm load into a scratch VGPR lands after hipcc has given that
+            // register to the next address -- a memory fault, seen); the 256 bytes fall on the attention's unused LDS state
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(cb + ((size_t)rr * row_lines + ll) * 128),
+                                             (__attribute__((address_space(3))) void *)dump, 4, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int D, int GMAX, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
                                                                const bf16_t *__restrict__ vT, const StepState *__restrict__ st,
                                                                float *__restrict__ part_m, float *__restrict__ part_l,
                                                                float *__restrict__ part_o, unsigned *__restrict__ counters,
                                                                bf16_t *__restrict__ out, int H, int Hkv, int seq_alloc,
-                                                               float scale, int nsplit) {
+                                                               float scale, int nsplit, const void *__restrict__ pf, unsigned pf_chunk_lines, unsigned pf_nchunks,
+                                                               unsigned pf_row_lines, unsigned pf_row_take, unsigned pf_delay) {
     __shared__ float lds[decode_lds_floats<D, GMAX, NW>()];
     __shared__ int is_last;
+    if ((int)blockIdx.y >= nsplit) {                                // workgroup-uniform
+        prefetch_chunks(lds, pf, pf_chunk_lines, pf_nchunks, pf_row_lines, pf_row_take, (blockIdx.y - nsplit) * gridDim.x + blockIdx.x, (gridDim.y - nsplit) * gridDim.x, NW * 64, pf_delay);
+        return;
+    }
     attn_decode_mfma_body<D, GMAX, NW>(q, kc, vT, st, part_m, part_l, part_o, counters, out, H, Hkv, seq_alloc, scale, nsplit, lds, &is_last);
 }
 
@@ -148,11 +181,35 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_batch_kernel(const b
 template <int D, int GMAX, int NW>
 static int launch_decode_mfma_t(Launcher &L, const void *q, const void *kc, const void *vT, const StepState *st, void *out,
                                 const AttnScratch &sc, int64_t H, int64_t Hkv, int64_t seq_alloc, float scale) {
-    dim3 grid((unsigned)Hkv, (unsigned)sc.nsplit, 1);
+    // Prefetch workgroups (FL_ATTN_PREFETCH=1; off by default): ~1 KiB per thread (eight lines), as extra rows of the grid.
+    // Measured, round 3 (tools/decode_probe.py): the consumer gets what the yardstick promised -- Mistral-7B o_proj 7.35 -> 4.4 us
+    // (7.6 TB/s of its weights), Qwen2-7B 6.2 -> 4.4 -- and the attention launch pays it back: 7.3 -> 9.5 us (Mistral, S = 530),
+    // 11.9 -> 13.7 (Qwen2, S = 4100): its chain of round trips (K, V, the splits' partials) slows down under the prefetch traffic
+    // by about what the consumer gains, whatever share of the rows is taken (FL_ATTN_PREFETCH_PCT 60 / 75 / 100) and however late
+    // the prefetchers start (FL_ATTN_PREFETCH_DELAY).  Tokens/s: Mistral-7B 369.8 -> 371.9 (four runs each), Qwen2-7B 360.1 ->
+    // 356.9, TinyLlama-1.1B unchanged (its o_proj is not memory-bound: 4.2-4.4 us either way).  (read per call: tests switch it)
+    const int pf_on = getenv("FL_ATTN_PREFETCH") ? atoi(getenv("FL_ATTN_PREFETCH")) : 0;
+    const int pf_per_thread = getenv("FL_ATTN_PREFETCH_LINES") ? std::max(1, atoi(getenv("FL_ATTN_PREFETCH_LINES"))) : 8;
+    const int pf_pct = getenv("FL_ATTN_PREFETCH_PCT") ? std::min(100, std::max(1, atoi(getenv("FL_ATTN_PREFETCH_PCT")))) : 100;
+    const int pf_delay = getenv("FL_ATTN_PREFETCH_DELAY") ? std::max(0, atoi(getenv("FL_ATTN_PREFETCH_DELAY"))) : 0;
+    unsigned pf_rows = 0, chunk_lines = 0, nchunks = 0, row_lines = 1, row_take = 1;
+    if (pf_on && sc.prefetch && sc.prefetch_chunk >= 128 && sc.prefetch_bytes >= sc.prefetch_chunk && sc.prefetch_row >= 128 && sc.prefetch_chunk % sc.prefetch_row == 0) {
+        chunk_lines = (unsigned)(sc.prefetch_chunk / 128);
+        row_lines = (unsigned)(sc.prefetch_row / 128);
+        row_take = std::max(1u, row_lines * (unsigned)pf_pct / 100u);
+        nchunks = (unsigned)std::min<int64_t>(sc.prefetch_bytes / sc.prefetch_chunk, 1 << 20);
+        const int64_t lines = (int64_t)chunk_lines / row_lines * row_take * nchunks, per_wg = (int64_t)NW * 64 * pf_per_thread;
+        int64_t wgs = (lines + per_wg - 1) / per_wg;
+        pf_rows = (unsigned)((wgs + Hkv - 1) / Hkv);
+        // a multiple of eight workgroups in the whole launch: the dispatcher's walk over the XCDs carries on from launch to
+        // launch, and the consumer's workgroup b is assumed on XCD b mod 8 (the prefetchers read their own XCC id)
+        while ((((unsigned)sc.nsplit + pf_rows) * (unsigned)Hkv) % 8) pf_rows++;
+    }
+    dim3 grid((unsigned)Hkv, (unsigned)sc.nsplit + pf_rows, 1);
     double kvbytes = 2.0 * (double)sc.kv_len_hint * Hkv * D * 2;
     return L.launch(KC_ATTN_DECODE, kvbytes, 4.0 * (double)sc.kv_len_hint * H * D, attn_decode_mfma_kernel<D, GMAX, NW>, grid,
                     dim3(NW * 64), 0, (const bf16_t *)q, (const bf16_t *)kc, (const bf16_t *)vT, st, sc.part_m, sc.part_l,
-                    sc.part_o, sc.counters, (bf16_t *)out, (int)H, (int)Hkv, (int)seq_alloc, scale, sc.nsplit);
+                    sc.part_o, sc.counters, (bf16_t *)out, (int)H, (int)Hkv, (int)seq_alloc, scale, sc.nsplit, sc.prefetch, chunk_lines, nchunks, row_lines, row_take, (unsigned)pf_delay);
 }
 
 bool attn_mfma_supported(int dtype, int64_t H, int64_t Hkv, int64_t d) {

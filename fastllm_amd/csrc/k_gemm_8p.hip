@@ -701,7 +701,9 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
     // the four-wave form of the same tile (same grid, workspace and fix-up).  FL_GEMM_4W: 0 never, 1 (default) where its longer
     // prologue (32 pieces per wave up front, 9 us of fixed cost against 6) is paid for -- stream-K pieces and K slices of ten or
     // more steps (Mistral-7B o_proj at T = 512, eight steps per slice: 28.3 us on eight waves, 31.3 on four) --, 2 always
-    if (four && !getenv("FL_8P_STAMPS") && (four > 1 || streamk || (K / P_BK) / ksplit >= 10)) {
+    // (its DMA pieces address a lane's bytes as a 32-bit offset from the matrix base: matrices of 4 GiB or more stay on eight waves)
+    const bool fits32 = (double)std::max(T, N) * (double)K * 2.0 < 4294967296.0;
+    if (four && fits32 && !getenv("FL_8P_STAMPS") && (four > 1 || streamk || (K / P_BK) / ksplit >= 10)) {
         auto k4 = streamk ? gemm_4w_kernel<true> : gemm_4w_kernel<false>;
         FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(k4), P_LDS));
         snprintf(tag, sizeof tag, "4w,%lldx%lld%s%s", (long long)N, (long long)K, streamk ? ",streamK" : ksplit > 1 ? ",splitK" : "", resid ? ",resid" : "");

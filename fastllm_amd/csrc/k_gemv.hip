@@ -623,6 +623,17 @@ bool gemv_leaves_candidates(int dtype, const GemvArgs &a) {
     return blocks + 1 <= kMaxArgmaxCand;
 }
 
+int64_t gemv_owner_chunk(int dtype, int64_t N, int64_t K) {
+    int R = g_gemv_r.load();
+    if (!R) R = env_int("FL_GEMV_R", 2);
+    if (R != 4) R = 2;
+    const size_t es = dtype == FL_DTYPE_BF16 ? 2 : 4;
+    int blocks = 1, waves = 4;
+    pick_geometry((N + R - 1) / R, ((size_t)K * es + 15) & ~(size_t)15, &blocks, &waves);
+    if (waves < 4) waves = 4;
+    return (int64_t)waves * R * K * (int64_t)es;
+}
+
 int launch_gemv(Launcher &L, int dtype, const GemvArgs &a) {
     if (a.N <= 0 || a.K <= 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "launch_gemv: bad shape");
     if (!gemv_supported(dtype, a.N, a.K)) FL_FAIL(FL_ERR_UNSUPPORTED, "launch_gemv: K=%d unsupported", a.K);

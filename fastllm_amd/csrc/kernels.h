@@ -87,6 +87,9 @@ struct GemvArgs {
     ArgmaxCand *amax = nullptr;
 };
 int launch_gemv(Launcher &L, int dtype, const GemvArgs &a);
+// bytes of W that workgroup b of the plain-epilogue launch (no norm prologue) of an N x K matrix reads as one contiguous piece
+// ([b chunk, (b + 1) chunk), then every grid-th piece): what a prefetcher needs to know to warm the right XCD's L2
+int64_t gemv_owner_chunk(int dtype, int64_t N, int64_t K);
 bool gemv_leaves_candidates(int dtype, const GemvArgs &a);   // the grid launch_gemv would pick fits the candidate buffer
 bool gemv_norm_supported(int dtype, int64_t N, int64_t K);
 void gemv_set_tuning(int R, int U, int maxblocks, int maxblocks_norm);
@@ -268,7 +271,13 @@ struct LLTable {
 int launch_ll_allreduce(Launcher &L, const LLTable *ll_dev, int slot, const float *in, float *out, int64_t n);
 
 // ---- attention -----------------------------------------------------------------------------
-struct AttnScratch { float *part_m, *part_l, *part_o; unsigned *counters; int nsplit; int64_t kv_len_hint; };
+struct AttnScratch {
+    float *part_m, *part_l, *part_o; unsigned *counters; int nsplit; int64_t kv_len_hint;
+    // decode (k_attn_mfma.hip): bytes the NEXT launch will stream (the layer's o_proj weights), touched by extra workgroups of
+    // this launch while its own few MB leave HBM idle -- they are then served from the Infinity Cache
+    // (prefetch_chunk: the bytes one workgroup of that launch reads contiguously, gemv_owner_chunk)
+    const void *prefetch = nullptr; int64_t prefetch_bytes = 0, prefetch_chunk = 0, prefetch_row = 0;   // (row: bytes of one matrix row)
+};
 // decode: one query token over len+1 cached keys, no mask (App. A.5)
 int launch_attn_decode(Launcher &L, int dtype, const void *q, const void *k_cache, const void *v_cache,
                        const StepState *st, void *out, const AttnScratch &sc, int64_t H, int64_t Hkv,

@@ -876,6 +876,8 @@ static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
             a.v_ld = c->v_transposed ? (int)c->seq_alloc : 0;
             FL_TRY(launch_gemv(L, dt, a));
             AttnScratch as{cs.part_m, cs.part_l, cs.part_o, cs.counters, c->nsplit, len_hint + 1};
+            as.prefetch = ly.wo; as.prefetch_bytes = D.h * sh.Hs * D.d * (int64_t)m->esize();   // o_proj's weights, while HBM idles under the attention
+            as.prefetch_chunk = gemv_owner_chunk(dt, D.h, sh.Hs * D.d); as.prefetch_row = sh.Hs * D.d * (int64_t)m->esize();
             if (c->fuse_oproj) {
                 FL_TRY(launch_attn_oproj(L, sc.q, kc, vc, cs.st, cs.st, cs.ao_part, cs.heads_done + l * sh.Hkvs, c->ao_nsplit, c->ao_waves, len_hint + 1, ly.wo,
                                          sc.delta, sh.Hs, sh.Hkvs, D.d, D.h, (int64_t)c->seq_alloc, D.scale));
