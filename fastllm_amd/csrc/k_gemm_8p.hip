@@ -357,12 +357,23 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__
 // (a plain global_load_dwordx4 in its place costs the same: 1287).  Tried and slower: the pieces in back-to-back pairs (1297),
 // one wave issuing all four of a row block (1177), a copy of the loop per wave with the piece in a different gap (1182), the
 // 32x32x16 MFMA shape with the same fillers in its 24-cycle gaps (1261: the chip holds a lower clock on that shape).
-// hipBLASLt on the same operands: 1430-1470 (tools/gemm_vs_library.py).
-// One 1-KiB DMA piece: lane offsets (32-bit, precomputed) on a wave-uniform base, M0 = LDS byte address of the piece.  Three
-// instructions; the builtin's form costs a 64-bit vector add and keeps 64-bit lane addresses (32 more registers).  hipcc does
-// not count it: every wait for these pieces is an explicit vmcnt below.
-__device__ inline void stage_piece4(const void *base, unsigned off, unsigned m0v) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(m0v) : "memory");
+// hipBLASLt on the same operands: 1430-1470 (tools/gemm_vs_library.py).  Neutral: the pieces as buffer loads with one M0 write per
+// phase and the K offset as the scalar offset (6 instructions fewer per phase: 1328 against 1311-1337) -- kept, the loop is cleaner.
+// The four 1-KiB DMA pieces a wave adds to a half tile are buffer loads into LDS: lane offset (32-bit, precomputed) + the K tile's
+// byte offset as the scalar offset + the piece's number x 1024 as the instruction offset, which moves the global address AND the
+// LDS address -- so M0 (the LDS address of the wave's piece 0 in that half) is written once per phase and a piece is ONE
+// instruction.  (The lane offsets carry 3072 - 1024 s and the descriptor's base lies 3072 bytes before the matrix, so that the
+// instruction offset cancels out of the global address.)  hipcc does not count them: every wait is an explicit vmcnt.
+typedef int int4w __attribute__((ext_vector_type(4)));
+constexpr int W4_BIAS = 3072;
+__device__ inline void w4_set_m0(unsigned m0v) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(m0v) : "memory"); }
+template <int S>
+__device__ inline void w4_piece(int4w rsrc, unsigned voff, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%c3 lds" : : "v"(voff), "s"(rsrc), "s"(soff), "i"(S * 1024) : "memory");
+}
+__device__ inline int4w w4_rsrc(const void *base) {                     // raw buffer over [base - 3072, +4 GiB): no stride, no swizzle
+    const unsigned long long b = (unsigned long long)base - W4_BIAS;
+    return int4w{(int)(unsigned)b, (int)(unsigned)(b >> 32) & 0xFFFF, -1, 0x00020000};
 }
 
 // The 256 accumulator registers are a[0:255], owned by the asm statements below (hipcc's allocator, given 64 accumulator tiles
@@ -370,7 +381,6 @@ __device__ inline void stage_piece4(const void *base, unsigned off, unsigned m0v
 // two K tiles).  Tile (n half h, row block i, column block j) lives in a[16 (8 h + i) + 4 j ..+3].  The compiler sees none of
 // them: build check = no v_accvgpr_* outside these statements and no scratch in the kernel (tests/test_build_audit.py).
 #define W4_AGPRS "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143","a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159","a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191","a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207","a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223","a224","a225","a226","a227","a228","a229","a230","a231","a232","a233","a234","a235","a236","a237","a238","a239","a240","a241","a242","a243","a244","a245","a246","a247","a248","a249","a250","a251","a252","a253","a254","a255"
-typedef int int4w __attribute__((ext_vector_type(4)));
 __device__ inline int4w frag4(const unsigned char *half, int row, int chunk) {
     const int pc = chunk ^ ((row >> 1) & 7);
     return *reinterpret_cast<const int4w *>(half + row * 128 + pc * 16);
@@ -443,35 +453,28 @@ __global__ __launch_bounds__(256) void gemm_4w_kernel(const bf16_t *__restrict__
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const int r = (wave * 4 + s) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
-                offA[h][s] = (unsigned)(((size_t)min(m0 + a_row(h, r), T - 1) * K + c * 8) * 2);
-                offB[h][s] = (unsigned)(((size_t)min(n0 + a_row(h, r), N - 1) * K + c * 8) * 2);
+                offA[h][s] = (unsigned)(((size_t)min(m0 + a_row(h, r), T - 1) * K + c * 8) * 2) + (W4_BIAS - 1024 * s);
+                offB[h][s] = (unsigned)(((size_t)min(n0 + a_row(h, r), N - 1) * K + c * 8) * 2) + (W4_BIAS - 1024 * s);
             }
         w4_for<16>([&](auto c) { w4_zero16<decltype(c)::value * 16>(); });
 
         auto hbuf = [&](int tile, int which) -> unsigned char * { return lds + ((tile & 1) * 4 + which) * P_HALF; };   // 0 A0, 1 A1, 2 B0, 3 B1
-        auto ktile = [&](int tile) { return min(tile, nk - 1) * P_BK; };
-        const unsigned lds0 = (unsigned)(size_t)lds + wave * 4096;      // this wave's first piece of half tile 0 (LDS byte address)
-        auto m0of = [&](int tile, int which, int s) { return lds0 + ((tile & 1) * 4 + which) * P_HALF + s * 1024; };
-        auto stA = [&](int h, int tile, int s) { stage_piece4(Xs + ktile(tile), offA[h][s], m0of(tile, h, s)); };
-        auto stB = [&](int h, int tile, int s) { stage_piece4(Ws + ktile(tile), offB[h][s], m0of(tile, 2 + h, s)); };
+        const int4w rsX = w4_rsrc(Xs), rsW = w4_rsrc(Ws);
+        auto koff = [&](int tile) { return (unsigned)(min(tile, nk - 1) * (P_BK * 2)); };   // byte offset of a K tile (clamped past the end)
+        const unsigned lds0 = (unsigned)(size_t)lds + wave * 4096;      // this wave's piece 0 of half tile 0 (LDS byte address)
+        auto m0of = [&](int tile, int which) { return lds0 + ((tile & 1) * 4 + which) * P_HALF; };
+        // all four pieces of a half (prologue), or piece q alone after the phase's w4_set_m0
+        auto half4 = [&](bool isA, int h, int tile) {
+            w4_set_m0(m0of(tile, isA ? h : 2 + h));
+            const unsigned ko = koff(tile);
+            const int4w rs = isA ? rsX : rsW;
+            const unsigned *of = isA ? offA[h] : offB[h];
+            w4_piece<0>(rs, of[0], ko); w4_piece<1>(rs, of[1], ko); w4_piece<2>(rs, of[2], ko); w4_piece<3>(rs, of[3], ko);
+        };
 
         // prologue: tiles 0 and 1 whole, in the order they are read
-#pragma unroll
-        for (int s = 0; s < 4; s++) stA(0, 0, s);
-#pragma unroll
-        for (int s = 0; s < 4; s++) stB(0, 0, s);
-#pragma unroll
-        for (int s = 0; s < 4; s++) stB(1, 0, s);
-#pragma unroll
-        for (int s = 0; s < 4; s++) stA(1, 0, s);
-#pragma unroll
-        for (int s = 0; s < 4; s++) stA(0, 1, s);
-#pragma unroll
-        for (int s = 0; s < 4; s++) stB(1, 1, s);
-#pragma unroll
-        for (int s = 0; s < 4; s++) stB(0, 1, s);
-#pragma unroll
-        for (int s = 0; s < 4; s++) stA(1, 1, s);
+        half4(true, 0, 0); half4(false, 0, 0); half4(false, 1, 0); half4(true, 1, 0);
+        half4(true, 0, 1); half4(false, 1, 1); half4(false, 0, 1); half4(true, 1, 1);
         asm volatile("s_waitcnt vmcnt(24)" ::: "memory");               // A0(0), B0(0) of this wave have landed
         __builtin_amdgcn_s_barrier();
 
@@ -486,14 +489,16 @@ __global__ __launch_bounds__(256) void gemm_4w_kernel(const bf16_t *__restrict__
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                   // everybody has read A0(0), B0(0)
-#pragma unroll
-        for (int s = 0; s < 4; s++) stA(0, 2, s);                       // ("phase 8 of tile -1")
+        half4(true, 0, 2);                                              // ("phase 8 of tile -1")
         asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
 
         // one phase: the 32 MFMAs of quadrant (NH, MI0) with 8 fragment requests and 4 DMA pieces between them, in this order
 #define W4_FENCE __builtin_amdgcn_sched_barrier(0);
 #define W4_PHASE(NH, MI0, FA, FB, RD, RHALF, RROW, ST_A, ST_H, ST_T)                                        \
         __builtin_amdgcn_s_barrier();                                                                       \
+        W4_FENCE                                                                                            \
+        const unsigned ko_##ST_A##ST_H = koff(ST_T);                                                        \
+        w4_set_m0(m0of(ST_T, (ST_A) ? (ST_H) : 2 + (ST_H)));                                                \
         W4_FENCE                                                                                            \
         w4_for<4>([&](auto qc) {                                                                            \
             constexpr int q = decltype(qc)::value, a0 = 16 * (8 * (NH) + (MI0) + q);                        \
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(256) void gemm_4w_kernel(const bf16_t *__restrict__
             W4_FENCE                                                                                        \
             w4_mfma<a0 + 4>(FA[q][1], FB[1][1]); W4_FENCE                                                   \
             w4_mfma<a0 + 8>(FA[q][0], FB[2][0]); W4_FENCE                                                   \
-            if (ST_A) stA(ST_H, ST_T, q); else stB(ST_H, ST_T, q);                                          \
+            w4_piece<q>((ST_A) ? rsX : rsW, (ST_A) ? offA[ST_H][q] : offB[ST_H][q], ko_##ST_A##ST_H);        \
             W4_FENCE                                                                                        \
             w4_mfma<a0 + 8>(FA[q][1], FB[2][1]); W4_FENCE                                                   \
             w4_mfma<a0 + 12>(FA[q][0], FB[3][0]); W4_FENCE                                                  \
