@@ -396,8 +396,8 @@ int fl_op_linear(const void *x, const void *w, const float *bias, int64_t T, int
             // the timed launches rotate over copies of W that together exceed the 256 MiB Infinity Cache: in the forward pass a
             // projection's weights always come from HBM, and a back-to-back replay on ONE copy would read them from the cache
             const size_t wbytes = (size_t)Nw * K * es;
-            // (FL_OP_HOT=1: one copy -- what the kernel would do with its weights already in the Infinity Cache)
-            const int ncopy = getenv("FL_OP_HOT") && atoi(getenv("FL_OP_HOT")) ? 1 : (int)std::min<size_t>(24, std::max<size_t>(1, (640u << 20) / wbytes + 1));
+            const int hot = getenv("FL_OP_HOT") ? atoi(getenv("FL_OP_HOT")) : 0;   // 1: one copy (L2 + Infinity Cache); n > 1: n copies (past the L2s, inside the Infinity Cache when n x bytes < 256 MiB)
+            const int ncopy = hot > 0 ? hot : (int)std::min<size_t>(24, std::max<size_t>(1, (640u << 20) / wbytes + 1));
             std::vector<void *> &copies = B.copies;
             copies.push_back(nullptr);                                   // slot 0 = B.w itself
             for (int c = 1; c < ncopy; c++) {
