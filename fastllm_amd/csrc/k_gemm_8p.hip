@@ -690,7 +690,8 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         // pieces aligned with the tiles keep the workgroups that share a W or X panel in lock step (its L2 hits): split every
         // tile into the same number of pieces, at most eight, while the grid fits the chip
         const int64_t nt = (int64_t)tiles_m * tiles_n, cus = cu_count();
-        const int64_t split = std::max<int64_t>(1, std::min<int64_t>({(int64_t)8, cus / std::max<int64_t>(1, nt), (K / P_BK) / 4}));
+        static const int sk_minsteps = getenv("FL_SK_MINSTEPS") ? std::max(2, atoi(getenv("FL_SK_MINSTEPS"))) : 8;   // K steps per piece, at least (Qwen2-7B 4k QKV tail: piece launch + fix-up 58.2 us at 4, 53.8 at 8, 53.0 at 12)
+        const int64_t split = std::max<int64_t>(1, std::min<int64_t>({(int64_t)8, cus / std::max<int64_t>(1, nt), (K / P_BK) / sk_minsteps}));
         const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>(nt * split, units / 2));
         FL_TRY(streamk_space(L.stream, nwg, &sk));
         grid = dim3((unsigned)nwg, 1);
