@@ -703,13 +703,17 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         return LF.launch(KC_GEMM_MFMA, 0.0, 0.0, gemm_8p_fixup_kernel, dim3((unsigned)(tiles_m * tiles_n * 8)), dim3(512), 0, bias, y, (int)T, (int)N,
                          (int)K, epi, tiles_m, tiles_n, row_scale, (int)ldc, (int)grid.x, sk, re, group_m);
     };
-    static const int four = [] { const char *e = getenv("FL_GEMM_4W"); return e ? atoi(e) : 1; }();
-    // the four-wave form of the same tile (same grid, workspace and fix-up).  FL_GEMM_4W: 0 never, 1 (default) where its longer
-    // prologue (32 pieces per wave up front, 9 us of fixed cost against 6) is paid for -- stream-K pieces and K slices of ten or
-    // more steps (Mistral-7B o_proj at T = 512, eight steps per slice: 28.3 us on eight waves, 31.3 on four) --, 2 always
+    const char *e4 = getenv("FL_GEMM_4W");                          // read per call: tests and A/B tools switch it
+    const int four = e4 && *e4 ? atoi(e4) : 1;
+    // the four-wave form of the same tile (same grid, workspace and fix-up).  FL_GEMM_4W: 0 never, 2 always, 1 (default) from 768
+    // tokens, stream-K pieces and K slices of ten or more steps.  The rule comes from an A/B inside one process, whole prefills back
+    // to back (tools/prefill_ab.py; ms, eight waves / four waves): Mistral-7B T = 512 8.75 / 8.83, 768 12.19 / 12.11, 1024 14.92 /
+    // 14.14, 2048 27.47 / 25.47, 4096 52.09 / 48.11; Qwen2-7B 512 8.85 / 9.16, 4096 49.52 / 46.11.  Launch by launch the four-wave
+    // kernel is 8-15 % faster at 512 tokens too (gate/up 116.7 -> 98.6 us between event pairs), but a sustained prefill of single-round
+    // grids gives that back in clock; from two rounds of tiles on it keeps 5-8 %.
     // (its DMA pieces address a lane's bytes as a 32-bit offset from the matrix base: matrices of 4 GiB or more stay on eight waves)
     const bool fits32 = (double)std::max(T, N) * (double)K * 2.0 < 4294967296.0;
-    if (four && fits32 && !getenv("FL_8P_STAMPS") && (four > 1 || streamk || (K / P_BK) / ksplit >= 10)) {
+    if (four && fits32 && !getenv("FL_8P_STAMPS") && (four > 1 || (T >= 768 && (streamk || (K / P_BK) / ksplit >= 10)))) {
         auto k4 = streamk ? gemm_4w_kernel<true> : gemm_4w_kernel<false>;
         FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(k4), P_LDS));
         snprintf(tag, sizeof tag, "4w,%lldx%lld%s%s", (long long)N, (long long)K, streamk ? ",streamK" : ksplit > 1 ? ",splitK" : "", resid ? ",resid" : "");

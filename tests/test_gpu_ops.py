@@ -109,7 +109,9 @@ def test_mfma_operand_maps_with_asymmetric_data(fa):
 @pytest.mark.parametrize("T,N,K,epi,bias", [(256, 256, 128, 0, True), (300, 700, 256, 0, True), (513, 1000, 1024, 0, False),
                                             (512, 4096, 4096, 0, False), (700, 1300, 192, 1, False), (260, 4096, 640, 1, False)])
 @pytest.mark.parametrize("force", ["2", None])
-def test_linear_8phase_kernel(fa, T, N, K, epi, bias, force, monkeypatch):
+@pytest.mark.parametrize("four", ["0", "2"])                  # the eight-wave kernel / its four-wave form (default: from 768 tokens)
+def test_linear_8phase_kernel(fa, T, N, K, epi, bias, force, four, monkeypatch):
+    monkeypatch.setenv("FL_GEMM_4W", four)
     if force:
         monkeypatch.setenv("FL_GEMM_8P", force)
     x, w = _rand((T, K), 11), _rand((N, K), 12, 0.05)
@@ -123,10 +125,12 @@ def test_linear_8phase_kernel(fa, T, N, K, epi, bias, force, monkeypatch):
         np.testing.assert_allclose(y, ref, atol=2e-5 * np.sqrt(K) + 1e-5, rtol=1e-5)
 
 
-def test_8phase_kernel_is_race_free_over_repeats(fa, monkeypatch):
+@pytest.mark.parametrize("four", ["0", "2"])
+def test_8phase_kernel_is_race_free_over_repeats(fa, monkeypatch, four):
     """The LDS-DMA hand-offs are ordered only by counted waits and barriers: a misplaced one shows up as rare
     wrong tiles.  Same inputs 30 times (different workgroup timing each launch): bit-identical outputs."""
     monkeypatch.setenv("FL_GEMM_8P", "2")
+    monkeypatch.setenv("FL_GEMM_4W", four)
     T, N, K = 1024, 2048, 2048
     xb, wb = synth.f32_to_bf16_bits(_rand((T, K), 21)), synth.f32_to_bf16_bits(_rand((N, K), 22, 0.05))
     first = fa.op_linear(xb, wb, None)
@@ -209,8 +213,10 @@ def test_linear_peeled_columns(fa, T, N, K, epi, bias):
 @pytest.mark.parametrize("T,N,K,epi,bias", [(2048, 3584, 4096, 0, False), (1024, 6144, 2624, 0, True), (2000, 3000, 1088, 0, True),
                                             (1024, 2176, 2624, 1, False), (300, 520, 512, 0, False),
                                             (1400, 1500, 1088, 0, True)])   # six row tiles: a group of four and a group of two (the four-wave kernel's tile order)
-def test_linear_streamk_whole(fa, monkeypatch, T, N, K, epi, bias):
+@pytest.mark.parametrize("four", ["0", "2"])
+def test_linear_streamk_whole(fa, monkeypatch, T, N, K, epi, bias, four):
     monkeypatch.setenv("FL_GEMM_STREAMK", "3")
+    monkeypatch.setenv("FL_GEMM_4W", four)
     x, w = _rand((T, K), 61), _rand((N if not epi else 2 * N, K), 62, 0.05)
     b = _rand((N,), 63) if bias else None
     xb, wb = synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w)
@@ -231,8 +237,10 @@ def test_linear_streamk_whole(fa, monkeypatch, T, N, K, epi, bias):
 # there): rows past T are clamped on load and skipped on store
 @pytest.mark.parametrize("T,N,K,epi,bias", [(130, 4096, 1024, 0, True), (200, 2048, 2048, 1, False), (255, 4608, 1024, 0, False),
                                             (257, 3072, 1024, 0, True), (257, 1536, 2048, 1, False)])
-def test_linear_8phase_ragged_rows(fa, monkeypatch, T, N, K, epi, bias):
+@pytest.mark.parametrize("four", ["0", "2"])
+def test_linear_8phase_ragged_rows(fa, monkeypatch, T, N, K, epi, bias, four):
     monkeypatch.setenv("FL_GEMM_8P", "2")
+    monkeypatch.setenv("FL_GEMM_4W", four)
     monkeypatch.setenv("FL_GEMM_SKINNY", "0")
     x, w = _rand((T, K), 71), _rand((N if not epi else 2 * N, K), 72, 0.05)
     b = _rand((N,), 73) if bias else None
