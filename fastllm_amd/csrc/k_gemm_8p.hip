@@ -713,7 +713,11 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
     // grids gives that back in clock; from two rounds of tiles on it keeps 5-8 %.
     // (its DMA pieces address a lane's bytes as a 32-bit offset from the matrix base: matrices of 4 GiB or more stay on eight waves)
     const bool fits32 = (double)std::max(T, N) * (double)K * 2.0 < 4294967296.0;
-    if (four && fits32 && !getenv("FL_8P_STAMPS") && (four > 1 || (T >= 768 && (streamk || (K / P_BK) / ksplit >= 10)))) {
+    // ... on matrices of K >= 3072 and N >= 3072 only: TinyLlama-1.1B (K = 2048; down_proj 2048 x 5632, eight column tiles) lost
+    // 3.5-5 % at 768-2048 tokens with it on either projection; with this rule it is untouched, Mistral-7B and Qwen2-7B keep
+    // their gains (768 tokens -0.6 / -3.6 %, 1024 -5.2 / -4.2 %, 4096 -7.7..-8.6 / -6.9..-7.9 %)
+    const int64_t ksteps = streamk ? K / P_BK : (K / P_BK) / ksplit;
+    if (four && fits32 && !getenv("FL_8P_STAMPS") && (four > 1 || (T >= 768 && ksteps >= 10 && K >= 3072 && (streamk || N >= 3072)))) {   // (N of a peeled tail is small: stream-K pieces go by K alone)
         auto k4 = streamk ? gemm_4w_kernel<true> : gemm_4w_kernel<false>;
         FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(k4), P_LDS));
         snprintf(tag, sizeof tag, "4w,%lldx%lld%s%s", (long long)N, (long long)K, streamk ? ",streamK" : ksplit > 1 ? ",splitK" : "", resid ? ",resid" : "");
