@@ -124,7 +124,7 @@ def test_four_wave_gemm_owns_its_accumulator_registers(tmp_path):
         txt = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", str(p)], capture_output=True, text=True, check=True).stdout
         if "gemm_4w_kernel" not in txt:
             continue
-        func, since_mfma, nmfma = None, None, 0
+        func, since_mfma, nmfma, recent = None, None, 0, []
         for line in txt.splitlines():
             m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
             if m:
@@ -137,13 +137,25 @@ def test_four_wave_gemm_owns_its_accumulator_registers(tmp_path):
             if not func or not m:
                 continue
             op, args = m.group(1), m.group(2)
+            if op.startswith("v_") and not op.startswith(("v_mfma", "v_accvgpr", "v_cmp", "v_readlane", "v_readfirstlane")):
+                d = re.match(r"v\[(\d+):(\d+)\]|v(\d+)", args)
+                recent = (recent + [(op, (int(d.group(1)), int(d.group(2))) if d and d.group(1) else (int(d.group(3)), int(d.group(3))) if d else None)])[-2:]
+            elif not op.startswith("v_mfma"):
+                recent = (recent + [(op, None)])[-2:]
             assert not op.startswith("scratch_"), "%s: scratch access\n%s" % (func, line)
             assert not op.startswith("v_accvgpr_mov"), "%s: compiler copy between accumulator registers\n%s" % (func, line)
             if op.startswith("v_accvgpr_write"):
                 assert re.search(r",\s*0$", args), "%s: a VGPR written into an accumulator register\n%s" % (func, line)
             if op.startswith("v_mfma"):
                 assert re.match(r"a\[\d+:\d+\]", args), "%s: MFMA outside the accumulator file\n%s" % (func, line)
+                # its A / B operands arrive by ds_read (hipcc waits for those); a VALU instruction writing one of them right in
+                # front of the asm MFMA would need wait states hipcc does not know to insert
+                srcs = [(int(a), int(b)) for a, b in re.findall(r"v\[(\d+):(\d+)\]", args)]
+                for pop, pdst in recent:
+                    for lo, hi in srcs:
+                        assert not (pdst and lo <= pdst[1] and pdst[0] <= hi), "%s: %s writes an MFMA operand two slots ahead\n%s" % (func, pop, line)
                 since_mfma, nmfma = 0, nmfma + 1
+                recent = (recent + [(op, None)])[-2:]
             elif since_mfma is not None:
                 if op.startswith("s_nop"):
                     since_mfma += int(args.split()[0], 0) + 1
