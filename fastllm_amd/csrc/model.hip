@@ -359,7 +359,7 @@ constexpr int kMaxKSplitMid = 8;
 constexpr int kMidT = 1024;
 constexpr int kMaxQkvSplit = 2;   // QKV projection of a long prompt (its grid leaves CUs idle); rope_kv sums the slabs
 constexpr int kMaxQkvSplitShort = 4;   // ... of a short prompt / a decode batch (T <= 128: the projection is a weight stream)
-static int mid_cap(int dflt) { static const int v = env_int("FL_KSPLIT_MID", 0); return v > 0 ? std::min(v, kMaxKSplitMid) : dflt; }
+static int mid_cap(int dflt) { const char *e = getenv("FL_KSPLIT_MID"); const int v = e && *e ? atoi(e) : 0; return v > 0 ? std::min(v, kMaxKSplitMid) : dflt; }   // (read per call: A/B tools lower it on a live model; the slabs were sized for the default)
 int ksplit_cap(int64_t T) { return T <= 1 ? 1 : (T > 128 && T <= kMidT ? mid_cap(kMaxKSplitMid) : kMaxKSplit); }
 static int qkv_split_cap(int64_t T) { return T <= 1 ? 1 : (T <= 128 ? kMaxQkvSplitShort : (T <= kMidT ? mid_cap(kMaxKSplitMid) : kMaxQkvSplit)); }
 // rows of slab storage that serve every prompt of at most T tokens

@@ -1,5 +1,6 @@
-"""A/B of the prefill GEMM kernels inside ONE process (same box, same clock history): alternates FL_GEMM_4W=0 / 1 over
-repeated prefills of T tokens, back to back (3 per sample) and prints the medians.  usage: prefill_ab.py [model] [T ...]"""
+"""A/B of a per-call switch inside ONE process (same box, same clock history): alternates two values of an environment variable
+(default FL_GEMM_4W=0 / 1: the eight-wave / four-wave prefill GEMM) over repeated prefills of T tokens, back to back (3 per sample),
+and prints the medians.  usage: prefill_ab.py [model] [T ...]   (AB_ENV=NAME AB_A=value AB_B=value pick another switch)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +10,7 @@ import fastllm_amd as fa
 from fastllm_amd.configs import MODEL_CONFIGS
 name = sys.argv[1] if len(sys.argv) > 1 else "mistral-7b"
 Ts = [int(t) for t in sys.argv[2:]] or [512]
+ENV, VA, VB = os.environ.get("AB_ENV", "FL_GEMM_4W"), os.environ.get("AB_A", "0"), os.environ.get("AB_B", "1")
 cfg = MODEL_CONFIGS[name]
 wts = bench.synth_device_weights(torch, cfg, torch.device("cuda", 0))
 gm = fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16")
@@ -17,17 +19,17 @@ rs = np.random.RandomState(0)
 for T in Ts:
     p = rs.randint(0, cfg["vocab_size"], size=T).astype(np.uint32)
     c = gm.new_cache(T + 8)
-    res = {"0": [], "1": []}
+    res = {VA: [], VB: []}
     for rep in range(7):
-        for mode in ("0", "1") if rep % 2 == 0 else ("1", "0"):
-            os.environ["FL_GEMM_4W"] = mode
+        for mode in (VA, VB) if rep % 2 == 0 else (VB, VA):
+            os.environ[ENV] = mode
             gm.forward_argmax(c, p, 0); c.reset()
             gm.synchronize(); t0 = time.perf_counter()
             for _ in range(3):
                 gm.forward_argmax(c, p, 0); c.reset()
             gm.synchronize()
             res[mode].append((time.perf_counter() - t0) / 3 * 1e3)
-    m0, m1 = np.median(res["0"]), np.median(res["1"])
-    print("%s T=%5d: eight waves %.3f ms (%.3f..%.3f)   four waves %.3f ms (%.3f..%.3f)   ratio %.3f" % (
-        name, T, m0, min(res["0"]), max(res["0"]), m1, min(res["1"]), max(res["1"]), m1 / m0), flush=True)
+    m0, m1 = np.median(res[VA]), np.median(res[VB])
+    print("%s T=%5d: %s=%s %.3f ms (%.3f..%.3f)   %s=%s %.3f ms (%.3f..%.3f)   ratio %.3f" % (
+        name, T, ENV, VA, m0, min(res[VA]), max(res[VA]), ENV, VB, m1, min(res[VB]), max(res[VB]), m1 / m0), flush=True)
     c.close()
