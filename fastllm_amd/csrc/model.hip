@@ -606,7 +606,12 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
     // MFMA kernel: 128 keys (four 32-key wave steps) per workgroup; VALU kernel: 64.  One CU pulls only
     // ~25-50 GB/s from HBM, so a kv head's K/V stream must be spread over many CUs -- except when it is
     // small (<= 96 KB per head): then one wide workgroup per head with no cross-workgroup combine wins.
-    int64_t ns = (int64_t)((max_seq + (c->v_transposed ? 127 : 63)) / (c->v_transposed ? 128 : 64));
+    // Long caches: 256 keys (two steps per wave) -- fewer workgroups and half the partials to combine.  A/B inside one process
+    // (tools/decode_ab.py, FL_ATTN_NSPLIT, tokens/s): Qwen2-7B at S = 4100 34 / 24 / 17 / 12 splits 361.3 / 363.1 / 364.9 / 359.6,
+    // Mistral-7B at S = 4100 34 / 17 splits 340.5 / 347.1, at S = 2100 18 / 9 splits 358.0 / 356.9, at S = 530 7 / 4 370.4 / 364.5.
+    // (A workgroup never takes fewer than 128 keys, so the split count of a large cache costs a short sequence nothing.)
+    const int64_t keys_per_wg = c->v_transposed ? (max_seq > 2560 ? 256 : 128) : 64;
+    int64_t ns = (int64_t)((max_seq + keys_per_wg - 1) / keys_per_wg);
     if (c->v_transposed && max_seq * (size_t)D.d * 4 <= 96 * 1024) ns = 1;
     c->nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(ns, c->v_transposed ? 48 : 64));   // (measured at S = 8192 / 16384: 32..48 splits 17.4 / 24.0 us, 64: 18.7 / 25.4)
     c->nsplit = env_int("FL_ATTN_NSPLIT", c->nsplit);
