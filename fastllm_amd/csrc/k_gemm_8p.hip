@@ -712,7 +712,7 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
     // kernel is 8-15 % faster at 512 tokens too (gate/up 116.7 -> 98.6 us between event pairs), but a sustained prefill of single-round
     // grids gives that back in clock; from two rounds of tiles on it keeps 5-8 %.
     // (its DMA pieces address a lane's bytes as a 32-bit offset from the matrix base: matrices of 4 GiB or more stay on eight waves)
-    const bool fits32 = (double)std::max(T, N) * (double)K * 2.0 < 4294967296.0;
+    const bool fits32 = (double)std::max(T, N) * (double)K * 2.0 + (double)K * 2.0 + 8192.0 < 4294967296.0;   // (+ the K offset and the 3072-byte bias of the lane offsets)
     // ... on matrices of K >= 3072 and N >= 3072 only: TinyLlama-1.1B (K = 2048; down_proj 2048 x 5632, eight column tiles) lost
     // 3.5-5 % at 768-2048 tokens with it on either projection; with this rule it is untouched, Mistral-7B and Qwen2-7B keep
     // their gains (768 tokens -0.6 / -3.6 %, 1024 -5.2 / -4.2 %, 4096 -7.7..-8.6 / -6.9..-7.9 %)
