@@ -68,7 +68,8 @@ GROUPS = [(8, 8), (32, 8), (28, 4), (8, 1)]                      # (H, Hkv): G =
 
 @pytest.mark.parametrize("d", [64, 128])
 @pytest.mark.parametrize("H,Hkv", GROUPS)
-@pytest.mark.parametrize("S,nsplit", [(1, 1), (31, 1), (127, 1), (128, 1), (129, 2), (300, 0), (640, 0), (1025, 0), (1025, 1), (2500, 48)])
+@pytest.mark.parametrize("S,nsplit", [(1, 1), (31, 1), (127, 1), (128, 1), (129, 2), (300, 0), (640, 0), (1025, 0), (1025, 1), (2500, 48),
+                                      (1025, 2), (2048, 4), (4100, 17), (4100, 34)])   # 4-wave splits of 2 / 4 / 4 / 2 (256-key) steps per wave: the long-cache rule
 def test_decode_kernel(fa, d, H, Hkv, S, nsplit):
     q, k, v = make(1, S - 1, H, Hkv, d, seed=S * 7 + d + H)
     got = fa.op_attention(q, k, v, S - 1, H, Hkv, d, kernel=1, nsplit=nsplit)
