@@ -722,7 +722,8 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(k4), P_LDS));
         snprintf(tag, sizeof tag, "4w,%lldx%lld%s%s", (long long)N, (long long)K, streamk ? ",streamK" : ksplit > 1 ? ",splitK" : "", resid ? ",resid" : "");
         LL.tag = tag;
-        static const int group_env = [] { const char *e = getenv("FL_GEMM_GROUPM"); return e ? atoi(e) : 0; }();
+        const char *eg = getenv("FL_GEMM_GROUPM");                  // read per call (A/B tools)
+        const int group_env = eg && *eg ? atoi(eg) : 0;
         group_m = std::max(1, std::min(tiles_m, group_env > 0 ? group_env : 4));   // 4: +3-4 % at T = 4096 over the 16 x 2 strip (8: +2-3, 2: +1)
         FL_TRY(LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, k4, grid, dim3(256), P_LDS, (const bf16_t *)W, (const bf16_t *)x,
                          bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, sk, re, group_m));
