@@ -122,6 +122,53 @@ def parity_check(torch, fa, binding, cfg, wts, local_rank, n_layers=4, T=512, n_
             "sample": "first %d of %d layers + lm_head, %d-token prefill + %d decode steps, single GPU" % (n_layers, cfg["num_hidden_layers"], T, n_decode)}
 
 
+def secondary_entry(torch, fa, binding, device, local_rank, name, T, gen, dtype="bf16", parity_layers=4, steps=None, with_parity=True):
+    """One of the other single-GPU BASELINE configs (or the headline workload in the fp32 parity mode), measured after the headline
+    with the same rules: its own parity gate against the oracle first, synthetic weights of the model's real shapes, the median of
+    three prefills, `steps` greedy decode steps behind the prompt timed between device syncs."""
+    from fastllm_amd.configs import MODEL_CONFIGS, decode_bytes_per_token, prefill_flops
+    cfg = MODEL_CONFIGS[name]
+    steps = steps or gen
+    wts = synth_device_weights(torch, cfg, device)
+    par = parity_check(torch, fa, binding, cfg, wts, local_rank, n_layers=parity_layers, T=min(T, 512), n_decode=4) if with_parity else None
+    m = fa.Model(cfg, as_fl_tensors(wts, local_rank), dtype=dtype, tp_mode=binding.TP_NONE, device_ids=[local_rank])
+    del wts
+    torch.cuda.empty_cache()
+    try:
+        rs = np.random.RandomState(1234)
+        prompt = rs.randint(0, cfg["vocab_size"], size=T).astype(np.uint32)
+        prompt[0] = 1
+        cache = m.new_cache(T + max(steps, 8) + 72)
+        first = m.forward_argmax(cache, prompt, 0)
+        m.decode_greedy(cache, first, T, 8)                          # warm-up + graph capture
+        samples = []
+        for _ in range(3):
+            cache.reset()
+            m.synchronize()
+            t0 = time.perf_counter()
+            first = m.forward_argmax(cache, prompt, 0)
+            m.synchronize()
+            samples.append(time.perf_counter() - t0)
+        t_prefill = sorted(samples)[1]
+        m.synchronize(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        toks = m.decode_greedy(cache, first, T, steps)
+        m.synchronize(); torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        assert len(toks) == steps
+        tok_s = steps / el
+        b_tok = decode_bytes_per_token(cfg, T + steps // 2, bytes_per_elem=2 if dtype == "bf16" else 4)
+        cache.close()
+        return {"workload": "%s %s greedy decode, %d-token prompt, %d generated tokens (%d timed), batch 1, TP=1" % (name, dtype, T, gen, steps),
+                "tokens_per_sec": round(tok_s, 2), "ms_per_step": round(el / steps * 1e3, 4),
+                "e2e_frac": round(tok_s * b_tok / 8e12, 4), "prefill_ms": round(t_prefill * 1e3, 2),
+                "prefill_tokens_per_sec": round(T / t_prefill, 1),
+                "mfma_frac": round(prefill_flops(cfg, T) / t_prefill / 2.5e15, 4) if dtype == "bf16" else None,
+                "parity_check": par, "tokens_crc32": zlib.crc32(np.asarray(toks, dtype=np.uint32).tobytes())}
+    finally:
+        m.close()
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` run directly: start `python -m torch.distributed.run --nproc-per-node N bench.py ...`
     as a CHILD process (never exec: under `rocprofv3 -- python3 bench.py` the profiler has already initialised the GPU
@@ -168,6 +215,7 @@ def main():
     ap.add_argument("--model", default=os.environ.get("FL_BENCH_MODEL", "mistral-7b"))
     ap.add_argument("--prompt", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other single-GPU configs and the fp32-mode figure")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -455,6 +503,35 @@ def main():
         except Exception as e:                                               # the headline line must not depend on it
             log("batched decode leg failed:", repr(e))
 
+    # ---- the other single-GPU BASELINE configs and the fp32 parity mode, each behind its own parity gate (N = 1, default model only):
+    #      configs[1] TinyLlama-1.1B 128 / 128; configs[4]'s single-GPU half, Qwen2-7B 4096-token prefill + decode at S = 4097..;
+    #      and the headline workload in fp32 mode, the mode that meets north_star's literal 1e-3 / bit-exact-ids bar.
+    #      The headline's numbers are complete at this point: nothing below can take them down. ----
+    secondary, fp32_mode = None, None
+    if world == 1 and rank == 0 and args.model == "mistral-7b" and not args.no_secondary and os.environ.get("FL_BENCH_SECONDARY", "1") == "1":
+        secondary = []
+        for nm, t_, gen_, steps_ in (("tinyllama-1.1b", 128, 128, 128), ("qwen2-7b", 4096, 64, 64)):
+            try:
+                t0 = time.perf_counter()
+                e = secondary_entry(torch, fa, binding, device, local_rank, nm, t_, gen_, steps=steps_)
+                if not (e["parity_check"] and e["parity_check"]["ok"]):
+                    e["tokens_per_sec"] = None; e["invalid"] = "parity gate failed"
+                secondary.append(e)
+                log("secondary %s: %s tokens/s, prefill %.2f ms (%.1fs)" % (nm, e["tokens_per_sec"], e["prefill_ms"], time.perf_counter() - t0))
+            except Exception as ex:                                          # noqa: the headline line must not depend on it
+                log("secondary %s failed: %r" % (nm, ex))
+                secondary.append({"workload": nm, "error": repr(ex)})
+        try:
+            t0 = time.perf_counter()
+            e = secondary_entry(torch, fa, binding, device, local_rank, args.model, T, K, dtype="f32", steps=min(K, 32), with_parity=False)
+            fp32_mode = {"tokens_per_sec": e["tokens_per_sec"], "ms_per_step": e["ms_per_step"], "prefill_ms": e["prefill_ms"], "workload": e["workload"],
+                         "note": "fp32 weights / activations / KV: the mode tests/test_gpu_literal_configs.py holds to logits within 1e-3 of the "
+                                 "oracle and identical greedy ids over this very workload (512 / 256, all 32 layers); 4 bytes per weight"}
+            log("fp32 mode: %s tokens/s (%.1fs)" % (e["tokens_per_sec"], time.perf_counter() - t0))
+        except Exception as ex:                                              # noqa
+            log("fp32-mode leg failed: %r" % (ex,))
+            fp32_mode = {"error": repr(ex)}
+
     # every rank's own kernel times (a tensor-parallel step is as slow as its slowest rank's launches + collectives)
     per_rank = None
     if world > 1:
@@ -513,6 +590,9 @@ def main():
             "parity_check": parity,
             "tokens_crc32": my_crc, "ranks_agree": ranks_agree,
             "batched_decode": batch8,
+            "secondary": secondary,
+            "fp32_mode_tokens_per_sec": fp32_mode["tokens_per_sec"] if fp32_mode and "tokens_per_sec" in fp32_mode else None,
+            "fp32_mode": fp32_mode,
             "host_loop": {"tokens_per_sec": round(1.0 / t_host_loop, 2),
                           "note": "fl_forward per token: logits (V fp32) to the host + host argmax, PCIe-inclusive"},
             "prefill": {"tokens": T, "tokens_per_sec": round(T / t_prefill, 1), "ms": round(t_prefill * 1e3, 2), "timing": "median of 3 calls",

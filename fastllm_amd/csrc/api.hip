@@ -121,7 +121,8 @@ int fl_model_get_info(const fl_model *m, fl_model_info *out) {
         out->hbm_bytes_allocated = mm->hbm_bytes;
         for (auto &sh : mm->shards) {                           // + the stream-K workspace of each shard's streams (first long prompt)
             if (hipSetDevice(sh.device) != hipSuccess) continue;
-            out->hbm_bytes_allocated += gemm_8p_workspace_bytes(sh.stream) + gemm_8p_workspace_bytes(sh.comm_stream);
+            out->hbm_bytes_allocated += gemm_8p_workspace_bytes(sh.stream) + gemm_8p_workspace_bytes(sh.comm_stream) + gemm_h4_workspace_bytes(sh.stream) +
+                                        gemm_h4_workspace_bytes(sh.comm_stream);
         }
         out->small_collectives = mm->shards[0].pc.connected ? 2 : mm->tp == 1 ? 0 : mm->tp_mode == FL_TP_EMULATED ? 3 : 1;
         out->fused_all_reduce = fused_all_reduce_ready(mm) ? 1 : 0;
@@ -300,7 +301,8 @@ int fl_tune(const char *key, int value) {
         else if (!strcmp(key, "gemv_blocks")) gemv_set_tuning(0, 0, value, -1);        // 0 = automatic
         else if (!strcmp(key, "gemv_waves")) gemv_set_tuning(0, 0, -1, value);          // 0 = automatic
         else if (!strcmp(key, "engine_grid")) engine_set_grid(value);                   // 0 = one workgroup per CU (tests: a grid that cannot be resident)
-        else FL_FAIL(FL_ERR_BAD_ARGUMENT, "unknown tuning key %s", key);
+        else if (!strcmp(key, "reload_env")) tune_reload_env();                        // re-read every FL_<NAME> switch of the table (common.h)
+        else if (tune_set(key, value) != FL_OK) FL_FAIL(FL_ERR_BAD_ARGUMENT, "unknown tuning key %s", key);
         return FL_OK;
     });
 }
@@ -351,7 +353,7 @@ int fl_op_linear(const void *x, const void *w, const float *bias, int64_t T, int
                       std::vector<void *> copies;
                       ~Bufs() { (void)hipFree(x); (void)hipFree(w); (void)hipFree(ws); (void)hipFree(y); (void)hipFree(b);
                                 for (size_t i = 1; i < copies.size(); i++) (void)hipFree(copies[i]);
-                                if (s) { (void)hipStreamSynchronize(s); gemm_8p_release_stream(s); (void)hipStreamDestroy(s); }
+                                if (s) { (void)hipStreamSynchronize(s); gemm_8p_release_stream(s); gemm_h4_release_stream(s); (void)hipStreamDestroy(s); }
                                 if (e0) (void)hipEventDestroy(e0);
                                 if (e1) (void)hipEventDestroy(e1); } } B;
         FL_HIP(hipStreamCreate(&B.s));

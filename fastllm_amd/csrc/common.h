@@ -25,6 +25,21 @@ const char *last_error();
 // the same instantiation on every GPU of the group).
 int raise_dynamic_lds(const void *fn, size_t lds_bytes);
 
+// ---- process-wide switches -------------------------------------------------------------------
+// Every kernel-selection knob is an int in ONE table (model.hip, g_tune_table): read once from the environment (FL_<NAME>) when first
+// used, afterwards changed only through fl_tune(name, value) ("reload_env" re-reads the environment: tests and A/B tools).
+// No per-launch getenv.
+enum TuneKey {
+    TK_GEMM_H4 = 0,        // 128 x 256 GEMM with in-launch K-slice sums: 0 never, 1 where the cost model prefers it, 2 wherever it is supported
+    TK_H4_SPLIT,           // 0: as the model; 1..4: K slices it uses (probes, tests)
+    TK_H4_PF,              // its L2 prefetch of the W panel: K tiles ahead + 256 x lanes per 128-byte line (0: off)
+    TK_H4_WAIT_US,         // how long an early K slice waits for the others before it leaves its share to the last one
+    TK_COUNT
+};
+int tune(TuneKey k);
+int tune_set(const char *name, int value);   // FL_OK, or FL_ERR_BAD_ARGUMENT for an unknown name
+void tune_reload_env();
+
 // ---- element types ------------------------------------------------------------------------
 typedef uint16_t bf16_t;   // raw bf16 bits in memory
 

@@ -392,6 +392,7 @@ int gemm_resid_partials(int64_t N) { return (int)((N + 255) / 256) * 4; }
 bool gemm_resid_supported(int dtype, int64_t T, int64_t N, int64_t K, int max_split) {
     const char *e = getenv("FL_GEMM_RESID");                     // read per call: tests switch it
     if (e && *e && atoi(e) == 0) return false;
+    if (dtype == FL_DTYPE_BF16 && N % 16 == 0 && gemm_h4_plan(T, N, K, EPI_RESID) > 0) return true;   // mid-size prompts: k_gemm_h4.hip
     const char *e8 = getenv("FL_GEMM_8P");
     if (dtype != FL_DTYPE_BF16 || (e8 && *e8 && atoi(e8) != 1) || T < 256 || K % 64 || K / 64 < 2 || N % 16) return false;
     if (gemm_streamk_whole(T, N, K, EPI_F32)) return false;
@@ -412,6 +413,7 @@ bool gemm_resid_supported(int dtype, int64_t T, int64_t N, int64_t K, int max_sp
 }
 int launch_gemm_resid(Launcher &L, const void *W, const void *x, int64_t T, int64_t N, int64_t K, const ResidEpi &re) {
     if (re.np != gemm_resid_partials(N)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_resid: partial-sum layout");
+    if (const int ks = gemm_h4_plan(T, N, K, EPI_RESID)) return launch_gemm_h4(L, W, x, nullptr, nullptr, T, N, K, EPI_RESID, nullptr, ks, N, &re);
     int64_t n_main = 0;
     if (peel_plan(T, N, K, &n_main)) {
         FL_TRY(launch_gemm_8p(L, W, x, nullptr, nullptr, T, n_main, K, EPI_RESID, nullptr, 1, N, false, &re));

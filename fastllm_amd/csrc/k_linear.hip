@@ -112,6 +112,11 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
     static const int force_generic = env_int("FL_FORCE_GENERIC_GEMM", 0);
     if (dtype == FL_DTYPE_BF16) {
         if (T == 1 && gemv_supported(dtype, N, K)) return launch_gemv(L, dtype, plain_args(W, x, bias, y, N, K, epi, row_scale));
+        // mid-size prompts: 128 x 256 tiles, K slices summed inside the launch (k_gemm_h4.hip) -- one complete output, no slabs
+        if (!force_generic && T > 1) {
+            const int ks = gemm_h4_plan(T, N, K, epi);
+            if (ks > 0) return launch_gemm_h4(L, W, x, bias, y, T, N, K, epi, row_scale, ks);
+        }
         static const int use_skinny = env_int("FL_GEMM_SKINNY", 1);
         if (!force_generic && use_skinny && gemm_skinny_supported(T, N, K)) {     // short prompts: a weight stream
             const int ks = (n_split_out && !bias) ? gemm_skinny_ksplit(T, N, K, epi, std::min(max_split, 4)) : 1;   // (more slabs cost the summing launch more than they save here)

@@ -18,8 +18,12 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <ctype.h>
+
 #include <algorithm>
+#include <atomic>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 
@@ -34,6 +38,40 @@ const char *last_error() { return g_err; }
 
 
 int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
+
+// ------------------------------------------------------------------------------- switches (common.h: TuneKey)
+struct TuneEntry { const char *name; int dflt; };
+static const TuneEntry g_tune_table[TK_COUNT] = {
+    {"gemm_h4", 1},
+    {"h4_split", 0},
+    {"h4_pf", 6},
+    {"h4_wait_us", 30},
+};
+static std::atomic<int> g_tune[TK_COUNT];
+static std::once_flag g_tune_once;
+static void tune_read_env() {
+    for (int k = 0; k < TK_COUNT; k++) {
+        char env[64] = "FL_";
+        size_t n = 3;
+        for (const char *c = g_tune_table[k].name; *c && n + 1 < sizeof env; c++) env[n++] = (char)toupper((unsigned char)*c);
+        env[n] = 0;
+        g_tune[k].store(env_int(env, g_tune_table[k].dflt), std::memory_order_relaxed);
+    }
+}
+int tune(TuneKey k) {
+    std::call_once(g_tune_once, tune_read_env);
+    return g_tune[k].load(std::memory_order_relaxed);
+}
+int tune_set(const char *name, int value) {
+    std::call_once(g_tune_once, tune_read_env);
+    for (int k = 0; k < TK_COUNT; k++)
+        if (!strcmp(name, g_tune_table[k].name)) { g_tune[k].store(value, std::memory_order_relaxed); return FL_OK; }
+    return FL_ERR_BAD_ARGUMENT;
+}
+void tune_reload_env() {
+    std::call_once(g_tune_once, tune_read_env);
+    tune_read_env();
+}
 
 int raise_dynamic_lds(const void *fn, size_t lds) {
     if (lds < 64 * 1024) return FL_OK;
@@ -151,6 +189,7 @@ Model::~Model() {
         if (s.stream && std::find(closed.begin(), closed.end(), s.stream) == closed.end()) {
             closed.push_back(s.stream);
             gemm_8p_release_stream(s.stream);
+            gemm_h4_release_stream(s.stream);
             (void)hipStreamDestroy(s.stream);
         }
     }
@@ -362,6 +401,10 @@ constexpr int kMaxQkvSplitShort = 4;   // ... of a short prompt / a decode batch
 static int mid_cap(int dflt) { const char *e = getenv("FL_KSPLIT_MID"); const int v = e && *e ? atoi(e) : 0; return v > 0 ? std::min(v, kMaxKSplitMid) : dflt; }   // (read per call: A/B tools lower it on a live model; the slabs were sized for the default)
 int ksplit_cap(int64_t T) { return T <= 1 ? 1 : (T > 128 && T <= kMidT ? mid_cap(kMaxKSplitMid) : kMaxKSplit); }
 static int qkv_split_cap(int64_t T) { return T <= 1 ? 1 : (T <= 128 ? kMaxQkvSplitShort : (T <= kMidT ? mid_cap(kMaxKSplitMid) : kMaxQkvSplit)); }
+// the same caps with the switch at its largest value: what the slab buffers are SIZED for (a later, larger FL_KSPLIT_MID must
+// never write past a buffer that was allocated while it was lowered)
+static int ksplit_cap_max(int64_t T) { return T <= 1 ? 1 : (T > 128 && T <= kMidT ? kMaxKSplitMid : kMaxKSplit); }
+static int qkv_split_cap_max(int64_t T) { return T <= 1 ? 1 : (T <= 128 ? kMaxQkvSplitShort : (T <= kMidT ? kMaxKSplitMid : kMaxQkvSplit)); }
 // rows of slab storage that serve every prompt of at most T tokens
 static int64_t slab_rows(int64_t T, int (*cap)(int64_t)) {
     return std::max<int64_t>({T * cap(T), std::min<int64_t>(T, kMidT) * cap(std::min<int64_t>(T, kMidT)), std::min<int64_t>(T, 128) * cap(std::min<int64_t>(T, 128))});
@@ -378,11 +421,11 @@ static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T, std::vecto
     FL_TRY(dev_alloc(own, (void **)&sc.x_res, (size_t)T * D.h * 4, acct));
     if (T == 1) FL_TRY(dev_alloc(own, (void **)&sc.x_res2, (size_t)D.h * 4, acct));
     // split-K slabs of any prompt <= T; decode: one partial vector per kv head (fused attention + o_proj launch)
-    FL_TRY(dev_alloc(own, (void **)&sc.delta, (size_t)std::max<int64_t>(slab_rows(T, ksplit_cap), T == 1 ? sh.Hkvs : 0) * D.h * 4, acct));
+    FL_TRY(dev_alloc(own, (void **)&sc.delta, (size_t)std::max<int64_t>(slab_rows(T, ksplit_cap_max), T == 1 ? sh.Hkvs : 0) * D.h * 4, acct));
     FL_TRY(dev_alloc(own, &sc.xn, (size_t)T * D.h * es, acct));
     FL_TRY(dev_alloc(own, (void **)&sc.inv_rms, (size_t)T * 4, acct));
-    if (T >= 256) FL_TRY(dev_alloc(own, (void **)&sc.rs_part, (size_t)T * gemm_resid_partials(D.h) * 4, acct));
-    FL_TRY(dev_alloc(own, (void **)&sc.qkv, (size_t)slab_rows(T, qkv_split_cap) * nq * 4, acct));    // split-K slabs of any prompt <= T
+    if (T > 128) FL_TRY(dev_alloc(own, (void **)&sc.rs_part, (size_t)T * gemm_resid_partials(D.h) * 4, acct));
+    FL_TRY(dev_alloc(own, (void **)&sc.qkv, (size_t)slab_rows(T, qkv_split_cap_max) * nq * 4, acct));    // split-K slabs of any prompt <= T
     FL_TRY(dev_alloc(own, &sc.q, (size_t)T * sh.Hs * D.d * es, acct));
     FL_TRY(dev_alloc(own, &sc.ao, (size_t)T * sh.Hs * D.d * es, acct));
     FL_TRY(dev_alloc(own, &sc.act, (size_t)T * sh.Ip * es, acct));
@@ -1060,7 +1103,7 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
     int nslab = 1;                        // slabs the current delta consists of (same on every shard)
     // Long prompts on one GPU: where the 256x256 kernel takes o_proj / down_proj in one piece, its epilogue adds the residual,
     // writes the next norm's x * w and leaves partial sums of squares (EPI_RESID) -- no delta round trip, no rmsnorm_add launch.
-    const bool resid_ok = ns == 1 && m->tp == 1 && !m->shards[0].comm && dt == FL_DTYPE_BF16 && T >= 256 && SC(m->shards[0]).rs_part != nullptr;
+    const bool resid_ok = ns == 1 && m->tp == 1 && !m->shards[0].comm && dt == FL_DTYPE_BF16 && T > 128 && SC(m->shards[0]).rs_part != nullptr;
     bool norm_done = false;               // xn / inv_rms for the upcoming norm were produced by the previous projection
     auto linear_resid = [&](Launcher &L, Shard &sh, Scratch &sc, const void *W, const void *x, int64_t K, const float *next_norm_w) -> int {
         ResidEpi re;

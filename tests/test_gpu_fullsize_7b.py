@@ -207,7 +207,9 @@ def test_mistral_7b_long_prompt_chunked(env, monkeypatch):
     gm.close()
 
 
-@pytest.mark.parametrize("name,T", [("qwen2-7b", 4096), ("mistral-7b", 4100)])
+@pytest.mark.parametrize("name,T", [("qwen2-7b", 4096), ("mistral-7b", 4100),
+                                    # mid-size prompts: the 128 x 256 kernel whose K slices meet inside the launch (k_gemm_h4.hip) runs the same epilogue
+                                    ("mistral-7b", 512), ("mistral-7b", 300), ("qwen2-7b", 640)])
 def test_long_prompt_residual_epilogue_equals_rmsnorm_launches(env, monkeypatch, name, T):
     """Long prompts: the 256x256 GEMM's residual epilogue (h += y, next norm's x*w, partial sums of squares -> 1/rms;
     EPI_RESID) against the separate rmsnorm_add launches it replaces (FL_GEMM_RESID=0), full width, 3 layers: the same
@@ -232,6 +234,8 @@ def test_long_prompt_residual_epilogue_equals_rmsnorm_launches(env, monkeypatch,
         c.close()
     assert not any("finalize" in n or "resid" in n for n in out["0"][2]), out["0"][2]
     assert sum(v for n, v in out["1"][2].items() if "resid" in n) >= 2 * 3, out["1"][2]      # o_proj and down_proj of every layer
+    if T <= 640:
+        assert sum(v for n, v in out["1"][2].items() if "h4," in n and "sliced" in n) == 2 * 3, out["1"][2]
     for k in (0, 1):
         a, b = out["1"][k], out["0"][k]
         # (noise floor of the bf16 pipeline: 3.5e-3 measured here; 5.6e-3 between the 256x256 and the 128x128 GEMM kernels, which

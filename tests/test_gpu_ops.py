@@ -251,3 +251,47 @@ def test_linear_8phase_ragged_rows(fa, monkeypatch, T, N, K, epi, bias, four):
         np.testing.assert_allclose(y, ref, atol=2e-3, rtol=2 ** -7)
     else:
         np.testing.assert_allclose(y, ref, atol=2e-5 * np.sqrt(K) + 1e-5, rtol=1e-5)
+
+
+# 128 x 256 GEMM whose K slices meet inside the launch (k_gemm_h4.hip): forced on (gemm_h4 = 2) with 1-4 slices.  Integer operands:
+# the sum of the slices is exact in any order, so a wrong block, a missed slice or a stale partial shows as a wrong integer.
+# wait_us = 0 makes every early slice abandon its blocks at once, so that the slice counted last finishes them from memory
+# (the rescue path, which ordinary timing never takes).
+@pytest.mark.parametrize("T,N,K", [(128, 256, 64), (130, 300, 512), (512, 4096, 4096), (257, 1000, 1024), (300, 520, 6400), (640, 4096, 2048)])
+@pytest.mark.parametrize("slices", [1, 2, 3, 4])
+@pytest.mark.parametrize("wait_us", [30, 0])
+def test_linear_h4_slices_meet_in_the_launch(fa, T, N, K, slices, wait_us):
+    if K // 64 < slices or (slices == 1 and wait_us == 0):
+        pytest.skip("no such case")
+    rs = np.random.RandomState(T + N + K)
+    x = rs.randint(-3, 4, size=(T, K)).astype(np.float32)
+    w = rs.randint(-3, 4, size=(N, K)).astype(np.float32)
+    ref = (x.astype(np.float64) @ w.astype(np.float64).T).astype(np.float32)
+    xb, wb = synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w)
+    try:
+        fa.tune("gemm_h4", 2); fa.tune("h4_split", slices); fa.tune("h4_wait_us", wait_us)
+        y = fa.op_linear(xb, wb, None)
+        np.testing.assert_array_equal(y, ref)
+        for _ in range(6):                                        # the tile words alternate between two sets: several launches in a row
+            np.testing.assert_array_equal(fa.op_linear(xb, wb, None), y)
+    finally:
+        fa.tune("reload_env", 0)
+
+
+@pytest.mark.parametrize("T,N,K,epi,bias", [(512, 4096, 4096, 0, True), (200, 1408, 1024, 1, False), (384, 704, 512, 1, False), (300, 1000, 1024, 0, True)])
+@pytest.mark.parametrize("slices", [1, 2, 4])
+def test_linear_h4_epilogues(fa, T, N, K, epi, bias, slices):
+    """bias and the SiLU-gate epilogue behind the in-launch sum (a K-sliced launch of the older kernels could run neither)."""
+    x, w = _rand((T, K), 81), _rand((N if not epi else 2 * N, K), 82, 0.05)
+    b = _rand((N,), 83) if bias else None
+    xb, wb = synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w)
+    ref = _ref(synth.bf16_bits_to_f32(xb), synth.bf16_bits_to_f32(wb), b, epi)
+    try:
+        fa.tune("gemm_h4", 2); fa.tune("h4_split", slices)
+        y = fa.op_linear(xb, wb, b, epilogue=epi)
+    finally:
+        fa.tune("reload_env", 0)
+    if epi:
+        np.testing.assert_allclose(y, ref, atol=2e-3, rtol=2 ** -7)
+    else:
+        np.testing.assert_allclose(y, ref, atol=2e-5 * np.sqrt(K) + 1e-5, rtol=1e-5)
