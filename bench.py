@@ -305,6 +305,8 @@ def main():
             os.environ["FL_TP_OVERLAP"] = "0"
         if level >= 2:
             os.environ["FL_ONESHOT"] = "0"
+        if level >= 1:
+            fa.reload_env()                              # the library reads its switches once: have them re-read
         model = build_model()
         if world == 1:
             break

@@ -374,6 +374,16 @@ def tune(key, value):
     _check(lib().fl_tune(key.encode(), int(value)))
 
 
+def reload_env():
+    """The library reads its FL_<NAME> switches from the environment ONCE (first use); after changing os.environ in a live process
+    call this to have every switch re-read."""
+    _check(lib().fl_tune(b"reload_env", 0))
+
+
+def library_loaded():
+    return _LIB is not None
+
+
 def op_attention(q, k, v, s_past, H, Hkv, d, window=-1, kernel=0, nsplit=0):
     """The bf16 MFMA attention kernels alone.  q [T, H*d], k / v [s_past + T, Hkv*d]: uint16 bf16 bits; returns [T, H*d] f32."""
     q, k, v = (np.ascontiguousarray(a, dtype=np.uint16) for a in (q, k, v))

@@ -108,18 +108,24 @@ int fl_model_get_info(const fl_model *m, fl_model_info *out) {
         const Dims &D = mm->D;
         memset(out, 0, sizeof *out);
         out->cfg = mm->cfg_resolved;
-        out->head_dim = D.d;
+        out->head_dim = D.dm;                                    // the model's (the kernels may run it padded to 64 / 128)
         out->compute_dtype = mm->dtype;
         out->tp_size = mm->tp;
         const int64_t es = (int64_t)mm->esize();
         // weights read once per decoded token (one embedding row, norms, biases
         // included; the rest of the embedding table excluded)
-        int64_t per_layer = 2 * D.h * D.h + 2 * D.Hkv * D.d * D.h + 3 * D.h * D.inter;
-        int64_t small = 2 * D.h + (D.qkv_bias ? D.h + 2 * D.Hkv * D.d : 0);
+        int64_t per_layer = 2 * D.h * D.h + 2 * D.Hkv * D.dm * D.h + 3 * D.h * D.inter;
+        int64_t small = 2 * D.h + (D.qkv_bias ? D.h + 2 * D.Hkv * D.dm : 0);
         out->weight_bytes_per_token = es * (D.L * (per_layer + small) + D.h + D.V * D.h);
-        out->kv_bytes_per_position = es * D.L * D.Hkv * D.d * 2;
+        out->kv_bytes_per_position = es * D.L * D.Hkv * D.dm * 2;
         out->hbm_bytes_allocated = mm->hbm_bytes;
-        for (auto &sh : mm->shards) {                           // + the stream-K workspace of each shard's streams (first long prompt)
+        // + the GEMM workspaces of each shard's streams (first long prompt).  The workspace tables are keyed by (current device,
+        // stream): the calling thread's device is put back afterwards, and forward() is kept out meanwhile (it sets devices too).
+        std::lock_guard<std::mutex> lock(const_cast<Model *>(mm)->mu);
+        int dev0 = -1;
+        (void)hipGetDevice(&dev0);
+        struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{dev0};
+        for (auto &sh : mm->shards) {
             if (hipSetDevice(sh.device) != hipSuccess) continue;
             out->hbm_bytes_allocated += gemm_8p_workspace_bytes(sh.stream) + gemm_8p_workspace_bytes(sh.comm_stream) + gemm_h4_workspace_bytes(sh.stream) +
                                         gemm_h4_workspace_bytes(sh.comm_stream);
@@ -295,12 +301,17 @@ int fl_profile_end(fl_model *m, fl_kernel_stat *stats, size_t cap, size_t *n_sta
 
 int fl_tune(const char *key, int value) {
     return guarded([&]() -> int {
-        if (!key || value < 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "bad tuning key/value");
+        if (!key || value < -1) FL_FAIL(FL_ERR_BAD_ARGUMENT, "bad tuning key/value");       // (-1: "automatic", for the switches that have it)
         if (!strcmp(key, "gemv_r")) gemv_set_tuning(value, 0, -1, -1);
         else if (!strcmp(key, "gemv_u")) gemv_set_tuning(0, value, -1, -1);
         else if (!strcmp(key, "gemv_blocks")) gemv_set_tuning(0, 0, value, -1);        // 0 = automatic
         else if (!strcmp(key, "gemv_waves")) gemv_set_tuning(0, 0, -1, value);          // 0 = automatic
         else if (!strcmp(key, "engine_grid")) engine_set_grid(value);                   // 0 = one workgroup per CU (tests: a grid that cannot be resident)
+        else if (!strcmp(key, "experimental")) {                                        // is this the EXPERIMENTAL build? (tests skip otherwise)
+#ifndef FL_EXPERIMENTAL
+            FL_FAIL(FL_ERR_UNSUPPORTED, "default build: the experimental kernels (decode engine, fused attention + o_proj, attention prefetch, loader waves) are not compiled in");
+#endif
+        }
         else if (!strcmp(key, "reload_env")) tune_reload_env();                        // re-read every FL_<NAME> switch of the table (common.h)
         else if (tune_set(key, value) != FL_OK) FL_FAIL(FL_ERR_BAD_ARGUMENT, "unknown tuning key %s", key);
         return FL_OK;
@@ -360,7 +371,7 @@ int fl_op_linear(const void *x, const void *w, const float *bias, int64_t T, int
         FL_HIP(hipMalloc(&B.x, (size_t)T * K * es));
         FL_HIP(hipMalloc(&B.w, (size_t)Nw * K * es));
         const size_t ybytes = (size_t)T * Ny * (epilogue == EPI_GATEUP ? es : 4);
-        static const int op_split = getenv("FL_OP_MAXSPLIT") ? atoi(getenv("FL_OP_MAXSPLIT")) : 0;
+        const int op_split = tune(TK_OP_MAXSPLIT);
         const int max_split = (epilogue == EPI_F32 && !bias) ? (op_split > 0 ? op_split : std::max(4, ksplit_cap(T))) : 1;      // exercise split-K where the model would
         int nsplit = 1;
         FL_HIP(hipMalloc(&B.y, ybytes * max_split));
@@ -381,7 +392,7 @@ int fl_op_linear(const void *x, const void *w, const float *bias, int64_t T, int
         }
         // FL_OP_LINEAR_DMA=1: T <= 8 rows go through the batched-decode projection kernel (k_gemv_dma.hip) instead, so that
         // its weight-streaming rate can be measured (and its arithmetic tested) without a model around it
-        const bool use_dma = getenv("FL_OP_LINEAR_DMA") && atoi(getenv("FL_OP_LINEAR_DMA")) == 1;
+        const bool use_dma = tune(TK_OP_LINEAR_DMA) == 1;
         const bool dma = use_dma && dtype == FL_DTYPE_BF16 && T <= 8 && !B.b && gemv_dma_supported((int)T, Nw, K, epilogue, 0) &&
                          gemv_dma_ksplit(K, Nw, epilogue) <= max_split;
         auto run = [&](const void *wp) -> int {
@@ -398,7 +409,7 @@ int fl_op_linear(const void *x, const void *w, const float *bias, int64_t T, int
             // the timed launches rotate over copies of W that together exceed the 256 MiB Infinity Cache: in the forward pass a
             // projection's weights always come from HBM, and a back-to-back replay on ONE copy would read them from the cache
             const size_t wbytes = (size_t)Nw * K * es;
-            const int hot = getenv("FL_OP_HOT") ? atoi(getenv("FL_OP_HOT")) : 0;   // 1: one copy (L2 + Infinity Cache); n > 1: n copies (past the L2s, inside the Infinity Cache when n x bytes < 256 MiB)
+            const int hot = tune(TK_OP_HOT);   // 1: one copy (L2 + Infinity Cache); n > 1: n copies (past the L2s, inside the Infinity Cache when n x bytes < 256 MiB)
             const int ncopy = hot > 0 ? hot : (int)std::min<size_t>(24, std::max<size_t>(1, (640u << 20) / wbytes + 1));
             std::vector<void *> &copies = B.copies;
             copies.push_back(nullptr);                                   // slot 0 = B.w itself

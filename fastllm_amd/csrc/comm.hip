@@ -21,7 +21,7 @@ int comm_alloc(Model *m, Shard &sh) {
     PeerComm &pc = sh.pc;
     FL_HIP(hipSetDevice(sh.device));
     // a slot holds at least one rank's share of the logits, so the per-step gather is always a one-shot collective
-    pc.nmax = (std::max<int64_t>(std::max<int64_t>(env_int("FL_AR_INBOX_FLOATS", 65536), sh.Vs), 4) + 3) / 4 * 4;
+    pc.nmax = (std::max<int64_t>(std::max<int64_t>(tune(TK_AR_INBOX_FLOATS), sh.Vs), 4) + 3) / 4 * 4;
     pc.ll_off = (kCommFlagBytes + (size_t)2 * m->tp * pc.nmax * 4 + 255) & ~(size_t)255;
     pc.bytes = pc.ll_off + (size_t)2 * m->tp * m->D.h * 8;
     FL_HIP(hipExtMallocWithFlags(&pc.local, pc.bytes, hipDeviceMallocUncached));
@@ -31,7 +31,7 @@ int comm_alloc(Model *m, Shard &sh) {
     FL_HIP(hipMalloc((void **)&pc.ll_dev, sizeof(LLTable)));
     FL_HIP(hipHostMalloc((void **)&pc.err, 64, hipHostMallocDefault));
     *pc.err = 0;
-    pc.timeout_ticks = (long long)env_int("FL_AR_TIMEOUT_MS", 20000) * 100000LL;       // 100 MHz wall clock
+    pc.timeout_ticks = (long long)tune(TK_AR_TIMEOUT_MS) * 100000LL;       // 100 MHz wall clock
     FL_HIP(hipDeviceSynchronize());
     m->hbm_bytes += (int64_t)pc.bytes;
     return FL_OK;
@@ -123,7 +123,7 @@ int comm_bootstrap_over_rccl(Model *m) {
     Shard &sh = m->shards[0];
     PeerComm &pc = sh.pc;
     const int tp = m->tp;
-    const bool verbose = env_int("FL_VERBOSE", 0) != 0;
+    const bool verbose = tune(TK_VERBOSE) != 0;
     FL_HIP(hipSetDevice(sh.device));
     char *dbuf = nullptr;
     const size_t test_n = 4096;
@@ -220,8 +220,12 @@ int comm_probe(Model *m, int form, int64_t n, int iters, double *us_per_call) {
     FL_HIP(hipSetDevice(sh.device));
     float *buf = sh.dec.delta;                                   // [h] fp32 scratch of the decode step
     FL_HIP(hipMemsetAsync(buf, 0, (size_t)n * 4, sh.stream));
-    hipEvent_t e0, e1, e2;
-    FL_HIP(hipEventCreate(&e0)); FL_HIP(hipEventCreate(&e1)); FL_HIP(hipEventCreate(&e2));
+    struct Events {                                         // destroyed on every way out (an FL_HIP below returns early)
+        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+        ~Events() { for (auto x : e) if (x) (void)hipEventDestroy(x); }
+    } ev;
+    for (auto &x : ev.e) FL_HIP(hipEventCreate(&x));
+    hipEvent_t e0 = ev.e[0], e1 = ev.e[1], e2 = ev.e[2];
     Launcher L = make_launcher(m, sh);
     L.prof = nullptr;
     int rc = FL_OK;
@@ -251,7 +255,6 @@ int comm_probe(Model *m, int form, int64_t n, int iters, double *us_per_call) {
     }
     float ms01 = 0.f, ms12 = 0.f;
     if (rc == FL_OK) { FL_HIP(hipEventElapsedTime(&ms01, e0, e1)); FL_HIP(hipEventElapsedTime(&ms12, e1, e2)); }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     FL_TRY(rc);
     if (pc.err && *pc.err) FL_FAIL(FL_ERR_RCCL, "comm_probe: a wait gave up (code 0x%x)", *pc.err);
     *us_per_call = form == 2 ? (double)(ms01 - ms12) * 1e3 / ((double)iters * slots) : (double)ms01 * 1e3 / iters;
@@ -275,7 +278,7 @@ int comm_check(Model *m) {
 bool fused_all_reduce_ready(const Model *m) {
     // 0: never; 1: when every rank has a GPU of its own (two full-chip GEMV grids that wait for each other's rows
     // cannot both be resident on one card -- the same-device rehearsals); 2: regardless (tests with small grids)
-    const int allow = env_int("FL_TP_FUSED_AR", 1);
+    const int allow = tune(TK_TP_FUSED_AR);
     if (!allow || !m->fused_decode) return false;
     if (allow < 2) for (auto &sh : m->shards) if (sh.pc.shares_device) return false;
     const bool group_of_one = m->tp == 1 && m->shards[0].pc.connected;          // FL_DEBUG_RCCL_SELF: the bootstrap rehearsal

@@ -30,13 +30,85 @@ int raise_dynamic_lds(const void *fn, size_t lds_bytes);
 // used, afterwards changed only through fl_tune(name, value) ("reload_env" re-reads the environment: tests and A/B tools).
 // No per-launch getenv.
 enum TuneKey {
-    TK_GEMM_H4 = 0,        // 128 x 256 GEMM with in-launch K-slice sums: 0 never, 1 where the cost model prefers it, 2 wherever it is supported
-    TK_H4_SPLIT,           // 0: as the model; 1..4: K slices it uses (probes, tests)
-    TK_H4_PF,              // its L2 prefetch of the W panel: K tiles ahead + 256 x lanes per 128-byte line (0: off)
-    TK_H4_WAIT_US,         // how long an early K slice waits for the others before it leaves its share to the last one
+    TK_GEMM_H4,   // 128 x 256 GEMM with in-launch K-slice sums: 0 never, 1 where the rule prefers it, 2 wherever it is supported
+    TK_H4_SPLIT,   // 0: as the rule; 1..4: K slices it uses (probes, tests)
+    TK_H4_PF,   // its L2 prefetch of the W panel: K tiles ahead + 256 x lanes per 128-byte line (0 lanes: off; measured neutral)
+    TK_H4_WAIT_US,   // how long an early K slice waits for the others before it leaves its blocks to the last one
+    TK_OP_MAXSPLIT,   // fl_op_linear: most K slabs (0: as the model)
+    TK_OP_LINEAR_DMA,   // fl_op_linear: T <= 8 through the batched-decode ring kernel
+    TK_OP_HOT,   // fl_op_linear timing: copies of W the loop rotates over (0: enough to defeat the Infinity Cache)
+    TK_AR_INBOX_FLOATS,   // one-shot collectives: floats per inbox slot
+    TK_AR_TIMEOUT_MS,   // bound on every wait for a peer
+    TK_VERBOSE,   // bootstrap log lines
+    TK_TP_FUSED_AR,   // decode all-reduces inside the GEMV epilogues (2: even when ranks share a GPU)
+    TK_ATTN_NW,   // VALU decode attention: waves
+    TK_ATTN_PREFETCH,   // decode attention: workgroups that touch the next launch's weights (experimental build)
+    TK_ATTN_PREFETCH_LINES,
+    TK_ATTN_PREFETCH_PCT,
+    TK_ATTN_PREFETCH_DELAY,
+    TK_ATTN_BATCH_WGS,   // batched decode attention: workgroup cap
+    TK_ATTN_PF32_MIN_T,   // 32-row prefill attention from this many tokens (0: 640 with wave pairs, else 1024)
+    TK_ATTN_PF32_KS2,   // its key-split form: -1 automatic, 0 / 1
+    TK_ATTN_PF32_PAIRED,   // its work distribution: -1 automatic, 0 plain, 1 paired, 2 snake
+    TK_ATTN_PF_WAVES,   // 16-row prefill attention: waves per workgroup (0: automatic)
+    TK_ATTN_PF_STAGES,
+    TK_ATTN_PF_KSPLIT,
+    TK_AO_DELAY,   // fused attention + o_proj (experimental build): head start of the attention loads, x 1/4 us
+    TK_AO_WAVES,
+    TK_ENGINE_DELAY,   // decode engine (experimental build)
+    TK_ENGINE_PF,
+    TK_ENGINE_TIMEOUT_MS,
+    TK_SK_MINSTEPS,   // stream-K: K steps per piece, at least
+    TK_GEMM_4W,   // four-wave 256 x 256 GEMM: 0 never, 1 from 768 tokens on wide matrices, 2 always
+    TK_GEMM_GROUPM,   // its tile order: row tiles per group (0: 4)
+    TK_8P_MINK,   // 256 x 256 GEMM: K steps per slice, at least
+    TK_GEMM_8P,   // 256 x 256 GEMM: 0 off, 1 where the cost model prefers it, 2 always
+    TK_GEMM_256,
+    TK_GEMM_256_SPLIT,
+    TK_GEMM_STREAMK,   // 1: peeled tails; 0: tails on 128 x 128 tiles; 2: also whole grids of 96-255 tiles; 3: every shape (tests)
+    TK_GEMM_PEEL,
+    TK_GEMM_RESID,   // residual epilogue of o_proj / down_proj (0: keep the rmsnorm_add launches)
+    TK_GEMM_SKINNY_MAXT,
+    TK_SKINNY_STAGES,
+    TK_SKINNY_NT,
+    TK_SKINNY_WM,
+    TK_SKINNY_LOADERS,   // short-prompt GEMM staged by loader waves (experimental build): -1 = only with FL_SKINNY_STAMPS
+    TK_GEMM_SKINNY_MAXT2,
+    TK_GEMV_SMALL,
+    TK_GEMV_R,
+    TK_GEMV_U,
+    TK_BATCH_U,
+    TK_BATCH_MODE,
+    TK_BATCH_MFMA_MIN,
+    TK_DMA_KT,
+    TK_FORCE_GENERIC_GEMM,
+    TK_GEMM_SKINNY,
+    TK_ROPE_VEC,
+    TK_WEIGHT_ARENA,
+    TK_KSPLIT_MID,   // most slabs for prompts of 129-1024 tokens (0: eight)
+    TK_PREFILL_CHUNK,
+    TK_GRAPH,   // decode step as a hipGraph: -1 = on (single GPU), off for an RCCL group of one unless asked
+    TK_FUSED,
+    TK_ALLOW_ANY_ARCH,
+    TK_ENGINE,   // persistent decode engine (experimental build)
+    TK_FUSE_OPROJ,   // attention + o_proj in one launch (experimental build)
+    TK_ONESHOT,
+    TK_DEBUG_RCCL_SELF,
+    TK_ATTN_MFMA,
+    TK_ATTN_NSPLIT,   // decode attention splits (-1: by cache length)
+    TK_ATTN_REP,
+    TK_SAMPLE_WALK,
+    TK_ARGMAX_FUSED,
+    TK_TP_OVERLAP,
+    TK_TP_OVERLAP_MIN_T,
+    TK_QKV_SPLIT,
+    TK_TP_GRAPH,
+    TK_BATCH_DMA_MIN,
+    TK_BATCH_UNFUSED_MIN,   // first batch size on the prefill-shaped step (-1: 3 with the ring kernel, else 7)
     TK_COUNT
 };
 int tune(TuneKey k);
+const char *env_str(const char *name);   // diagnostic file paths (FL_*_STAMPS) and the fault injector: null when unset or empty
 int tune_set(const char *name, int value);   // FL_OK, or FL_ERR_BAD_ARGUMENT for an unknown name
 void tune_reload_env();
 

@@ -200,7 +200,7 @@ int launch_attn_decode(Launcher &L, int dtype, const void *q, const void *k_cach
                        int64_t max_seq, float scale) {
     const int G = (int)(H / Hkv);
     const bool small = G <= 4;
-    static const int nw = getenv("FL_ATTN_NW") ? atoi(getenv("FL_ATTN_NW")) : 4;
+    const int nw = tune(TK_ATTN_NW);
 #define FL_DISPATCH(CT)                                                                                        \
     if (d == 128 && nw >= 16) return small ? launch_decode_t<CT, 128, 4, 16>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale) \
                                : launch_decode_t<CT, 128, 8, 8>(L, q, k_cache, v_cache, st, out, sc, H, Hkv, max_seq, scale); \

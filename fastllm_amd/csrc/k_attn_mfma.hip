@@ -188,10 +188,14 @@ static int launch_decode_mfma_t(Launcher &L, const void *q, const void *kc, cons
     // by about what the consumer gains, whatever share of the rows is taken (FL_ATTN_PREFETCH_PCT 60 / 75 / 100) and however late
     // the prefetchers start (FL_ATTN_PREFETCH_DELAY).  Tokens/s: Mistral-7B 369.8 -> 371.9 (four runs each), Qwen2-7B 360.1 ->
     // 356.9, TinyLlama-1.1B unchanged (its o_proj is not memory-bound: 4.2-4.4 us either way).  (read per call: tests switch it)
-    const int pf_on = getenv("FL_ATTN_PREFETCH") ? atoi(getenv("FL_ATTN_PREFETCH")) : 0;
-    const int pf_per_thread = getenv("FL_ATTN_PREFETCH_LINES") ? std::max(1, atoi(getenv("FL_ATTN_PREFETCH_LINES"))) : 8;
-    const int pf_pct = getenv("FL_ATTN_PREFETCH_PCT") ? std::min(100, std::max(1, atoi(getenv("FL_ATTN_PREFETCH_PCT")))) : 100;
-    const int pf_delay = getenv("FL_ATTN_PREFETCH_DELAY") ? std::max(0, atoi(getenv("FL_ATTN_PREFETCH_DELAY"))) : 0;
+#ifdef FL_EXPERIMENTAL
+    const int pf_on = tune(TK_ATTN_PREFETCH);
+#else
+    const int pf_on = 0;                                           // (measured neutral: EXPERIMENTAL build only)
+#endif
+    const int pf_per_thread = std::max(1, tune(TK_ATTN_PREFETCH_LINES));
+    const int pf_pct = std::min(100, std::max(1, tune(TK_ATTN_PREFETCH_PCT)));
+    const int pf_delay = std::max(0, tune(TK_ATTN_PREFETCH_DELAY));
     unsigned pf_rows = 0, chunk_lines = 0, nchunks = 0, row_lines = 1, row_take = 1;
     if (pf_on && sc.prefetch && sc.prefetch_chunk >= 128 && sc.prefetch_bytes >= sc.prefetch_chunk && sc.prefetch_row >= 128 && sc.prefetch_chunk % sc.prefetch_row == 0) {
         chunk_lines = (unsigned)(sc.prefetch_chunk / 128);
@@ -244,7 +248,7 @@ int launch_attn_decode_mfma_batch(Launcher &L, const void *q, const SeqRef *seqs
     if (max_nsplit > 64 || max_nsplit < 1) FL_FAIL(FL_ERR_BAD_ARGUMENT, "attention: 1..64 splits");
     // measured (Mistral-7B, 8 sequences at S ~ 600), with a release fence per split workgroup: 128 workgroups (2 splits)
     // 15.3 us, 448 (7 splits) 24.3 us; with write-through publication (attn_common.h): 128 -> 11.4 us, 256 -> 10.9, 512 -> 12.2
-    static const int wg_cap = getenv("FL_ATTN_BATCH_WGS") ? atoi(getenv("FL_ATTN_BATCH_WGS")) : 256;
+    const int wg_cap = tune(TK_ATTN_BATCH_WGS);
     const int cap = (int)std::max<int64_t>(1, wg_cap / (Hkv * B));
     max_nsplit = std::min(max_nsplit, cap);
     dim3 grid((unsigned)Hkv, (unsigned)max_nsplit, (unsigned)B);
@@ -745,7 +749,7 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
     // 32-row waves (attn_prefill32_kernel) once the prompt is long enough to fill the chip with their workgroups
     // (with wave pairs from 640 tokens for G = 1, 2, 4: Mistral-7B T = 768 31.9 -> 24.8 us per layer, T = 512 a tie, below slower;
     // from 256 tokens for the groups dealt as subgroups of four heads: Qwen2-7B T = 512 23.2 -> 18.3, TinyLlama 16.5 -> 13.2, T = 256 a tie)
-    static const int pf32_min_env = getenv("FL_ATTN_PF32_MIN_T") ? atoi(getenv("FL_ATTN_PF32_MIN_T")) : 0;
+    const int pf32_min_env = tune(TK_ATTN_PF32_MIN_T);
     const int pf32_min_t = pf32_min_env > 0 ? pf32_min_env : ((G == 1 || G == 2 || G == 4) ? 640 : (G > 4 ? 256 : 1024));
     const int force = g_prefill_force.load();                        // fl_op_attention pins one kernel (unit tests)
     if ((force == 3 || (force == 0 && T >= pf32_min_t)) && scale > 0.f) {
@@ -756,8 +760,7 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
         const int NW = G <= 4 ? (8 / G) * G : G;
         int TB = NW / G;
         // too few (block, kv head) items to balance: halve the token blocks and split every block's keys over a wave pair
-        const char *eks = getenv("FL_ATTN_PF32_KS2");                // read per call: tests pin it
-        const int ks2_mode = eks && *eks ? atoi(eks) : -1;
+        const int ks2_mode = tune(TK_ATTN_PF32_KS2);
         bool ks2 = NW == 8 && TB % 2 == 0 && (ks2_mode >= 0 ? ks2_mode != 0 : ((T + 32 * TB - 1) / (32 * TB)) * Hkv < 2 * 256);
         // groups of 5..8 heads: wave pairs only fit when the group is dealt in subgroups of four heads (8 waves = 4 heads x a pair)
         int gsub = 0;
@@ -765,8 +768,7 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
         if (ks2) TB /= 2;
         const int64_t nb = (T + 32 * TB - 1) / (32 * TB);
         const int64_t nhs = Hkv * (gsub ? (G + gsub - 1) / gsub : 1);
-        const char *fp = getenv("FL_ATTN_PF32_PAIRED");              // read per call: tests pin the schedule
-        const int force_pair = fp && *fp ? atoi(fp) : -1;
+        const int force_pair = tune(TK_ATTN_PF32_PAIRED);
         // two rounds or more of (block, kv head) items: persistent workgroups, snake order (launch_pf32)
         const int paired = force_pair >= 0 ? force_pair : (nb * nhs >= 2 * 256 ? 2 : ((nb + 1) / 2 * nhs >= 180 ? 1 : 0));
         if (ks2 && d == 128) return launch_pf32<128, 8, true>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired, gsub);
@@ -781,7 +783,7 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
     // the causal mask)
     // ... but only while the grid still covers the chip: at T = 512 (Mistral) 4-wave workgroups (256 of them) take
     // 26 us per layer against 36 us for 64 16-wave ones; at T = 1024 8 waves 49 us against 57 (4) and 67 (16)
-    static const int tt_waves = getenv("FL_ATTN_PF_WAVES") ? atoi(getenv("FL_ATTN_PF_WAVES")) : 0;
+    const int tt_waves = tune(TK_ATTN_PF_WAVES);
     int TT = tt_waves > 0 ? std::max(1, std::min(16, tt_waves) / G) : (G <= 4 ? 16 / G : 1);
     if (tt_waves <= 0)
         while (TT > 1 && ((T + 16 * TT - 1) / (16 * TT)) * Hkv < 256) TT >>= 1;
@@ -790,10 +792,10 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
     // LDS tiles in the ring (FL_ATTN_PF_STAGES, 2..4).  Measured: a deeper ring buys nothing -- Mistral T = 512 25 / 26 /
     // 25 us per layer with 2 / 3 / 4 tiles, T = 768 41 / 40 / 42: with one wave per SIMD a key step is a chain of
     // dependent LDS read -> MFMA -> shuffle -> exp -> MFMA latencies (~1.5 us), not a wait for the tile
-    static const int pf_stages = getenv("FL_ATTN_PF_STAGES") ? atoi(getenv("FL_ATTN_PF_STAGES")) : 2;
+    const int pf_stages = tune(TK_ATTN_PF_STAGES);
     int nst = std::max(2, std::min(4, G * TT <= 8 ? pf_stages : 2));
     // key split (two waves per head and token sub-tile) while the workgroup stays within 8 waves: short prompts
-    static const int pf_ksplit = getenv("FL_ATTN_PF_KSPLIT") ? atoi(getenv("FL_ATTN_PF_KSPLIT")) : 2;
+    const int pf_ksplit = tune(TK_ATTN_PF_KSPLIT);
     // (four waves per query tile measured slower than two: Mistral T = 512 23 vs 18 us per layer, T = 768 45 vs 33)
     // ... while the workgroup stays within 16 waves and its merge slabs within the 64 KB of LDS a launch gets by default
     const size_t slabs = (size_t)G * TT * (16 * d + 32) * 4;

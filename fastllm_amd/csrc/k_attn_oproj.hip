@@ -26,6 +26,8 @@
 #include "attn_mfma.h"
 
 namespace fl {
+#ifdef FL_EXPERIMENTAL
+
 
 struct AttnOprojArgs {
     const bf16_t *q, *kc, *vT; const StepState *st;
@@ -297,11 +299,11 @@ int launch_attn_oproj(Launcher &L, const void *q, const void *k_cache, const voi
     const double bytes = (double)h * H * d * 2 + 2.0 * (double)kv_len_hint * Hkv * d * 2;
     const double flops = 2.0 * h * H * d + 4.0 * (double)kv_len_hint * H * d;
     a.attn_waves = std::max(1, std::min(8, attn_waves));
-    static const int delay = getenv("FL_AO_DELAY") ? std::max(0, atoi(getenv("FL_AO_DELAY"))) : 6;    // x ~0.25 us (measured: 0 -> 13.9 us, 6 -> 12.0, 12 -> 12.5)
+    const int delay = std::max(0, tune(TK_AO_DELAY));    // x ~0.25 us (measured: 0 -> 13.9 us, 6 -> 12.0, 12 -> 12.5)
     a.dma_delay = delay;
     // FL_AO_STAMPS=1 (eager launches only: run with FL_GRAPH=0): every workgroup records s_memrealtime at its section
     // boundaries; launches 201-203 of the process are read back and summarised on stderr (tools/ao_stamps.sh)
-    static const bool want_stamps = getenv("FL_AO_STAMPS") != nullptr;
+    const bool want_stamps = env_str("FL_AO_STAMPS") != nullptr;
     static unsigned long long *stamps = nullptr;
     static std::atomic<int> launches{0};
     a.stamps = nullptr;
@@ -336,4 +338,12 @@ int launch_attn_oproj(Launcher &L, const void *q, const void *k_cache, const voi
     return G <= 4 ? go(attn_oproj_kernel<64, 4>) : go(attn_oproj_kernel<64, 8>);
 }
 
+#else
+// Default build: 0-1.5 % on Mistral-7B, slower elsewhere (profiles/r02/README.md): not compiled in; `make EXPERIMENTAL=1` builds it.
+bool attn_oproj_plan(int64_t, int64_t, int64_t, int64_t, int, int, int *, int *, int *, size_t *) { return false; }
+int launch_attn_oproj(Launcher &, const void *, const void *, const void *, const StepState *, StepState *, float *, unsigned *, int, int, int64_t,
+                      const void *, float *, int64_t, int64_t, int64_t, int64_t, int64_t, float) {
+    FL_FAIL(FL_ERR_UNSUPPORTED, "the fused attention + o_proj launch is not in this build (make EXPERIMENTAL=1)");
+}
+#endif
 }  // namespace fl

@@ -559,7 +559,7 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         // pieces aligned with the tiles keep the workgroups that share a W or X panel in lock step (its L2 hits): split every
         // tile into the same number of pieces, at most eight, while the grid fits the chip
         const int64_t nt = (int64_t)tiles_m * tiles_n, cus = cu_count();
-        static const int sk_minsteps = getenv("FL_SK_MINSTEPS") ? std::max(2, atoi(getenv("FL_SK_MINSTEPS"))) : 8;   // K steps per piece, at least (Qwen2-7B 4k QKV tail: piece launch + fix-up 58.2 us at 4, 53.8 at 8, 53.0 at 12)
+        const int sk_minsteps = std::max(2, tune(TK_SK_MINSTEPS));   // K steps per piece, at least (Qwen2-7B 4k QKV tail: piece launch + fix-up 58.2 us at 4, 53.8 at 8, 53.0 at 12)
         const int64_t split = std::max<int64_t>(1, std::min<int64_t>({(int64_t)8, cus / std::max<int64_t>(1, nt), (K / P_BK) / sk_minsteps}));
         const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>(nt * split, units / 2));
         FL_TRY(streamk_space(L.stream, nwg, &sk));
@@ -572,8 +572,7 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         return LF.launch(KC_GEMM_MFMA, 0.0, 0.0, gemm_8p_fixup_kernel, dim3((unsigned)(tiles_m * tiles_n * 8)), dim3(512), 0, bias, y, (int)T, (int)N,
                          (int)K, epi, tiles_m, tiles_n, row_scale, (int)ldc, (int)grid.x, sk, re, group_m);
     };
-    const char *e4 = getenv("FL_GEMM_4W");                          // read per call: tests and A/B tools switch it
-    const int four = e4 && *e4 ? atoi(e4) : 1;
+    const int four = tune(TK_GEMM_4W);
     // the four-wave form of the same tile (same grid, workspace and fix-up).  FL_GEMM_4W: 0 never, 2 always, 1 (default) from 768
     // tokens, stream-K pieces and K slices of ten or more steps.  The rule comes from an A/B inside one process, whole prefills back
     // to back (tools/prefill_ab.py; ms, eight waves / four waves): Mistral-7B T = 512 8.75 / 8.83, 768 12.19 / 12.11, 1024 14.92 /
@@ -586,23 +585,22 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
     // 3.5-5 % at 768-2048 tokens with it on either projection; with this rule it is untouched, Mistral-7B and Qwen2-7B keep
     // their gains (768 tokens -0.6 / -3.6 %, 1024 -5.2 / -4.2 %, 4096 -7.7..-8.6 / -6.9..-7.9 %)
     const int64_t ksteps = streamk ? K / P_BK : (K / P_BK) / ksplit;
-    if (four && fits32 && !getenv("FL_8P_STAMPS") && (four > 1 || (T >= 768 && ksteps >= 10 && K >= 3072 && (streamk || N >= 3072)))) {   // (N of a peeled tail is small: stream-K pieces go by K alone)
+    if (four && fits32 && !env_str("FL_8P_STAMPS") && (four > 1 || (T >= 768 && ksteps >= 10 && K >= 3072 && (streamk || N >= 3072)))) {   // (N of a peeled tail is small: stream-K pieces go by K alone)
         auto k4 = streamk ? gemm_4w_kernel<true> : gemm_4w_kernel<false>;
         FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(k4), P_LDS));
         snprintf(tag, sizeof tag, "4w,%lldx%lld%s%s", (long long)N, (long long)K, streamk ? ",streamK" : ksplit > 1 ? ",splitK" : "", resid ? ",resid" : "");
         LL.tag = tag;
-        const char *eg = getenv("FL_GEMM_GROUPM");                  // read per call (A/B tools)
-        const int group_env = eg && *eg ? atoi(eg) : 0;
+        const int group_env = tune(TK_GEMM_GROUPM);
         group_m = std::max(1, std::min(tiles_m, group_env > 0 ? group_env : 4));   // 4: +3-4 % at T = 4096 over the 16 x 2 strip (8: +2-3, 2: +1)
         FL_TRY(LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, k4, grid, dim3(256), P_LDS, (const bf16_t *)W, (const bf16_t *)x,
                          bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, sk, re, group_m));
         return fixup();
     }
-    const bool stamp = getenv("FL_8P_STAMPS") != nullptr;           // diagnostics only: synchronous, appends one record per launch
+    const bool stamp = env_str("FL_8P_STAMPS") != nullptr;           // diagnostics only: synchronous, appends one record per launch
     auto kern = streamk ? (stamp ? gemm_8p_kernel<true, true> : gemm_8p_kernel<false, true>) : (stamp ? gemm_8p_kernel<true, false> : gemm_8p_kernel<false, false>);
     FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), P_LDS));
     if (stamp) {
-        const char *path = getenv("FL_8P_STAMPS");
+        const char *path = env_str("FL_8P_STAMPS");
         const size_t nwg = (size_t)grid.x * grid.y;
         unsigned long long *d = nullptr;
         FL_HIP(hipMalloc(&d, nwg * 80));

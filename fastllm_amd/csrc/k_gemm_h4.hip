@@ -515,7 +515,7 @@ int launch_gemm_h4(Launcher &L, const void *W, const void *x, const float *bias,
     // groups of four row tiles x columns: the eight tiles an XCD works on per K slice at T = 512 are 4 x 2 (four X panels, two W panels)
     const int group_m = std::max(1, std::min(tiles_m, 4));
     const double bytes = ((double)N * K + (double)T * K) * 2.0;
-    static const char *stamp_path = getenv("FL_H4_STAMPS");        // diagnostics only: synchronous, appends one record per launch
+    const char *stamp_path = env_str("FL_H4_STAMPS");        // diagnostics only: synchronous, appends one record per launch
     unsigned long long *d_st = nullptr;
     const size_t nwg = (size_t)tiles_m * tiles_n * ksplit;
     if (stamp_path) { FL_HIP(hipMalloc((void **)&d_st, nwg * 64)); FL_HIP(hipMemsetAsync(d_st, 0, nwg * 64, L.stream)); }

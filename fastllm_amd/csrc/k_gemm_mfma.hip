@@ -264,9 +264,8 @@ static const double kNoKernel = 1e30;
 // rmsnorm_add with eight 8.4 MB slabs 13.3 us against 5-6 with one)
 static double cost_slabs(int64_t T, int64_t N, int ks) { return ks > 1 ? (double)ks * T * N * 4.0 / 6.0e6 : 0.0; }
 static double cost_8p(int64_t T, int64_t N, int64_t K, int ks) {
-    static const int mink = getenv("FL_8P_MINK") ? atoi(getenv("FL_8P_MINK")) : 8;   // K steps per slice: keep the pipeline long enough to pay for its ramp
-    const char *e8 = getenv("FL_GEMM_8P");                        // read per call: tests switch it
-    if (e8 && *e8 && atoi(e8) == 0) return kNoKernel;
+    const int mink = tune(TK_8P_MINK);   // K steps per slice: keep the pipeline long enough to pay for its ramp
+    if (tune(TK_GEMM_8P) == 0) return kNoKernel;
     if (T <= 128 || K % 64 || ks < 1 || (K / 64) / ks < mink) return kNoKernel;
     const int64_t t8 = ((T + 255) / 256) * ((N + 255) / 256) * ks, rounds = (t8 + 255) / 256;
     // a K step takes 1.3-1.4 us on a grid that leaves a quarter of the chip idle and 1.5-1.6 us on a full one (clock and memory
@@ -277,8 +276,8 @@ static double cost_8p(int64_t T, int64_t N, int64_t K, int ks) {
 // the 256x128 kernel keeps its measured niches: very large grids that do not suit the 256x256 one, and -- with K slices -- a
 // grid of exactly one round (224..256 workgroups, >= 8 K steps per slice: Mistral-7B T = 512 down_proj 80 -> 71.5 us in round 1)
 static double cost_256(int64_t T, int64_t N, int64_t K, int ks) {
-    static const int use256 = getenv("FL_GEMM_256") ? atoi(getenv("FL_GEMM_256")) : 1;
-    static const int split256 = getenv("FL_GEMM_256_SPLIT") ? atoi(getenv("FL_GEMM_256_SPLIT")) : 1;
+    const int use256 = tune(TK_GEMM_256);
+    const int split256 = tune(TK_GEMM_256_SPLIT);
     if (!use256 || T < 192 || K % BK || K / BK < 3 || ks < 1) return kNoKernel;
     const int64_t tiles = ((T + BM2 - 1) / BM2) * ((N + BN - 1) / BN) * ks, rounds = (tiles + 255) / 256;
     const bool one_round = split256 && tiles >= 224 && tiles <= 256 && (K / BK) / ks >= 8;
@@ -333,18 +332,16 @@ static int launch_gemm_mfma_impl(Launcher &L, const void *W, const void *x, cons
 // the (tile, K step) line cut into equal pieces), or, with FL_GEMM_STREAMK=0, on the smaller tiles when the remainder
 // is at most a quarter round.  A grid of less than one round runs stream-K whole when that saves more than it costs.
 static int streamk_on() {
-    const char *e = getenv("FL_GEMM_STREAMK");                  // read per call: tests switch it
-    return e && *e ? atoi(e) : 1;
+    return tune(TK_GEMM_STREAMK);
 }
 // Whole-matrix stream-K (FL_GEMM_STREAMK=2: grids of 96..255 tiles; =3: every shape the kernel takes -- tests).  Off by
 // default: measured on Qwen2-7B's down_proj at T = 4096 (224 tiles, an eighth of the chip idle) it LOST 440 -> 535 us --
 // pieces that start inside a tile take the workgroups that share a W or X panel out of lock step (their L2 hits become
 // MALL/HBM reads), and every split tile moves its fp32 accumulators through memory twice (profiles/r02/README.md).
 static bool gemm_streamk_whole(int64_t T, int64_t N, int64_t K, int epi) {
-    const char *e8 = getenv("FL_GEMM_8P");
     const int sk = streamk_on();
     (void)epi;
-    if (sk < 2 || (e8 && *e8 && atoi(e8) != 1) || T < 256 || K % 64 || K / 64 < 8) return false;
+    if (sk < 2 || tune(TK_GEMM_8P) != 1 || T < 256 || K % 64 || K / 64 < 8) return false;
     if (sk >= 3) return true;
     const int64_t t8 = ((T + 255) / 256) * ((N + 255) / 256);
     return T >= 1024 && K / 64 >= 32 && t8 >= 96 && t8 < 256;
@@ -352,9 +349,8 @@ static bool gemm_streamk_whole(int64_t T, int64_t N, int64_t K, int epi) {
 
 // column peeling of a ragged 256x256 grid: whole rounds first (n_main columns), the rest as a stream-K (or 128x128) tail
 static bool peel_plan(int64_t T, int64_t N, int64_t K, int64_t *n_main_out) {
-    static const int peel = getenv("FL_GEMM_PEEL") ? atoi(getenv("FL_GEMM_PEEL")) : 1;
-    const char *e8 = getenv("FL_GEMM_8P");
-    const int use8p = e8 && *e8 ? atoi(e8) : 1;
+    const int peel = tune(TK_GEMM_PEEL);
+    const int use8p = tune(TK_GEMM_8P);
     if (!(peel && use8p == 1 && T >= 256 && K % 64 == 0 && (K / 64) >= 16)) return false;
     const int64_t tm = (T + 255) / 256, tn = (N + 255) / 256, t8 = tm * tn;
     const int64_t full = t8 / 256;
@@ -390,11 +386,9 @@ int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bia
 // pair of launches): long prompts.  FL_GEMM_RESID=0 keeps the rmsnorm_add launches.
 int gemm_resid_partials(int64_t N) { return (int)((N + 255) / 256) * 4; }
 bool gemm_resid_supported(int dtype, int64_t T, int64_t N, int64_t K, int max_split) {
-    const char *e = getenv("FL_GEMM_RESID");                     // read per call: tests switch it
-    if (e && *e && atoi(e) == 0) return false;
+    if (tune(TK_GEMM_RESID) == 0) return false;
     if (dtype == FL_DTYPE_BF16 && N % 16 == 0 && gemm_h4_plan(T, N, K, EPI_RESID) > 0) return true;   // mid-size prompts: k_gemm_h4.hip
-    const char *e8 = getenv("FL_GEMM_8P");
-    if (dtype != FL_DTYPE_BF16 || (e8 && *e8 && atoi(e8) != 1) || T < 256 || K % 64 || K / 64 < 2 || N % 16) return false;
+    if (dtype != FL_DTYPE_BF16 || tune(TK_GEMM_8P) != 1 || T < 256 || K % 64 || K / 64 < 2 || N % 16) return false;
     if (gemm_streamk_whole(T, N, K, EPI_F32)) return false;
     int64_t n_main = 0;
     if (peel_plan(T, N, K, &n_main)) return streamk_on() != 0;     // main launch + stream-K tail, both with the residual epilogue
@@ -427,8 +421,7 @@ int launch_gemm_resid(Launcher &L, const void *W, const void *x, int64_t T, int6
 static int launch_gemm_mfma_impl(Launcher &L, const void *W, const void *x, const float *bias, void *y,
                                  int64_t T, int64_t N, int64_t K, int epi, const float *row_scale, int ksplit, int64_t ldc, bool allow8p) {
     // 256x256 phase-interleaved kernel (k_gemm_8p.hip).  FL_GEMM_8P: 0 off, 1 where the model above prefers it, 2 always
-    const char *e8 = getenv("FL_GEMM_8P");                      // read per call: tests switch it
-    const int use8p = !allow8p ? 0 : (e8 && *e8 ? atoi(e8) : 1);
+    const int use8p = !allow8p ? 0 : tune(TK_GEMM_8P);
     const bool splittable = ksplit == 1 || (!bias && epi == EPI_F32);
     int kern = splittable ? pick_kernel(T, N, K, ksplit) : GK_128;
     if (!use8p && kern == GK_8P) kern = cost_256(T, N, K, ksplit) < cost_128(T, N, K, ksplit) ? GK_256 : GK_128;

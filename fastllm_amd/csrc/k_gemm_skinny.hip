@@ -73,7 +73,7 @@ __device__ inline void skinny_epilogue(const float4v (&acc)[MT][NT], void *__res
 
 // beyond BM = 128 tokens the kernel can run ceil(T / 128) token blocks per strip (FL_GEMM_SKINNY_MAXT moves the
 // limit), but the 128x128 kernel is then faster: Mistral-7B prefill T = 256 9.8 vs 9.2 ms, T = 512 18.3 vs 11.7 ms
-static const int kSkinnyMaxT = getenv("FL_GEMM_SKINNY_MAXT") ? atoi(getenv("FL_GEMM_SKINNY_MAXT")) : 128;
+static inline int kSkinnyMaxT_() { return tune(TK_GEMM_SKINNY_MAXT); }
 
 template <int N> __device__ inline void wait_vmcnt() {
     static_assert(N < 64, "vmcnt is a 6-bit field");
@@ -338,7 +338,7 @@ static int launch_skinny_ld_s(Launcher &L, const void *W, const void *x, const f
     char tag[32];
     snprintf(tag, sizeof tag, "skinny,ld,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");
     Launcher LL = L; LL.tag = tag;
-    if (const char *path = getenv("FL_SKINNY_STAMPS"))
+    if (const char *path = env_str("FL_SKINNY_STAMPS"))
         return run_stamped(LL, gemm_skinny_ld_kernel<BM, NT, NW, NWM, NLW, NSTG, WNT, true>, grid, block, lds, bytes, 2.0 * T * N * K, path, NWV + NLW,
                            W, x, bias, y, T, N, K, epi, row_scale, ksplit);
     auto kern = gemm_skinny_ld_kernel<BM, NT, NW, NWM, NLW, NSTG, WNT, false>;
@@ -362,7 +362,7 @@ static int launch_skinny_s(Launcher &L, const void *W, const void *x, const floa
     Launcher LL = L; LL.tag = tag;
     const dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)ksplit, (unsigned)((T + BM - 1) / BM));
     if constexpr (BM == 128 && !WNT && NSTG == 4) {                // (the shipped kernel's own counters: FL_SKINNY_STAMPS with FL_SKINNY_LOADERS=0)
-        if (const char *path = getenv("FL_SKINNY_STAMPS"))
+        if (const char *path = env_str("FL_SKINNY_STAMPS"))
             return run_stamped(LL, gemm_skinny_kernel<BM, NT, NW, NSTG, WNT, NWM, true>, grid, dim3(NW * NWM * 64), lds, bytes, 2.0 * T * N * K, path,
                                NW * NWM, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
     }
@@ -372,12 +372,12 @@ static int launch_skinny_s(Launcher &L, const void *W, const void *x, const floa
 
 // ring depth: FL_SKINNY_STAGES (default 4; deeper rings measured SLOWER: profiles/r02/README.md); FL_SKINNY_NT: non-temporal
 // weight loads for T <= 32 (-5..10 % there, +3..8 % at T = 128); FL_SKINNY_WM: two wave rows for BM >= 64
-static const int kSkinnyStages = getenv("FL_SKINNY_STAGES") ? atoi(getenv("FL_SKINNY_STAGES")) : 4;
-static const int kSkinnyNt = getenv("FL_SKINNY_NT") ? atoi(getenv("FL_SKINNY_NT")) : 1;
-static const int kSkinnyWm = getenv("FL_SKINNY_WM") ? atoi(getenv("FL_SKINNY_WM")) : 1;
+static inline int kSkinnyStages_() { return tune(TK_SKINNY_STAGES); }
+static inline int kSkinnyNt_() { return tune(TK_SKINNY_NT); }
+static inline int kSkinnyWm_() { return tune(TK_SKINNY_WM); }
 // 64 / 128 tokens: dedicated staging waves (gemm_skinny_ld_kernel).  Off: per projection it is -1..6 % (TinyLlama down -8..15 %)
 // and +10..19 % on short K loops, end to end (prefill_sweep) within the noise.  Read per call: tests and the stamps tool switch it.
-static int skinny_loaders() { const char *e = getenv("FL_SKINNY_LOADERS"); return e && *e ? atoi(e) : (getenv("FL_SKINNY_STAMPS") ? 1 : 0); }
+static int skinny_loaders() { const int v = tune(TK_SKINNY_LOADERS); return v >= 0 ? v : (env_str("FL_SKINNY_STAMPS") ? 1 : 0); }
 
 template <int BM, int NT, int NW>
 static int launch_skinny_t(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
@@ -386,26 +386,28 @@ static int launch_skinny_t(Launcher &L, const void *W, const void *x, const floa
     // deepest ring: LDS (<= 152 KB) and the 6-bit vmcnt field
     constexpr int kFit = 152 * 1024 / STG, kCnt = 63 / PW + 2;
     constexpr int kDeep = kFit < kCnt ? (kFit < 12 ? kFit : 12) : (kCnt < 12 ? kCnt : 12);
-    const bool nt = (kSkinnyNt == 1 && T <= 32) || kSkinnyNt == 2;
+    const bool nt = (kSkinnyNt_() == 1 && T <= 32) || kSkinnyNt_() == 2;
     if constexpr (BM >= 64) {
         // wave rows: 2 for the 4-column workgroups; the narrow (2-column) strips of small matrices get 4 (128 tokens, gate/up
         // pairs: 24 staging instructions per K tile over 8 waves instead of 2) or 2 where the instruction count divides
         constexpr int NI = (BM + BN) / 8;
         constexpr int WM = NW == 4 ? 2 : (BM == 128 && NI % 8 == 0 ? 4 : 2);
         static_assert(NI % (NW * WM) == 0 && BM % (16 * WM) == 0, "wave rows must divide the stage and the token tiles");
-        if (kSkinnyWm) {
+        if (kSkinnyWm_()) {
             // (A/B on one box, three passes each: down_proj -1..3 %, gate/up -2..6 %, TinyLlama down -8..15 %; but a 64-token
             // workgroup with only 16 K steps -- Mistral's QKV in four slices -- loses 10-19 %: the loaders' start-up is not amortised)
+#ifdef FL_EXPERIMENTAL
             if (skinny_loaders() && (BM == 128 || (K / S_BK) / ksplit >= 20))
                 return nt ? launch_skinny_ld_s<BM, NT, NW, WM, true>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)
                           : launch_skinny_ld_s<BM, NT, NW, WM, false>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
+#endif
             constexpr int kStg = 4 * STG <= 160 * 1024 ? 4 : 3;
             return nt ? launch_skinny_s<BM, NT, NW, kStg, true, WM>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)
                       : launch_skinny_s<BM, NT, NW, kStg, false, WM>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
         }
     }
     if constexpr (kDeep > 4 && BM <= 32) {
-        if (kSkinnyStages > 4)
+        if (kSkinnyStages_() > 4)
             return nt ? launch_skinny_s<BM, NT, NW, kDeep, true, 1>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit)
                       : launch_skinny_s<BM, NT, NW, kDeep, false, 1>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit);
     }
@@ -421,8 +423,8 @@ static int launch_skinny_t(Launcher &L, const void *W, const void *x, const floa
 // Mistral QKV 31.0 -> 36.2, gate/up 91 -> 112, lm_head 94 -> 172 (TinyLlama T = 256 prefill 3.05 -> 2.0 ms).
 bool gemm_skinny_supported(int64_t T, int64_t N, int64_t K) {
     if (!(T > 1 && K % S_BK == 0 && K / S_BK >= 4 && N >= 64)) return false;
-    if (T <= kSkinnyMaxT) return true;
-    static const int max2 = getenv("FL_GEMM_SKINNY_MAXT2") ? atoi(getenv("FL_GEMM_SKINNY_MAXT2")) : 256;
+    if (T <= kSkinnyMaxT_()) return true;
+    const int max2 = tune(TK_GEMM_SKINNY_MAXT2);
     return T <= max2 && N * K < ((int64_t)24 << 20);
 }
 

@@ -489,7 +489,6 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
 }
 
 static std::atomic<int> g_gemv_r{0}, g_gemv_u{0}, g_force_blocks{0}, g_force_waves{0};
-static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
 
 void gemv_set_tuning(int R, int U, int blocks, int waves) {
     if (R > 0) g_gemv_r = R;
@@ -580,7 +579,7 @@ static int launch_gemv_t(Launcher &L, const GemvArgs &a) {
     }
     if (PRO == PRO_NORM && (int64_t)waves * 64 * 3 * 8 < K) waves = (int)((K + 64 * 3 * 8 - 1) / (64 * 3 * 8));   // staging capacity
     if (waves < 4) waves = 4;
-    static const int allow_small = env_int("FL_GEMV_SMALL", 1);
+    const int allow_small = tune(TK_GEMV_SMALL);
     const bool small = allow_small && sizeof(WT) == 2 && ngroups <= (int64_t)blocks * waves && (K >> 3) % (64 * U) == 0 &&
                        (K >> 3) <= 2 * 64 * U && (PRO != PRO_NORM || (int64_t)waves * 64 * 8 >= K);
     if (small) return launch_gemv_k<WT, XT, R, U, PRO, 768, true>(L, a, blocks, waves, lds);
@@ -590,8 +589,8 @@ static int launch_gemv_t(Launcher &L, const GemvArgs &a) {
 template <typename WT, typename XT, int PRO>
 static int launch_gemv_ru(Launcher &L, const GemvArgs &a) {
     int R = g_gemv_r.load(), U = g_gemv_u.load();
-    if (!R) { R = env_int("FL_GEMV_R", 2); g_gemv_r = R; }
-    if (!U) { U = env_int("FL_GEMV_U", 0); g_gemv_u = U ? U : -1; }
+    if (!R) { R = tune(TK_GEMV_R); g_gemv_r = R; }
+    if (!U) { U = tune(TK_GEMV_U); g_gemv_u = U ? U : -1; }
     // default (no FL_GEMV_U / fl_tune): four 1-KiB chunks in flight per row, two for the plain and RoPE epilogues at
     // K <= 4096 (Mistral-7B: o_proj 7.96 -> 7.48 us, lm_head 43.8 -> 42.0, QKV 11.95 -> 11.82; down_proj at K = 14336
     // 19.9 vs 20.9 and gate/up 38.2 vs 38.1 stay on four)
@@ -615,7 +614,7 @@ static int launch_gemv_ru(Launcher &L, const GemvArgs &a) {
 // device with >= 512 CUs may not: the caller then leaves amax null and token selection scans the logits instead.
 bool gemv_leaves_candidates(int dtype, const GemvArgs &a) {
     int R = g_gemv_r.load();
-    if (!R) R = env_int("FL_GEMV_R", 2);
+    if (!R) R = tune(TK_GEMV_R);
     if (R != 4) R = 2;                                       // (the instantiations launch_gemv_ru picks from)
     const size_t es = dtype == FL_DTYPE_BF16 ? 2 : 4;
     int blocks = 1, waves = 4;
@@ -625,7 +624,7 @@ bool gemv_leaves_candidates(int dtype, const GemvArgs &a) {
 
 int64_t gemv_owner_chunk(int dtype, int64_t N, int64_t K) {
     int R = g_gemv_r.load();
-    if (!R) R = env_int("FL_GEMV_R", 2);
+    if (!R) R = tune(TK_GEMV_R);
     if (R != 4) R = 2;
     const size_t es = dtype == FL_DTYPE_BF16 ? 2 : 4;
     int blocks = 1, waves = 4;

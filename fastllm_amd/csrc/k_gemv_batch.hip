@@ -614,7 +614,7 @@ template <int NB, int PRO, int EPI>
 static int launch_gemv_batch_e(Launcher &L, const GemvBatchArgs &a) {
     // FL_BATCH_U=8: 16-KiB blocks as the single-sequence kernel uses from K = 4096 -- measured no better here (one and two streams:
     // 2.97 / 3.04 ms per step against 2.93 / 3.01 with 8-KiB blocks), so 4 is the default; NB <= 2 only (registers)
-    static const int u_env = getenv("FL_BATCH_U") ? atoi(getenv("FL_BATCH_U")) : 0;
+    const int u_env = tune(TK_BATCH_U);
     if constexpr (NB <= 2) {
         if (u_env == 8) return launch_gemv_batch_u<NB, PRO, EPI, 8>(L, a);
     }
@@ -655,7 +655,7 @@ static int launch_gemv_batch_mfma_t(Launcher &L, const GemvBatchArgs &a) {
     const int64_t nchunk_all = a.K / 8;
     const int64_t per = ((nchunk_all + a.nks - 1) / a.nks + 63) & ~(int64_t)63;
     int mu = 4;
-    bool pipe = !(getenv("FL_BATCH_MODE") && atoi(getenv("FL_BATCH_MODE")) == 0);
+    bool pipe = tune(TK_BATCH_MODE) != 0;
     for (int k = 0; k < a.nks; k++) {
         const int64_t c0 = std::min(nchunk_all, k * per), c1 = std::min(nchunk_all, c0 + per);
         const int64_t steps = (c1 - c0) / 4;
@@ -664,7 +664,7 @@ static int launch_gemv_batch_mfma_t(Launcher &L, const GemvBatchArgs &a) {
     }
     // staging variants need room for 64 KB next to the activations
     const size_t lds_staged = (size_t)8 * (per * 8 + 8) * 2 + (size_t)(8 * 2 * 256 + 2 * 256) * 4 + 8 * 8192;
-    static const int mode_env = getenv("FL_BATCH_MODE") ? atoi(getenv("FL_BATCH_MODE")) : 2;
+    const int mode_env = tune(TK_BATCH_MODE);
     if (pipe) {
         if (mu == 4 && mode_env >= 2 && lds_staged <= 160 * 1024 - 1024) return launch_gemv_batch_mfma_k<PRO, 4, 2>(L, a);
         if (mu == 4) return launch_gemv_batch_mfma_k<PRO, 4, 1>(L, a);
@@ -680,7 +680,7 @@ int launch_gemv_batch(Launcher &L, const GemvBatchArgs &a) {
     if (a.nks > 1 && a.epi != EPI_F32) FL_FAIL(FL_ERR_BAD_ARGUMENT, "launch_gemv_batch: K slices only for the fp32 epilogue");
     if (a.epi == EPI_GATEUP && a.N % 32) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gate/up matrix rows must be a multiple of 32");
     if (a.epi == EPI_QKV_ROPE && (a.d <= 0 || a.d % 2 || a.N != (a.H + 2 * a.Hkv) * a.d || !a.seqs)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "bad qkv shape");
-    static const int mfma_min = [] { const char *e = getenv("FL_BATCH_MFMA_MIN"); return e && *e ? atoi(e) : 3; }();
+    const int mfma_min = tune(TK_BATCH_MFMA_MIN);
     const bool mfma_ok = a.K % 32 == 0 && (a.epi != EPI_QKV_ROPE || (a.d % 32 == 0)) && (a.epi != EPI_GATEUP || a.N % 32 == 0);
     if (a.B >= mfma_min && mfma_ok)
         return a.pro == PRO_NORM ? launch_gemv_batch_mfma_t<PRO_NORM>(L, a) : launch_gemv_batch_mfma_t<PRO_X>(L, a);

@@ -221,7 +221,7 @@ static int cu_count_d() {
 
 // K tiles per wave for a slice count; 0 = the shape does not fit the kernel
 static int dma_kt(int64_t K) {                                  // k per ring stage: 128 (256-byte row segments) where K allows it
-    static const int want = [] { const char *e = getenv("FL_DMA_KT"); return e && *e ? atoi(e) : 128; }();
+    const int want = tune(TK_DMA_KT);
     return want == 128 && K % 128 == 0 ? 128 : 64;
 }
 static int dma_tiles_per_wave(int64_t K, int nks) {

@@ -15,10 +15,6 @@
 
 namespace fl {
 
-static int env_int(const char *name, int dflt) {
-    const char *s = getenv(name);
-    return s && *s ? atoi(s) : dflt;
-}
 
 // =============================================================================== generic GEMM
 // 64x64 output tile, 16-deep K slices through LDS (as fp32), 256 threads, 4x4 per thread with
@@ -109,7 +105,7 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
     if (n_split_out) *n_split_out = 1;
     if (T <= 0 || N <= 0 || K <= 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "launch_linear: bad shape");
     if (epi == EPI_GATEUP && N % 32) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gate/up matrix rows must be a multiple of 32");
-    static const int force_generic = env_int("FL_FORCE_GENERIC_GEMM", 0);
+    const int force_generic = tune(TK_FORCE_GENERIC_GEMM);
     if (dtype == FL_DTYPE_BF16) {
         if (T == 1 && gemv_supported(dtype, N, K)) return launch_gemv(L, dtype, plain_args(W, x, bias, y, N, K, epi, row_scale));
         // mid-size prompts: 128 x 256 tiles, K slices summed inside the launch (k_gemm_h4.hip) -- one complete output, no slabs
@@ -117,7 +113,7 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
             const int ks = gemm_h4_plan(T, N, K, epi);
             if (ks > 0) return launch_gemm_h4(L, W, x, bias, y, T, N, K, epi, row_scale, ks);
         }
-        static const int use_skinny = env_int("FL_GEMM_SKINNY", 1);
+        const int use_skinny = tune(TK_GEMM_SKINNY);
         if (!force_generic && use_skinny && gemm_skinny_supported(T, N, K)) {     // short prompts: a weight stream
             const int ks = (n_split_out && !bias) ? gemm_skinny_ksplit(T, N, K, epi, std::min(max_split, 4)) : 1;   // (more slabs cost the summing launch more than they save here)
             if (n_split_out) *n_split_out = ks;

@@ -241,7 +241,7 @@ int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st
     const unsigned blocks = (unsigned)((total + 255) / 256);
     const int es = dtype == FL_DTYPE_BF16 ? 2 : 4;
     double bytes = (double)T * (H + 2 * Hkv) * d * (4 + es);
-    static const int use_vec = getenv("FL_ROPE_VEC") ? atoi(getenv("FL_ROPE_VEC")) : 1;
+    const int use_vec = tune(TK_ROPE_VEC);
     if (use_vec && dtype == FL_DTYPE_BF16 && v_transposed && T >= 16 && d % 64 == 0 && max_seq % 8 == 0) {
         const int64_t itemsA = T * (H + Hkv) * (d / 16);
         const int nA = (int)((itemsA + 255) / 256), nB = (int)(((T + 31) / 32) * Hkv * (d / 64));
@@ -793,27 +793,32 @@ template <typename DT>
 __global__ __launch_bounds__(256) void convert_slice_kernel(const void *__restrict__ src, int src_dt, long long src_ld,
                                                             long long r0, long long c0, long long rows, long long cols,
                                                             DT *__restrict__ dst, long long dst_ld, long long dst_row0,
-                                                            int row_mode) {
+                                                            int row_mode, int head_pad, int dm, int d) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * cols) return;
     const long long r = i / cols, c = i % cols;
     const float v = load_as_f32(src, (size_t)((r0 + r) * src_ld + c0 + c), src_dt);
-    long long dr = row_mode == 0 ? dst_row0 + r : gateup_row(r, row_mode == 2);
-    elem<DT>::st(dst + (size_t)(dr * dst_ld + c), v);
+    long long dr = row_mode == 0 ? dst_row0 + r : gateup_row(r, row_mode == 2), dc = c;
+    // head_pad: element j of a head of the model's head_dim dm goes to j (first half) or d/2 + j - dm/2 (second half) of a padded
+    // head of d: rotate-half partners stay d/2 apart; 1 = the slice's rows are heads, 2 = its columns are
+    auto padded = [&](long long x) { const long long hd = x / dm, j = x % dm; return hd * d + (j < dm / 2 ? j : d / 2 + j - dm / 2); };
+    if (head_pad == 1) dr = dst_row0 + padded(r);
+    if (head_pad == 2) dc = padded(c);
+    elem<DT>::st(dst + (size_t)(dr * dst_ld + dc), v);
 }
 
 int launch_convert_slice(Launcher &L, int src_dtype, const void *src, int64_t src_ld, int64_t r0, int64_t c0,
                          int64_t rows, int64_t cols, int dst_dtype, void *dst, int64_t dst_ld, int64_t dst_row0,
-                         int row_mode) {
+                         int row_mode, int head_pad, int64_t dm, int64_t d) {
     const int64_t total = rows * cols;
     const unsigned blocks = (unsigned)((total + 255) / 256);
     if (dst_dtype == FL_DTYPE_BF16)
         return L.launch(KC_CONVERT, 0, 0, convert_slice_kernel<bf16_t>, dim3(blocks), dim3(256), 0, src, src_dtype,
                         (long long)src_ld, (long long)r0, (long long)c0, (long long)rows, (long long)cols,
-                        (bf16_t *)dst, (long long)dst_ld, (long long)dst_row0, row_mode);
+                        (bf16_t *)dst, (long long)dst_ld, (long long)dst_row0, row_mode, head_pad, (int)dm, (int)d);
     return L.launch(KC_CONVERT, 0, 0, convert_slice_kernel<float>, dim3(blocks), dim3(256), 0, src, src_dtype,
                     (long long)src_ld, (long long)r0, (long long)c0, (long long)rows, (long long)cols, (float *)dst,
-                    (long long)dst_ld, (long long)dst_row0, row_mode);
+                    (long long)dst_ld, (long long)dst_row0, row_mode, head_pad, (int)dm, (int)d);
 }
 
 int launch_convert_vec_f32(Launcher &L, int src_dtype, const void *src, int64_t off, int64_t n, float *dst) {

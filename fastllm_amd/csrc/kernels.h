@@ -337,7 +337,7 @@ int launch_attn_oproj_rep(Launcher &L, const AttnRepArgs &a);
 // dst[row_map(r)][c] = cvt(src[r0+r][c0+c]); row_mode 0: dst_row0+r, 1: gate rows, 2: up rows
 int launch_convert_slice(Launcher &L, int src_dtype, const void *src, int64_t src_ld, int64_t r0, int64_t c0,
                          int64_t rows, int64_t cols, int dst_dtype, void *dst, int64_t dst_ld,
-                         int64_t dst_row0, int row_mode);
+                         int64_t dst_row0, int row_mode, int head_pad = 0, int64_t dm = 1, int64_t d = 1);   // head_pad: padded head_dim (model.hip)
 int launch_convert_vec_f32(Launcher &L, int src_dtype, const void *src, int64_t off, int64_t n, float *dst);
 
 }  // namespace fl

@@ -14,7 +14,9 @@ namespace fl {
 
 struct Dims {                    // resolved config (defaults applied)
     int family = 0, qkv_bias = 0;
-    int64_t h = 0, inter = 0, V = 0, L = 0, H = 0, Hkv = 0, d = 0, max_pos = 0, window = -1;
+    int64_t h = 0, inter = 0, V = 0, L = 0, H = 0, Hkv = 0, max_pos = 0, window = -1;
+    int64_t dm = 0;              // the MODEL's head_dim = hidden_size / num_attention_heads (any even value, config.rs:31-43)
+    int64_t d = 0;               // the head_dim the kernels run: dm padded to 64 or 128 with zero weight rows (model.hip, build_weights)
     float eps = 0.f, scale = 0.f;
     double theta = 10000.0;
 };

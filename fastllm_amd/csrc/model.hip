@@ -37,7 +37,9 @@ void set_error(const char *fmt, ...) {
 const char *last_error() { return g_err; }
 
 
-int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
+// the library's only reads of the environment: the switch table below (integers) and a handful of diagnostic paths / the fault injector (strings)
+const char *env_str(const char *name) { const char *s = getenv(name); return s && *s ? s : nullptr; }
+int env_int(const char *name, int dflt) { const char *s = env_str(name); return s ? atoi(s) : dflt; }
 
 // ------------------------------------------------------------------------------- switches (common.h: TuneKey)
 struct TuneEntry { const char *name; int dflt; };
@@ -46,6 +48,77 @@ static const TuneEntry g_tune_table[TK_COUNT] = {
     {"h4_split", 0},
     {"h4_pf", 6},
     {"h4_wait_us", 30},
+    {"op_maxsplit", 0},
+    {"op_linear_dma", 0},
+    {"op_hot", 0},
+    {"ar_inbox_floats", 65536},
+    {"ar_timeout_ms", 20000},
+    {"verbose", 0},
+    {"tp_fused_ar", 1},
+    {"attn_nw", 4},
+    {"attn_prefetch", 0},
+    {"attn_prefetch_lines", 8},
+    {"attn_prefetch_pct", 100},
+    {"attn_prefetch_delay", 0},
+    {"attn_batch_wgs", 256},
+    {"attn_pf32_min_t", 0},
+    {"attn_pf32_ks2", -1},
+    {"attn_pf32_paired", -1},
+    {"attn_pf_waves", 0},
+    {"attn_pf_stages", 2},
+    {"attn_pf_ksplit", 2},
+    {"ao_delay", 6},
+    {"ao_waves", 0},
+    {"engine_delay", 12},
+    {"engine_pf", 1},
+    {"engine_timeout_ms", 2000},
+    {"sk_minsteps", 8},
+    {"gemm_4w", 1},
+    {"gemm_groupm", 0},
+    {"8p_mink", 8},
+    {"gemm_8p", 1},
+    {"gemm_256", 1},
+    {"gemm_256_split", 1},
+    {"gemm_streamk", 1},
+    {"gemm_peel", 1},
+    {"gemm_resid", 1},
+    {"gemm_skinny_maxt", 128},
+    {"skinny_stages", 4},
+    {"skinny_nt", 1},
+    {"skinny_wm", 1},
+    {"skinny_loaders", -1},
+    {"gemm_skinny_maxt2", 256},
+    {"gemv_small", 1},
+    {"gemv_r", 2},
+    {"gemv_u", 0},
+    {"batch_u", 0},
+    {"batch_mode", 2},
+    {"batch_mfma_min", 3},
+    {"dma_kt", 128},
+    {"force_generic_gemm", 0},
+    {"gemm_skinny", 1},
+    {"rope_vec", 1},
+    {"weight_arena", 1},
+    {"ksplit_mid", 0},
+    {"prefill_chunk", 8192},
+    {"graph", -1},
+    {"fused", 1},
+    {"allow_any_arch", 0},
+    {"engine", 0},
+    {"fuse_oproj", 0},
+    {"oneshot", 1},
+    {"debug_rccl_self", 0},
+    {"attn_mfma", 1},
+    {"attn_nsplit", -1},
+    {"attn_rep", 1},
+    {"sample_walk", 0},
+    {"argmax_fused", 1},
+    {"tp_overlap", 1},
+    {"tp_overlap_min_t", 512},
+    {"qkv_split", 8},
+    {"tp_graph", 1},
+    {"batch_dma_min", 3},
+    {"batch_unfused_min", -1},
 };
 static std::atomic<int> g_tune[TK_COUNT];
 static std::once_flag g_tune_once;
@@ -91,7 +164,7 @@ int raise_dynamic_lds(const void *fn, size_t lds) {
 // Fault injection for the tests of the ABI's exception barrier: FL_DEBUG_THROW="<site>=<bad_alloc|runtime|int>"
 // makes the named site throw, as a failed `new` / std::vector growth would.
 void debug_inject(const char *site) {
-    const char *s = getenv("FL_DEBUG_THROW");
+    const char *s = env_str("FL_DEBUG_THROW");
     if (!s || !*s) return;
     const size_t n = strlen(site);
     if (strncmp(s, site, n) || s[n] != '=') return;
@@ -112,9 +185,14 @@ int resolve_config(const fl_config *cfg, Dims *o) {
     D.L = cfg->num_hidden_layers; D.H = cfg->num_attention_heads;
     if (D.h <= 0 || D.inter <= 0 || D.V <= 0 || D.L <= 0 || D.H <= 0) FL_FAIL(FL_ERR_BAD_CONFIG, "non-positive model dimension");
     D.Hkv = cfg->num_key_value_heads > 0 ? cfg->num_key_value_heads : D.H;          // llama.rs:39
-    D.d = D.h / D.H;
-    if (D.d * D.H != D.h) FL_FAIL(FL_ERR_BAD_CONFIG, "hidden_size must be divisible by num_attention_heads");   // config.rs:34
-    if (D.d % 2) FL_FAIL(FL_ERR_BAD_CONFIG, "head_dim must be even for RoPE embeddings");                       // config.rs:39
+    D.dm = D.h / D.H;
+    if (D.dm * D.H != D.h) FL_FAIL(FL_ERR_BAD_CONFIG, "hidden_size must be divisible by num_attention_heads");   // config.rs:34
+    if (D.dm % 2) FL_FAIL(FL_ERR_BAD_CONFIG, "head_dim must be even for RoPE embeddings");                       // config.rs:39
+    // The kernels are built for head_dim 64 and 128 (MFMA tiles, 16-byte rows).  Any other even head_dim up to 128 -- the reference
+    // takes every even value (config.rs:31-43; e.g. 80, 96, 100) -- runs as the next of the two: every head's q / k / v rows are
+    // laid out as [first half | zeros | second half | zeros] (so rotate-half pairs stay dm/2... d/2 apart) and o_proj gets zero
+    // columns to match; the padded lanes carry exact zeros through RoPE, scores and values.  Above 128: fl_model_create refuses.
+    D.d = D.dm <= 64 ? 64 : 128;
     if (D.H % D.Hkv) FL_FAIL(FL_ERR_BAD_CONFIG, "num_attention_heads must be divisible by num_key_value_heads"); // config.rs:48
     if (cfg->rms_norm_eps < 0) FL_FAIL(FL_ERR_BAD_CONFIG, "negative rms_norm_eps");
     D.eps = (float)cfg->rms_norm_eps;
@@ -123,7 +201,7 @@ int resolve_config(const fl_config *cfg, Dims *o) {
     D.max_pos = cfg->max_position_embeddings > 0 ? cfg->max_position_embeddings : dflt_pos;
     if (D.family == FL_FAMILY_LLAMA) D.window = -1;
     else D.window = cfg->sliding_window > 0 ? cfg->sliding_window : (cfg->sliding_window < 0 ? -1 : 4096);      // mistral.rs:139
-    D.scale = (float)(1.0 / sqrt((double)D.d));
+    D.scale = (float)(1.0 / sqrt((double)D.dm));                                                                 // (the model's head_dim, not the padded one)
     *o = D;
     return FL_OK;
 }
@@ -139,7 +217,7 @@ int tp_slice(const Dims &D, const char *name_c, int rank, int tp, int64_t out[4]
     if (D.H % tp || D.Hkv % tp) FL_FAIL(FL_ERR_UNSUPPORTED, "tp=%d must divide heads (%lld) and kv heads (%lld)", tp, (long long)D.H, (long long)D.Hkv);
     if (D.inter % tp) FL_FAIL(FL_ERR_UNSUPPORTED, "tp=%d must divide intermediate_size %lld", tp, (long long)D.inter);
     const std::string name(name_c);
-    const int64_t qd = D.H * D.d, kvd = D.Hkv * D.d;
+    const int64_t qd = D.H * D.dm, kvd = D.Hkv * D.dm;             // (source tensor coordinates: the model's head_dim)
     int64_t R = 0, C = 0, r0 = 0, r1 = 0, c0 = 0, c1 = 0;
     auto rows = [&](int64_t n, int64_t k) { R = n; C = k; r0 = n / tp * rank; r1 = n / tp * (rank + 1); c0 = 0; c1 = k; };
     auto cols = [&](int64_t n, int64_t k) { R = n; C = k; r0 = 0; r1 = n; c0 = k / tp * rank; c1 = k / tp * (rank + 1); };
@@ -249,9 +327,10 @@ struct Builder {
 
 // Copy slice [r0,r1) x [c0,c1) of tensor `name` (full shape R x C) into dst (ld = dst_ld) on every
 // shard that lives on st.device; dst_of(shard) gives the destination base, row_mode the row map.
+// head_pad: 0 none; 1 the ROWS are heads of the model's head_dim dm, placed as padded heads of d rows; 2 the COLUMNS are
 template <typename DstFn>
 static int put_matrix(Builder &B, Stager &st, const std::string &name, int64_t R, int64_t C, int dst_dtype,
-                      int64_t dst_ld, int64_t dst_row0, int row_mode, DstFn dst_of) {
+                      int64_t dst_ld, int64_t dst_row0, int row_mode, DstFn dst_of, int head_pad = 0) {
     Model *m = B.m;
     const fl_tensor *t = nullptr;
     FL_TRY(B.want(name, R, C, &t));
@@ -263,7 +342,7 @@ static int put_matrix(Builder &B, Stager &st, const std::string &name, int64_t R
         FL_TRY(tp_slice(m->D, name.c_str(), sh.rank, m->tp, sl));
         Launcher L; L.stream = sh.stream;
         FL_TRY(launch_convert_slice(L, t->dtype, src, C, sl[0], sl[2], sl[1] - sl[0], sl[3] - sl[2], dst_dtype,
-                                    dst_of(sh), dst_ld, dst_row0, row_mode));
+                                    dst_of(sh), dst_ld, dst_row0, row_mode, m->D.dm != m->D.d ? head_pad : 0, m->D.dm, m->D.d));
     }
     FL_HIP(hipDeviceSynchronize());       // the staging buffer is reused by the next tensor
     return FL_OK;
@@ -279,7 +358,7 @@ static int build_weights(Builder &B) {
 
     // allocate: one arena per shard (FL_WEIGHT_ARENA=0: one hipMalloc per tensor).  The whole model is then a single
     // virtual range, which the driver can map with its largest page fragments
-    static const int use_arena = env_int("FL_WEIGHT_ARENA", 1);
+    const int use_arena = tune(TK_WEIGHT_ARENA);
     for (auto &sh : m->shards) {
         FL_HIP(hipSetDevice(sh.device));
         const int64_t nq = (sh.Hs + 2 * sh.Hkvs) * D.d;
@@ -311,6 +390,11 @@ static int build_weights(Builder &B) {
             FL_TRY(walloc(&ly.wd, (size_t)D.h * sh.Ip * es));
             FL_TRY(walloc((void **)&ly.ln1, (size_t)D.h * 4));
             FL_TRY(walloc((void **)&ly.ln2, (size_t)D.h * 4));
+            if (D.dm != D.d) {               // padded head_dim: the rows / columns between the halves of every head stay zero
+                FL_HIP(hipMemsetAsync(ly.wqkv, 0, (size_t)nq * D.h * es, sh.stream));
+                if (D.qkv_bias) FL_HIP(hipMemsetAsync(ly.bqkv, 0, (size_t)nq * 4, sh.stream));
+                FL_HIP(hipMemsetAsync(ly.wo, 0, (size_t)D.h * sh.Hs * D.d * es, sh.stream));
+            }
             if (sh.Ip != sh.Is) {            // zero padding rows/cols so they contribute nothing
                 FL_HIP(hipMemsetAsync(ly.wgu, 0, (size_t)2 * sh.Ip * D.h * es, sh.stream));
                 FL_HIP(hipMemsetAsync(ly.wd, 0, (size_t)D.h * sh.Ip * es, sh.stream));
@@ -344,18 +428,18 @@ static int build_weights(Builder &B) {
         for (int64_t l = 0; l < D.L; l++) {
             const std::string p = "model.layers." + std::to_string(l) + ".";
             auto LY = [l](Shard &s) -> LayerW & { return s.layers[l]; };
-            const int64_t qd = D.H * D.d, kvd = D.Hkv * D.d;
+            const int64_t qd = D.H * D.dm, kvd = D.Hkv * D.dm;       // (source tensors: the model's head_dim)
             // fused q|k|v: destination row offsets inside the shard's fused matrix
             struct { const char *nm; int64_t R; int which; } qkv[3] = {{"self_attn.q_proj", qd, 0}, {"self_attn.k_proj", kvd, 1}, {"self_attn.v_proj", kvd, 2}};
             for (auto &e : qkv) {
                 // all local shards have equal Hs / Hkvs, so the row offset is shard-independent
                 const Shard &s0 = m->shards[0];
                 const int64_t off = e.which == 0 ? 0 : (e.which == 1 ? s0.Hs * D.d : (s0.Hs + s0.Hkvs) * D.d);
-                FL_TRY(put_matrix(B, st, p + e.nm + ".weight", e.R, D.h, wdt, D.h, off, 0, [&](Shard &s) { return LY(s).wqkv; }));
+                FL_TRY(put_matrix(B, st, p + e.nm + ".weight", e.R, D.h, wdt, D.h, off, 0, [&](Shard &s) { return LY(s).wqkv; }, 1));
                 if (D.qkv_bias)
-                    FL_TRY(put_matrix(B, st, p + e.nm + ".bias", e.R, 1, FL_DTYPE_F32, 1, off, 0, [&](Shard &s) { return (void *)LY(s).bqkv; }));
+                    FL_TRY(put_matrix(B, st, p + e.nm + ".bias", e.R, 1, FL_DTYPE_F32, 1, off, 0, [&](Shard &s) { return (void *)LY(s).bqkv; }, 1));
             }
-            FL_TRY(put_matrix(B, st, p + "self_attn.o_proj.weight", D.h, qd, wdt, m->shards[0].Hs * D.d, 0, 0, [&](Shard &s) { return LY(s).wo; }));
+            FL_TRY(put_matrix(B, st, p + "self_attn.o_proj.weight", D.h, qd, wdt, m->shards[0].Hs * D.d, 0, 0, [&](Shard &s) { return LY(s).wo; }, 2));
             FL_TRY(put_matrix(B, st, p + "mlp.gate_proj.weight", D.inter, D.h, wdt, D.h, 0, 1, [&](Shard &s) { return LY(s).wgu; }));
             FL_TRY(put_matrix(B, st, p + "mlp.up_proj.weight", D.inter, D.h, wdt, D.h, 0, 2, [&](Shard &s) { return LY(s).wgu; }));
             FL_TRY(put_matrix(B, st, p + "mlp.down_proj.weight", D.h, D.inter, wdt, m->shards[0].Ip, 0, 0, [&](Shard &s) { return LY(s).wd; }));
@@ -370,13 +454,13 @@ static int build_weights(Builder &B) {
 // product); cos/sin in fp32.  Built once on the host, one copy per shard.
 static int build_rope(Model *m) {
     const Dims &D = m->D;
-    const int64_t half = D.d / 2;
+    const int64_t half = D.d / 2, half_m = D.dm / 2;             // pairs of the padded layout; of them, the model's (the rest rotate zeros: identity)
     std::vector<float> inv(half), c((size_t)D.max_pos * half), s((size_t)D.max_pos * half);
     const float theta = (float)D.theta;
-    for (int64_t j = 0; j < half; j++) inv[j] = 1.0f / powf(theta, (float)(2 * j) / (float)D.d);
+    for (int64_t j = 0; j < half_m; j++) inv[j] = 1.0f / powf(theta, (float)(2 * j) / (float)D.dm);
     for (int64_t p = 0; p < D.max_pos; p++)
         for (int64_t j = 0; j < half; j++) {
-            const float ang = (float)p * inv[j];
+            const float ang = j < half_m ? (float)p * inv[j] : 0.0f;
             c[(size_t)p * half + j] = cosf(ang);
             s[(size_t)p * half + j] = sinf(ang);
         }
@@ -398,7 +482,7 @@ constexpr int kMaxKSplitMid = 8;
 constexpr int kMidT = 1024;
 constexpr int kMaxQkvSplit = 2;   // QKV projection of a long prompt (its grid leaves CUs idle); rope_kv sums the slabs
 constexpr int kMaxQkvSplitShort = 4;   // ... of a short prompt / a decode batch (T <= 128: the projection is a weight stream)
-static int mid_cap(int dflt) { const char *e = getenv("FL_KSPLIT_MID"); const int v = e && *e ? atoi(e) : 0; return v > 0 ? std::min(v, kMaxKSplitMid) : dflt; }   // (read per call: A/B tools lower it on a live model; the slabs were sized for the default)
+static int mid_cap(int dflt) { const int v = tune(TK_KSPLIT_MID); return v > 0 ? std::min(v, kMaxKSplitMid) : dflt; }   // (read per call: A/B tools lower it on a live model; the slabs were sized for the default)
 int ksplit_cap(int64_t T) { return T <= 1 ? 1 : (T > 128 && T <= kMidT ? mid_cap(kMaxKSplitMid) : kMaxKSplit); }
 static int qkv_split_cap(int64_t T) { return T <= 1 ? 1 : (T <= 128 ? kMaxQkvSplitShort : (T <= kMidT ? mid_cap(kMaxKSplitMid) : kMaxQkvSplit)); }
 // the same caps with the switch at its largest value: what the slab buffers are SIZED for (a later, larger FL_KSPLIT_MID must
@@ -437,7 +521,7 @@ static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T, std::vecto
 // stream synchronisation, so under the model mutex the old buffers are idle (a long-running server that sees longer
 // and longer prompts would otherwise pile up one dead set per new maximum, ~180 KB per token for Mistral-7B).
 static int grow_prefill_scratch(Model *m, Shard &sh, int64_t T) {
-    const int64_t chunk_max = env_int("FL_PREFILL_CHUNK", 8192);
+    const int64_t chunk_max = tune(TK_PREFILL_CHUNK);
     int64_t cap = std::max<int64_t>(T, std::min<int64_t>(chunk_max, sh.pre.cap_T + sh.pre.cap_T / 2));
     cap = std::min<int64_t>(std::max<int64_t>(T, chunk_max), (cap + 127) / 128 * 128);
     FL_HIP(hipStreamSynchronize(sh.stream));
@@ -466,7 +550,7 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
     Dims D;
     FL_TRY(resolve_config(cfg, &D));
     if (D.h % 8) FL_FAIL(FL_ERR_UNSUPPORTED, "hidden_size must be a multiple of 8 (16-byte rows)");
-    if (D.d != 64 && D.d != 128) FL_FAIL(FL_ERR_UNSUPPORTED, "head_dim %lld not supported (64 or 128)", (long long)D.d);
+    if (D.dm > 128) FL_FAIL(FL_ERR_UNSUPPORTED, "head_dim %lld not supported (even values up to 128)", (long long)D.dm);
     if (D.max_pos > (1 << 20)) D.max_pos = 1 << 20;
     debug_inject("model_create");
 
@@ -489,8 +573,8 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
     m->cfg_resolved = *cfg;
     m->cfg_resolved.num_key_value_heads = D.Hkv; m->cfg_resolved.rope_theta = D.theta;
     m->cfg_resolved.max_position_embeddings = D.max_pos; m->cfg_resolved.sliding_window = D.window;
-    m->use_graph = env_int("FL_GRAPH", 1) != 0;
-    m->fused_decode = env_int("FL_FUSED", 1) != 0 && gemv_norm_supported(compute_dtype, 1, D.h);
+    m->use_graph = tune(TK_GRAPH) != 0;                 // (-1 = automatic: on)
+    m->fused_decode = tune(TK_FUSED) != 0 && gemv_norm_supported(compute_dtype, 1, D.h);
 
     auto dev_of = [&](int i) -> int { return (P.device_ids && i < P.n_device_ids) ? P.device_ids[i] : i; };
     int nlocal = 1;
@@ -516,7 +600,7 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
     {   // is it a gfx950?
         hipDeviceProp_t prop;
         FL_HIP(hipGetDeviceProperties(&prop, m->shards[0].device));
-        if (!strstr(prop.gcnArchName, "gfx950") && !env_int("FL_ALLOW_ANY_ARCH", 0))
+        if (!strstr(prop.gcnArchName, "gfx950") && !tune(TK_ALLOW_ANY_ARCH))
             FL_FAIL(FL_ERR_NO_DEVICE, "device is %s; this library is built for gfx950 only", prop.gcnArchName);
     }
 
@@ -555,8 +639,12 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
     FL_HIP(hipHostMalloc((void **)&m->host_logits, (size_t)D.V * 4, hipHostMallocDefault));
     FL_HIP(hipHostMalloc((void **)&m->host_tokens, kOutTokensCap * 4, hipHostMallocDefault));
     FL_HIP(hipHostMalloc((void **)&m->host_state, sizeof(StepState), hipHostMallocDefault));
-    m->engine = env_int("FL_ENGINE", 0);                  // persistent decode engine (k_engine.hip): 1 = wherever it runs (opt-in: it measured slower)
-    m->fuse_oproj = env_int("FL_FUSE_OPROJ", 0);          // 0.0-1.5 % at best (profiles/r02/README.md): off unless asked for; -1 = where it pays most
+#ifdef FL_EXPERIMENTAL
+    m->engine = tune(TK_ENGINE);                  // persistent decode engine (k_engine.hip): 1 = wherever it runs (opt-in: it measured slower)
+    m->fuse_oproj = tune(TK_FUSE_OPROJ);          // 0.0-1.5 % at best (profiles/r02/README.md): off unless asked for; -1 = where it pays most
+#else
+    m->engine = 0; m->fuse_oproj = 0;             // measured losers live in the EXPERIMENTAL build only (Makefile)
+#endif
 
     // communicators
     if (tp > 1 && P.mode == FL_TP_SINGLE_PROCESS) {
@@ -574,7 +662,7 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
             FL_NCCL(ncclCommInitAll(comms.data(), tp, devs.data()));
             for (int i = 0; i < tp; i++) m->shards[i].comm = comms[i];
         }
-        if (env_int("FL_ONESHOT", 1) || !distinct) {
+        if (tune(TK_ONESHOT) || !distinct) {
             bool ok = true;
             for (int i = 0; i < tp && ok; i++) ok = comm_alloc(m.get(), m->shards[i]) == FL_OK;
             for (int i = 0; i < tp && ok; i++) {
@@ -607,21 +695,21 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
             ncclUniqueId id; memcpy(&id, P.unique_id, sizeof id);
             FL_HIP(hipSetDevice(m->shards[0].device));
             FL_NCCL(ncclCommInitRank(&m->shards[0].comm, tp, id, P.tp_rank));
-            if (env_int("FL_ONESHOT", 1)) FL_TRY(comm_bootstrap_over_rccl(m.get()));
+            if (tune(TK_ONESHOT)) FL_TRY(comm_bootstrap_over_rccl(m.get()));
         }
     } else if (tp > 1 && P.mode == FL_TP_EMULATED) {
         FL_HIP(hipMalloc((void **)&m->emu_ptrs, sizeof(float *) * tp * 2));
     } else if (tp > 1) {
         FL_FAIL(FL_ERR_BAD_ARGUMENT, "tp_size %d needs a tensor-parallel mode", tp);
-    } else if (env_int("FL_DEBUG_RCCL_SELF", 0)) {
+    } else if (tune(TK_DEBUG_RCCL_SELF)) {
         // single-GPU rehearsal of the RCCL plumbing: a 1-rank communicator whose all-reduce is the
         // identity, issued at the two real call sites (after o_proj and down_proj) on the compute stream
         ncclUniqueId id;
         FL_NCCL(ncclGetUniqueId(&id));
         FL_HIP(hipSetDevice(m->shards[0].device));
         FL_NCCL(ncclCommInitRank(&m->shards[0].comm, 1, id, 0));
-        m->use_graph = env_int("FL_GRAPH", 0) != 0;     // eager unless graph capture of RCCL is asked for
-        if (env_int("FL_ONESHOT", 1)) {                 // ... and of the inbox bootstrap: a group of one
+        m->use_graph = tune(TK_GRAPH) > 0;              // eager unless graph capture of RCCL is asked for
+        if (tune(TK_ONESHOT)) {                 // ... and of the inbox bootstrap: a group of one
             FL_TRY(comm_alloc(m.get(), m->shards[0]));
             FL_TRY(comm_bootstrap_over_rccl(m.get()));
         }
@@ -643,7 +731,7 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
     // on that stream, and a legacy-stream memset would try to join the capture.
     std::lock_guard<std::mutex> lock(m->mu);
     c->seq_alloc = (max_seq + 31) / 32 * 32;
-    c->v_transposed = env_int("FL_ATTN_MFMA", 1) != 0 && attn_mfma_supported(m->dtype, m->shards[0].Hs, m->shards[0].Hkvs, D.d);
+    c->v_transposed = tune(TK_ATTN_MFMA) != 0 && attn_mfma_supported(m->dtype, m->shards[0].Hs, m->shards[0].Hkvs, D.d);
     // decode attention splits S so that the K/V stream of one kv head is spread over many CUs
     // (~64 cached positions per 4-wave workgroup at full length); partials are combined in-launch
     // MFMA kernel: 128 keys (four 32-key wave steps) per workgroup; VALU kernel: 64.  One CU pulls only
@@ -657,7 +745,7 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
     int64_t ns = (int64_t)((max_seq + keys_per_wg - 1) / keys_per_wg);
     if (c->v_transposed && max_seq * (size_t)D.d * 4 <= 96 * 1024) ns = 1;
     c->nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(ns, c->v_transposed ? 48 : 64));   // (measured at S = 8192 / 16384: 32..48 splits 17.4 / 24.0 us, 64: 18.7 / 25.4)
-    c->nsplit = env_int("FL_ATTN_NSPLIT", c->nsplit);
+    if (tune(TK_ATTN_NSPLIT) >= 0) c->nsplit = tune(TK_ATTN_NSPLIT);
     {   // decode attention + o_proj in one launch when W_o's per-CU slice fits in LDS next to the attention state
         hipDeviceProp_t prop;
         FL_HIP(hipGetDeviceProperties(&prop, m->shards[0].device));
@@ -665,7 +753,7 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
         // keeps the splits few enough (a CU pulls only ~40 GB/s, so a split's K/V should stay small -- but every split
         // is a workgroup that holds no rows of W_o, and the others' LDS is full at ~156 rows)
         const int cus = prop.multiProcessorCount;
-        const int w0 = env_int("FL_AO_WAVES", 0);
+        const int w0 = tune(TK_AO_WAVES);
         c->fuse_oproj = false;
         for (int aw = w0 > 0 ? std::min(w0, 8) : 4; aw <= (w0 > 0 ? std::min(w0, 8) : 8) && !c->fuse_oproj; aw++) {
             const int ns8 = (int)std::max<int64_t>(1, (int64_t)((max_seq + 32 * aw - 1) / (32 * aw)));
@@ -682,8 +770,8 @@ int cache_create(Model *m, size_t max_seq, Cache **out) {
     }
     // short caches: attention replicated in every workgroup of the o_proj launch (k_attn_rep.hip): one launch and one dependent
     // step fewer per layer; FL_ATTN_REP=0 keeps the two launches
-    c->rep_attn = env_int("FL_ATTN_REP", 1) != 0 && m->fused_decode && c->v_transposed && !c->fuse_oproj && m->dtype == FL_DTYPE_BF16 &&
-                  attn_oproj_rep_supported(m->shards[0].Hs, m->shards[0].Hkvs, D.d, D.h, (int64_t)c->seq_alloc, env_int("FL_ATTN_REP", 1) == 2);
+    c->rep_attn = tune(TK_ATTN_REP) != 0 && m->fused_decode && c->v_transposed && !c->fuse_oproj && m->dtype == FL_DTYPE_BF16 &&
+                  attn_oproj_rep_supported(m->shards[0].Hs, m->shards[0].Hkvs, D.d, D.h, (int64_t)c->seq_alloc, tune(TK_ATTN_REP) == 2);
     c->shards.resize(m->shards.size());
     for (size_t i = 0; i < m->shards.size(); i++) {
         Shard &sh = m->shards[i]; CacheShard &cs = c->shards[i];
@@ -733,7 +821,7 @@ __global__ void set_state_kernel(StepState *st, uint32_t token, uint32_t pos, ui
 SampleState make_sampler(const fl_sampling *sp) {
     SampleState s{};
     if (!sp || !(sp->temperature >= 1e-7)) return s;
-    s.on = env_int("FL_SAMPLE_WALK", 0) ? 2 : 1;       // 2: plain one-lane walk instead of ordered_sum (cross-check)
+    s.on = tune(TK_SAMPLE_WALK) ? 2 : 1;       // 2: plain one-lane walk instead of ordered_sum (cross-check)
     s.inv_temp = (float)(1.0 / sp->temperature);
     uint64_t state = sp->seed;
     for (int i = 0; i < 8; i++) {
@@ -844,7 +932,7 @@ static int enqueue_decode_engine(Model *m, Cache *c, int64_t len_hint) {
     Shard &sh = m->shards[0]; Scratch &sc = sh.dec; CacheShard &cs = c->shards[0];
     FL_HIP(hipSetDevice(sh.device));
     Launcher L = make_launcher(m, sh);
-    static const long long timeout_ticks = (long long)env_int("FL_ENGINE_TIMEOUT_MS", 2000) * 100000ll;
+    const long long timeout_ticks = (long long)tune(TK_ENGINE_TIMEOUT_MS) * 100000ll;
     auto kv_of = [&](int64_t l, void **kc, void **vc) {
         const size_t kv_layer = (size_t)l * sh.Hkvs * c->seq_alloc * D.d * m->esize();
         *kc = (char *)cs.k + kv_layer; *vc = (char *)cs.v + kv_layer;
@@ -887,7 +975,7 @@ static int enqueue_decode_engine(Model *m, Cache *c, int64_t len_hint) {
             e.H = (int)sh.Hs; e.Hkv = (int)sh.Hkvs; e.d = (int)D.d; e.max_seq = (int)c->seq_alloc; e.max_pos = (int)D.max_pos; e.v_ld = (int)c->seq_alloc;
         } else {
             o3.W = sh.lm_head; o3.N = (int)sh.Vs; o3.norm_w = sh.norm; o3.out = ENG_OUT_LOGITS; o3.dst = sh.logits_full;
-            if (env_int("FL_ARGMAX_FUSED", 1)) { e.amax = sh.amax; sh.amax_valid = true; }
+            if (tune(TK_ARGMAX_FUSED)) { e.amax = sh.amax; sh.amax_valid = true; }
         }
         FL_TRY(launch_engine(L, e));
     }
@@ -963,7 +1051,7 @@ static int enqueue_decode_fused(Model *m, Cache *c, int64_t len_hint) {
         Launcher L = make_launcher(m, sh);
         GemvArgs a;
         a.W = sh.lm_head; a.out = lm_head_out(m, sh); a.N = (int)sh.Vs; a.K = (int)D.h; a.epi = EPI_F32; a.pro = PRO_NORM;
-        if (!m->vocab_parallel && env_int("FL_ARGMAX_FUSED", 1) && gemv_leaves_candidates(dt, a)) { a.amax = sh.amax; sh.amax_valid = true; }   // token selection reads one candidate per workgroup
+        if (!m->vocab_parallel && tune(TK_ARGMAX_FUSED) && gemv_leaves_candidates(dt, a)) { a.amax = sh.amax; sh.amax_valid = true; }   // token selection reads one candidate per workgroup
         a.x_in = sc.x_res; a.delta = sc.delta; a.norm_w = sh.norm; a.eps = D.eps; a.st = c->shards[i].st;
         FL_TRY(launch_gemv(L, dt, a));
     }
@@ -1083,7 +1171,7 @@ static int enqueue_prefill_tp_overlap(Model *m, Cache *c, int64_t T) {
 static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_scratch, int64_t len_hint) {
     for (auto &sh : m->shards) sh.amax_valid = false;                  // (set by the path whose lm_head launch leaves ArgMax candidates)
     if (T == 1 && !pre && !ids_in_scratch && m->fused_decode) return enqueue_decode_fused(m, c, len_hint);
-    if (pre && ids_in_scratch && m->tp > 1 && env_int("FL_TP_OVERLAP", 1) && T >= env_int("FL_TP_OVERLAP_MIN_T", 512) && !m->profiling &&
+    if (pre && ids_in_scratch && m->tp > 1 && tune(TK_TP_OVERLAP) && T >= tune(TK_TP_OVERLAP_MIN_T) && !m->profiling &&
         (m->tp_mode == FL_TP_MULTI_PROCESS || m->tp_mode == FL_TP_SINGLE_PROCESS))
         return enqueue_prefill_tp_overlap(m, c, T);
     const Dims &D = m->D;
@@ -1122,7 +1210,7 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             if (!norm_done) FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, l == 0 ? nullptr : sc.delta, ly.ln1, D.eps, sc.xn, sc.inv_rms, T, D.h, nslab, slab));
             norm_done = false;
             int qkv_slabs = 1;
-            static const int qkv_split = env_int("FL_QKV_SPLIT", kMaxKSplitMid);
+            const int qkv_split = tune(TK_QKV_SPLIT);
             // (Qwen2's q/k/v bias moves into the RoPE launch, which sums the slabs anyway: with the bias in the GEMM epilogue the
             // projection could not run in K slices and a mid-size prompt's QKV sat on 128x128 tiles -- T = 512: 63 us at 0.27 PFLOP/s)
             FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, nullptr, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms,
@@ -1215,7 +1303,7 @@ static int decode_step(Model *m, Cache *c, int64_t len_hint) {
     // Graphs: one shard per process (plain single GPU, or one rank of a multi-process TP group: RCCL collectives are
     // stream-ordered and capturable, every rank captures the same sequence); or all shards of a single-process group
     // whose collectives are one-shot (they synchronise through memory, so each shard's step is its own graph).
-    static const int tp_graph = env_int("FL_TP_GRAPH", 1);
+    const int tp_graph = tune(TK_TP_GRAPH);
     const size_t ns = m->shards.size();
     const bool one_shard = ns == 1 && (m->tp == 1 || (m->tp_mode == FL_TP_MULTI_PROCESS && tp_graph));
     const bool local_group = ns > 1 && m->tp_mode == FL_TP_SINGLE_PROCESS && tp_graph && m->shards[0].pc.connected &&
@@ -1293,7 +1381,7 @@ int forward(Model *m, Cache *c, const uint32_t *ids, size_t T, size_t pos, float
         FL_TRY(decode_step(m, c, (int64_t)c->len));
         c->len += 1;
     } else {
-        const int64_t chunk_max = env_int("FL_PREFILL_CHUNK", 8192);
+        const int64_t chunk_max = tune(TK_PREFILL_CHUNK);
         size_t done = 0;
         const size_t call0 = c->len;                 // the mask of every chunk is that of the single call
         while (done < T) {
@@ -1404,7 +1492,7 @@ int batch_create(Model *m, Cache *const *caches, size_t B, Batch **out) {
     b->m = m; b->B = (int)B;
     b->caches.assign(caches, caches + B);
     // B >= 3: the prefill-shaped step (separate norm / RoPE launches) with the wide projections on the LDS-DMA ring kernel
-    b->dma = B >= (size_t)env_int("FL_BATCH_DMA_MIN", 3) && gemv_dma_supported((int)B, 2 * sh.Ip, D.h, EPI_GATEUP, 0) &&
+    b->dma = B >= (size_t)tune(TK_BATCH_DMA_MIN) && gemv_dma_supported((int)B, 2 * sh.Ip, D.h, EPI_GATEUP, 0) &&
              gemv_dma_supported((int)B, D.V, D.h, EPI_F32, 0) && gemv_dma_ksplit(D.h, 0, EPI_GATEUP) == 1;
     b->nks_o = gemv_batch_ksplit((int)B, sh.Hs * D.d, D.h, EPI_F32);
     b->nks_down = gemv_batch_ksplit((int)B, sh.Ip, D.h, EPI_F32);
@@ -1430,7 +1518,7 @@ int batch_create(Model *m, Cache *const *caches, size_t B, Batch **out) {
     // B >= 7: every projection through the short-prompt GEMM with the norm and RoPE / KV append as their own small
     // launches, i.e. the prefill pipeline at T = B with per-sequence positions and caches.  Measured (Mistral-7B,
     // ms per step, unfused vs fused): B = 3 4.16 / 3.87, 4 4.21 / 3.99, 6 4.24 / 4.18, 8 4.26 / 4.38
-    b->unfused = B >= (size_t)env_int("FL_BATCH_UNFUSED_MIN", b->dma ? 3 : 7) && gemm_skinny_supported((int64_t)B, D.h, D.h) &&
+    b->unfused = B >= (size_t)(tune(TK_BATCH_UNFUSED_MIN) >= 0 ? tune(TK_BATCH_UNFUSED_MIN) : (b->dma ? 3 : 7)) && gemm_skinny_supported((int64_t)B, D.h, D.h) &&
                  gemm_skinny_supported((int64_t)B, D.h, sh.Ip);
     if (b->unfused) {
         FL_TRY(alloc_scratch(m, sh, b->sc, (int64_t)B, &b->allocs));

@@ -63,9 +63,12 @@ typedef enum fl_dtype { FL_DTYPE_F32 = 0, FL_DTYPE_BF16 = 1, FL_DTYPE_F16 = 2 } 
  *   max_position_embeddings -> 4096 llama / 32768 mistral, qwen (llama.rs:47, mistral.rs:138, qwen.rs:48)
  *   sliding_window       -> 4096 mistral, qwen; unused for llama (mistral.rs:139, qwen.rs:49)
  * head_dim is hidden_size / num_attention_heads (mistral.rs:67-76, config.rs:32-44); it is not
- * a config field in the reference and is validated, not passed.  This library supports head_dim 64 and 128 (TinyLlama;
- * Mistral-7B, Qwen2-7B and every Llama-2/3 size): anything else is FL_ERR_UNSUPPORTED at fl_model_create, and
- * hidden_size must be a multiple of 8. */
+ * a config field in the reference and is validated, not passed.  Every even head_dim up to 128 is supported, as the
+ * reference accepts them (config.rs:31-43): the kernels are built for 64 and 128 (TinyLlama; Mistral-7B, Qwen2-7B and every
+ * Llama-2/3 size) and any other value -- 48, 80, 96, 100 (OpenLLaMA-3B) ... -- runs as the next of the two, with zero
+ * weight rows between the halves of every head (fl_model_info.head_dim still reports the model's).  REFUSED with
+ * FL_ERR_UNSUPPORTED at fl_model_create: head_dim above 128, and hidden_size that is not a multiple of 8; an odd
+ * head_dim is FL_ERR_BAD_CONFIG, as in the reference. */
 typedef struct fl_config {
     int32_t family;                 /* fl_family */
     int32_t qkv_bias;               /* 1 for Qwen2 (q/k/v_proj.bias tensors), else 0 */

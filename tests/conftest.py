@@ -39,3 +39,44 @@ def pytest_collection_finish(session):
             torch.cuda.is_available()
         except Exception:
             pass
+
+
+@pytest.fixture(autouse=True)
+def _fl_switches_follow_the_environment(monkeypatch):
+    """The product library reads its FL_<NAME> switches from the environment ONCE (no per-launch getenv); a test that changes one
+    through monkeypatch gets it re-read at once, and every test starts from the environment as it stands (the previous test's
+    changes were undone by then)."""
+    def reload():
+        import fastllm_amd
+        if fastllm_amd.library_loaded():
+            fastllm_amd.reload_env()
+    reload()
+    orig_set, orig_del = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, *a, **k):
+        orig_set(name, value, *a, **k)
+        if name.startswith("FL_"):
+            reload()
+
+    def delenv(name, *a, **k):
+        orig_del(name, *a, **k)
+        if name.startswith("FL_"):
+            reload()
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield
+
+
+def experimental_build():
+    """Is the loaded product library the EXPERIMENTAL build (make EXPERIMENTAL=1; FL_LIB_PATH=.../libfastllm_mi355x_exp.so)?  The kernels
+    that measured slower than the default path -- decode engine, fused attention + o_proj, attention prefetch workgroups, loader-wave
+    short-prompt GEMM -- are compiled into that library only; their tests skip on the default one."""
+    import fastllm_amd
+    try:
+        fastllm_amd.tune("experimental", 0)
+        return True
+    except fastllm_amd.FastLLMError:
+        return False
+
+
+needs_experimental = pytest.mark.skipif("not __import__('conftest').experimental_build()",
+                                        reason="kernel of the EXPERIMENTAL build (make -C fastllm_amd/csrc EXPERIMENTAL=1; run with FL_LIB_PATH)")

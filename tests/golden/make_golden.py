@@ -184,6 +184,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--qwen2-win":       # round 3: one new fixture, the committed ones stay byte-identical
         run_case_windowed_decode("qwen2_win", T=16, n_gen=8, ref_calls=8)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "--head-dims":       # round 4: head_dim 100 / 96 / 48 fixtures, the committed ones stay byte-identical
+        run_case("llama_d100", T=8, n_gen=16)
+        run_case("qwen2_d96", T=8, n_gen=16, ref_calls=8)
+        run_case("mistral_d48", T=8, n_gen=16, ref_calls=8)
+        for n in ("llama_d100", "qwen2_d96", "mistral_d48"):
+            add_bf16(n)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--add-bf16":        # round 2: extend the committed fixtures in place
         for n in ("llama_a", "llama_mha", "mistral_a", "mistral_win", "qwen2_a"):
             add_bf16(n)

@@ -54,6 +54,19 @@ CONFIGS = {
     "llama_mha": dict(family="llama", hidden_size=128, intermediate_size=256, vocab_size=200,
                       num_hidden_layers=3, num_attention_heads=2, num_key_value_heads=None,
                       rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=512),
+    # head_dim that is not 64 / 128 (the reference takes any even value, config.rs:31-43): 100 (not a multiple of 8; OpenLLaMA-3B's),
+    # 96 with GQA 3 + q/k/v bias, 48 (below 64).  The library runs them padded to 128 / 128 / 64 (model.hip, resolve_config).
+    "llama_d100": dict(family="llama", hidden_size=400, intermediate_size=352, vocab_size=256,
+                       num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                       rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=512),
+    "qwen2_d96": dict(family="qwen2", hidden_size=576, intermediate_size=512, vocab_size=300,
+                      num_hidden_layers=2, num_attention_heads=6, num_key_value_heads=2,
+                      rms_norm_eps=1e-6, rope_theta=1000000.0, max_position_embeddings=512,
+                      sliding_window=4096, qkv_bias=1),
+    "mistral_d48": dict(family="mistral", hidden_size=192, intermediate_size=256, vocab_size=320,
+                        num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                        rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=512,
+                        sliding_window=4096),
     # enough kv heads for a 4-way tensor-parallel group (no golden fixture: TP tests only)
     "llama_tp4": dict(family="llama", hidden_size=512, intermediate_size=1024, vocab_size=512,
                       num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=4,

@@ -111,24 +111,25 @@ def test_no_instruction_touches_a_dot_result_too_early(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump of the ROCm toolchain not found")
-def test_four_wave_gemm_owns_its_accumulator_registers(tmp_path):
-    """k_gemm_8p.hip's gemm_4w_kernel keeps its 64 accumulator tiles in a[0:255] through inline asm; hipcc does not know.
-    The shipped code must therefore hold no scratch access (a spill could land in those registers' shadow), no compiler copy
-    INTO an accumulator register (v_accvgpr_write from a VGPR, v_accvgpr_mov), and every read of the accumulators after an MFMA
-    must come behind the kernel's own s_nop padding (>= 16 wait states: the 4-pass MFMA's result latency)."""
+@pytest.mark.parametrize("kernel,min_mfma,min_found", [("gemm_4w_kernel", 2 * 256, 2), ("gemm_h4_kernel", 4 * 64, 4)])
+def test_four_wave_gemm_owns_its_accumulator_registers(tmp_path, kernel, min_mfma, min_found):
+    """k_gemm_8p.hip's gemm_4w_kernel keeps its 64 accumulator tiles in a[0:255] through inline asm (k_gemm_h4.hip's gemm_h4_kernel its
+    32 in a[0:127]); hipcc does not know.  The shipped code must therefore hold no scratch access (a spill could land in those
+    registers' shadow), no compiler copy INTO an accumulator register (v_accvgpr_write from a VGPR, v_accvgpr_mov), and every read of
+    the accumulators after an MFMA must come behind the kernel's own s_nop padding (>= 16 wait states: the 4-pass MFMA's result latency)."""
     blob = open(LIB, "rb").read()
     found = 0
     for n, co in enumerate(gfx950_code_objects(blob)):
         p = tmp_path / ("g%d.elf" % n)
         p.write_bytes(co)
         txt = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", str(p)], capture_output=True, text=True, check=True).stdout
-        if "gemm_4w_kernel" not in txt:
+        if kernel not in txt:
             continue
         func, since_mfma, nmfma, recent = None, None, 0, []
         for line in txt.splitlines():
             m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
             if m:
-                func = m.group(1) if "gemm_4w_kernel" in m.group(1) else None
+                func = m.group(1) if kernel in m.group(1) else None
                 if func:
                     found += 1
                 since_mfma = None
@@ -164,5 +165,5 @@ def test_four_wave_gemm_owns_its_accumulator_registers(tmp_path):
                     since_mfma = None                                  # the rest of this epilogue is covered
                 else:
                     since_mfma += 1
-        assert nmfma >= 2 * 256, "expected both instantiations' K loops, found %d MFMAs" % nmfma
-    assert found >= 2, "gemm_4w_kernel not found in the library"
+        assert nmfma >= min_mfma, "expected the instantiations' K loops, found %d MFMAs" % nmfma
+    assert found >= min_found, "%s not found in the library" % kernel

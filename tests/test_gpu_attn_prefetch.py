@@ -7,7 +7,9 @@ import pytest
 import synth
 from test_gpu_fullsize import pooled_weights
 
-pytestmark = pytest.mark.gpu
+from conftest import needs_experimental
+
+pytestmark = [pytest.mark.gpu, needs_experimental]
 
 
 @pytest.mark.parametrize("model,layers", [("tinyllama-1.1b", 3), ("mistral-7b", 2)])

@@ -10,7 +10,9 @@ from oracle import oracle
 from test_gpu_fullsize import close_bf16, pooled_weights
 from test_gpu_parity import check_logits
 
-pytestmark = pytest.mark.gpu
+from conftest import needs_experimental
+
+pytestmark = [pytest.mark.gpu, needs_experimental]
 
 
 @pytest.fixture()

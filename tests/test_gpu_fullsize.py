@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import synth
+from conftest import experimental_build
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -107,6 +108,8 @@ def test_fullsize_kv_cache_equivalence_and_determinism(tiny):
 def test_fullsize_variant_paths_agree(tiny, env, monkeypatch):
     """fused + hipGraph + MFMA attention (default) vs the unfused / eager / VALU-attention variants."""
     fa, cfg, w = tiny
+    if "FL_FUSE_OPROJ" in env and not experimental_build():
+        pytest.skip("fused attention + o_proj: EXPERIMENTAL build only")
     ids = synth.prompt_ids(cfg, 40, seed=6)
     ref = fa.Model(cfg, w, dtype="bf16")
     rc = ref.new_cache(128)

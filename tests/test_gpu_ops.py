@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 import synth
+from conftest import experimental_build
 
 pytestmark = pytest.mark.gpu
 
@@ -148,6 +149,8 @@ def test_8phase_kernel_is_race_free_over_repeats(fa, monkeypatch, four):
                                             (256, 1408, 1024, 1, False)])
 @pytest.mark.parametrize("loaders", [0, 1])      # 1: the staging moved to dedicated loader waves (64 / 128-token workgroups)
 def test_linear_skinny_kernel(fa, monkeypatch, T, N, K, epi, bias, loaders):
+    if loaders and not experimental_build():
+        pytest.skip("loader-wave form: EXPERIMENTAL build only")
     monkeypatch.setenv("FL_SKINNY_LOADERS", str(loaders))
     x, w = _rand((T, K), 31), _rand((N if not epi else 2 * N, K), 32, 0.05)
     b = _rand((N,), 33) if bias else None

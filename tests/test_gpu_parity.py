@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import synth
+from conftest import needs_experimental
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -31,7 +32,7 @@ def check_logits(got, ref, dtype, msg=""):
         assert np.linalg.norm(got - ref) <= BF16_REL_L2 * np.linalg.norm(ref), "%s rel L2 %g" % (
             msg, np.linalg.norm(got - ref) / np.linalg.norm(ref))
 
-CASES = ["llama_a", "llama_mha", "mistral_a", "mistral_win", "qwen2_a", "qwen2_win"]
+CASES = ["llama_a", "llama_mha", "mistral_a", "mistral_win", "qwen2_a", "qwen2_win", "llama_d100", "qwen2_d96", "mistral_d48"]
 
 
 @pytest.fixture(scope="module")
@@ -194,7 +195,7 @@ def test_errors(fa):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("name,tp", [("llama_a", 2), ("mistral_a", 2), ("qwen2_a", 2), ("llama_mha", 2)])
+@pytest.mark.parametrize("name,tp", [("llama_a", 2), ("mistral_a", 2), ("qwen2_a", 2), ("llama_mha", 2), ("llama_d100", 2), ("qwen2_d96", 2)])
 def test_tensor_parallel_emulated(fa, name, tp, dtype):
     """TP=N shards (row/column split + all-reduce after o_proj / down_proj + vocab all-gather) run on
     one GPU with local collectives must reproduce TP=1 (to summation-order tolerance)."""
@@ -255,6 +256,7 @@ def test_decode_split_s_path(fa, name, dtype):
 
 
 @pytest.mark.parametrize("name", ["llama_a", "mistral_a", "qwen2_a"])
+@needs_experimental
 def test_fused_attention_oproj_launch(fa, name, monkeypatch):
     """FL_FUSE_OPROJ=1: decode attention + o_proj in one launch (W_o cut along K by kv head, slice in LDS, one word per
     kv head, bounded poll, partial vectors summed by the next norm prologue) must give the two-launch result, also
@@ -280,6 +282,7 @@ def test_fused_attention_oproj_launch(fa, name, monkeypatch):
     assert same >= 10, (got_toks, want_toks)   # bf16 split-order noise may fork the two greedy runs late
 
 
+@needs_experimental
 @pytest.mark.parametrize("cap", [600, 768, 1000])
 def test_fused_attention_oproj_mistral_width(fa, cap, monkeypatch):
     """The fused launch (opt-in) at Mistral-7B's layer shape (8 kv heads: one group of 32 workgroups per head, ~150 rows

@@ -18,7 +18,7 @@ from oracle import oracle
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["llama_a", "llama_mha", "mistral_a", "mistral_win", "qwen2_a", "qwen2_win"]
+CASES = ["llama_a", "llama_mha", "mistral_a", "mistral_win", "qwen2_a", "qwen2_win", "llama_d100", "qwen2_d96", "mistral_d48"]
 
 
 @pytest.fixture(scope="module")

@@ -13,7 +13,7 @@ import pytest
 import synth
 from oracle import oracle
 
-CASES = ["llama_a", "llama_mha", "mistral_a", "mistral_win", "qwen2_a", "qwen2_win"]
+CASES = ["llama_a", "llama_mha", "mistral_a", "mistral_win", "qwen2_a", "qwen2_win", "llama_d100", "qwen2_d96", "mistral_d48"]
 TOL = 2e-4     # fp32 vs fp32, different summation order
 
 

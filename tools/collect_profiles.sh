@@ -31,7 +31,9 @@ cd /tmp
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 $R/tools/prefill_profile.py mistral-7b 512 > /dev/null 2> $O/pmc_mfma.err || exit 1
 cd $R
 python3 tools/pmc_mfma.py $O/pmc_mfma $O/pmc_mfma_mistral_t512.json > /dev/null
-python3 tools/rocprof_gemv.py $(ls $O/prof_stats/*/*kernel_stats.csv $O/prof_stats/*kernel_stats.csv 2>/dev/null | head -1) $O/rocprof_gemv.json > /dev/null
+KS=$(ls $O/prof_stats/*/*kernel_stats.csv $O/prof_stats/*kernel_stats.csv 2>/dev/null | head -1)
+[ -n "$KS" ] || { echo "no kernel_stats.csv under $O/prof_stats: rocprof_gemv.json NOT refreshed"; exit 1; }
+python3 tools/rocprof_gemv.py "$KS" $O/rocprof_gemv.json > /dev/null || exit 1
 python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/traffic_gemv.json > /dev/null
 # keep the merged output small: the per-dispatch traces are large
 find $O -name '*kernel_trace.csv' -size +20M -delete

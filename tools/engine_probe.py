@@ -33,6 +33,7 @@ def main():
     res = {}
     for mode in ("0", "1"):
         os.environ["FL_ENGINE"] = mode
+        fa.reload_env()
         m = fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16")
         c = m.new_cache(T + K + 80)
         lg0 = m.forward(c, prompt, 0)

@@ -23,6 +23,7 @@ for T in Ts:
     for rep in range(7):
         for mode in (VA, VB) if rep % 2 == 0 else (VB, VA):
             os.environ[ENV] = mode
+            fa.reload_env()
             gm.forward_argmax(c, p, 0); c.reset()
             gm.synchronize(); t0 = time.perf_counter()
             for _ in range(3):

@@ -24,6 +24,7 @@ for r in range(reps):
         junk = torch.full((6 << 30,), float("nan"), device="cuda", dtype=torch.bfloat16)
         torch.cuda.synchronize(); del junk; torch.cuda.empty_cache()
     os.environ["FL_PREFILL_CHUNK"] = str(chunks[r % len(chunks)])
+    fa.reload_env()
     c = gm.new_cache(T + 16)
     a = gm.forward(c, p, 0)
     c.close()
