@@ -51,12 +51,107 @@ constexpr int H4_MAX_TILES = 4096;                     // tiles of one launch (w
 
 #define H4_AGPRS "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135"
 
+// ---- EPI_QKV_ROPE: the QKV projection's epilogue does what rope_kv_vec_kernel does behind a plain fp32 output -- row scale, bias,
+// rotate-half RoPE of the q and k heads, q to the activation buffer, k / v appended to the cache (v transposed for the MFMA
+// attention) -- so the fp32 QKV matrix never exists and the launch goes away (candle_nn::rotary_emb::rope, App. A.4; K5 in place).
+// A head's columns belong to ONE wave: d = 128: the wave's 128 columns = n half 0 | n half 1 (blocks b and b + 4: one owner for 1,
+// 2 or 4 slices); d = 64: one n half.  The accumulator layout (a lane: 4 rows x one column per 16-column block) would make 2-byte
+// stores and one cos / sin load per element (measured: 16 us per launch at 512 tokens), so the wave's 16 x d part goes through a
+// wave-private LDS tile (fp32, padded rows: conflict-free both ways) and comes back ROW-major: a lane then holds 8 consecutive
+// columns of a row and their 8 partners, reads cos / sin as float4s and stores 16 bytes per half -- or, for the transposed value
+// cache, 8 consecutive tokens of one column.
+struct RopeLane {
+    const RopeEpi *ro; const float *rs_w; const float *bias;      // rs_w: LDS row scales of this wave's 64 rows
+    float *wlds;                                                   // this wave's staging tile: 16 x (128 + 4) floats
+    int T, N, t0w, lane; uint32_t pos0, len;
+};
+__device__ inline uint4v pack8(const float (&y)[8]) {
+    return uint4v{(uint32_t)float_to_bf16_bits(y[0]) | ((uint32_t)float_to_bf16_bits(y[1]) << 16), (uint32_t)float_to_bf16_bits(y[2]) | ((uint32_t)float_to_bf16_bits(y[3]) << 16),
+                  (uint32_t)float_to_bf16_bits(y[4]) | ((uint32_t)float_to_bf16_bits(y[5]) << 16), (uint32_t)float_to_bf16_bits(y[6]) | ((uint32_t)float_to_bf16_bits(y[7]) << 16)};
+}
+// rows [16 i, 16 i + 16) of a head of width D (128: lo = n half 0, hi = n half 1; 64: lo only, hi unused); col0 = the head's first column
+template <int D>
+__device__ inline void rope_head(const RopeLane &c, int i, int col0, const float4v (&lo)[4], const float4v (&hi)[4]) {
+    constexpr int HALF = D / 2, LD = D + 4, CH = HALF / 8;        // CH: 8-column chunks per half row
+    const RopeEpi &ro = *c.ro;
+    if (col0 >= c.N) return;                                       // (wave-uniform: N is a multiple of the head width)
+    float *w = c.wlds;
+    {
+        const int cn = c.lane & 15, rg0 = ((c.lane >> 4) & 3) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) {
+                w[(rg0 + rg) * LD + j * 16 + cn] = lo[j][rg];
+                if (D == 128) w[(rg0 + rg) * LD + 64 + j * 16 + cn] = hi[j][rg];
+            }
+    }
+    asm volatile("" ::: "memory");                                 // (one wave, in-order LDS: the tile is complete for the reads below)
+    const int hd = col0 / D, tb = c.t0w + i * 16;
+    const bool rot = hd < ro.H + ro.Hkv;
+    if (rot || !ro.v_transposed) {
+        // q / k (rotated) or a row-major value cache: 16 rows x CH chunks of 8 (column, partner) pairs
+#pragma unroll
+        for (int u = 0; u < (16 * CH + 63) / 64; u++) {
+            const int item = c.lane + 64 * u, row = item / CH, c8 = (item % CH) * 8, t = tb + row;
+            if (item >= 16 * CH) break;
+            const float rs = c.rs_w[i * 16 + row];
+            float x0[8], x1[8], cs[8], sn[8], y0[8], y1[8];
+            *reinterpret_cast<float4v *>(x0) = *reinterpret_cast<const float4v *>(w + row * LD + c8);
+            *reinterpret_cast<float4v *>(x0 + 4) = *reinterpret_cast<const float4v *>(w + row * LD + c8 + 4);
+            *reinterpret_cast<float4v *>(x1) = *reinterpret_cast<const float4v *>(w + row * LD + HALF + c8);
+            *reinterpret_cast<float4v *>(x1 + 4) = *reinterpret_cast<const float4v *>(w + row * LD + HALF + c8 + 4);
+            if (rot) {
+                const uint32_t pos = c.pos0 + (uint32_t)t, p = pos < (uint32_t)ro.max_pos ? pos : (uint32_t)ro.max_pos - 1;   // host validates range
+                const float *ct = ro.cos_tab + (size_t)p * HALF + c8, *st = ro.sin_tab + (size_t)p * HALF + c8;
+                *reinterpret_cast<float4v *>(cs) = *reinterpret_cast<const float4v *>(ct); *reinterpret_cast<float4v *>(cs + 4) = *reinterpret_cast<const float4v *>(ct + 4);
+                *reinterpret_cast<float4v *>(sn) = *reinterpret_cast<const float4v *>(st); *reinterpret_cast<float4v *>(sn + 4) = *reinterpret_cast<const float4v *>(st + 4);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float a = x0[e] * rs + (c.bias ? c.bias[col0 + c8 + e] : 0.f), b = x1[e] * rs + (c.bias ? c.bias[col0 + HALF + c8 + e] : 0.f);
+                if (rot) rope_rotate(a, b, cs[e], sn[e], y0[e], y1[e]);
+                else { y0[e] = a; y1[e] = b; }
+            }
+            if (t < c.T) {
+                bf16_t *o = hd < ro.H ? reinterpret_cast<bf16_t *>(ro.q_out) + ((size_t)t * ro.H + hd) * D
+                          : hd < ro.H + ro.Hkv ? reinterpret_cast<bf16_t *>(ro.k_cache) + ((size_t)(hd - ro.H) * ro.max_seq + c.len + t) * D
+                                               : reinterpret_cast<bf16_t *>(ro.v_cache) + ((size_t)(hd - ro.H - ro.Hkv) * ro.max_seq + c.len + t) * D;
+                *reinterpret_cast<uint4v *>(o + c8) = pack8(y0);
+                *reinterpret_cast<uint4v *>(o + HALF + c8) = pack8(y1);
+            }
+        }
+    } else {
+        // transposed value cache [Hkv][D][max_seq]: a lane takes one column and 8 consecutive tokens
+        const int hv = hd - ro.H - ro.Hkv;
+#pragma unroll
+        for (int u = 0; u < (2 * D) / 64; u++) {
+            const int item = c.lane + 64 * u, col = item >> 1, r8 = (item & 1) * 8, t = tb + r8;
+            const float bcol = c.bias ? c.bias[col0 + col] : 0.f;
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) y[e] = w[(r8 + e) * LD + col] * c.rs_w[i * 16 + r8 + e] + bcol;
+            bf16_t *o = reinterpret_cast<bf16_t *>(ro.v_cache) + ((size_t)hv * D + col) * ro.max_seq + c.len + t;
+            if (t + 7 < c.T && ((c.len + t) & 7) == 0) {
+                *reinterpret_cast<uint4v *>(o) = pack8(y);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    if (t + e < c.T) o[e] = float_to_bf16_bits(y[e]);
+            }
+        }
+    }
+    asm volatile("" ::: "memory");                                 // (the next call rewrites the tile behind these reads: in-order LDS)
+}
+__device__ inline void rope_rows128(const RopeLane &c, int i, int colw, const float4v (&lo)[4], const float4v (&hi)[4]) { rope_head<128>(c, i, colw, lo, hi); }
+__device__ inline void rope_rows64(const RopeLane &c, int i, int colh, const float4v (&v)[4]) { rope_head<64>(c, i, colh, v, v); }
+
 template <int S>
 __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
                                                       const float *__restrict__ bias, void *__restrict__ out,
                                                       int T, int N, int K, int epi, int tiles_m, int tiles_n,
                                                       const float *__restrict__ row_scale, int ldc,
-                                                      H4Space ws, ResidEpi re, int group_m, int pf_mode, int set, int wait_ticks, unsigned long long *stamps) {
+                                                      H4Space ws, ResidEpi re, RopeEpi ro, int group_m, int pf_mode, int set, int wait_ticks, unsigned long long *stamps) {
     constexpr int ksplit = S;
     const int pf_dist = pf_mode & 255;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [slot][A B0 B1]
@@ -255,8 +350,21 @@ __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__
     if (tid_e < H4_BM) rs_lds[tid_e] = row_scale ? row_scale[min(m0 + tid_e, T - 1)] : 1.0f;
     const bool whole = m0 + H4_BM <= T && n0 + H4_BN <= N;
 
+    RopeLane rl{&ro, rs_lds + wr * 64, bias, reinterpret_cast<float *>(lds + 4096) + (tid_e >> 6) * (16 * 132), T, N, m0 + wr * 64, tid_e & 63, 0u, 0u};
+    if (ro.on) { rl.pos0 = ro.st->pos; rl.len = ro.st->len; }
+    const int colw = n0 + wn * 128;                                     // first column of this wave's 128
     if constexpr (S == 1) {
         __syncthreads();
+        if (ro.on) {
+            w4_for<4>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const float4v lo[4] = {w4_read<16 * i>(), w4_read<16 * i + 4>(), w4_read<16 * i + 8>(), w4_read<16 * i + 12>()};
+                const float4v hi[4] = {w4_read<16 * (4 + i)>(), w4_read<16 * (4 + i) + 4>(), w4_read<16 * (4 + i) + 8>(), w4_read<16 * (4 + i) + 12>()};
+                if (ro.d == 128) rope_rows128(rl, i, colw, lo, hi);
+                else { rope_rows64(rl, i, colw, lo); rope_rows64(rl, i, colw + 64, hi); }
+            });
+            return;
+        }
         w4_for<2>([&](auto hc) {
             constexpr int h = decltype(hc)::value;
             EpiCtx ctx;
@@ -376,10 +484,11 @@ __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__
                 });
         });
         stamp(6);
+        // (the sums replace the own accumulators in place: one array less -- at three slices the tail sat at the 256-VGPR limit and
+        // hipcc parked two registers in a0 / a1, which it believes free: wrong sums.  tests/test_dot_hazard.py audits the build.)
+        float4v (&vs)[NB][4] = own;
 #pragma unroll
         for (int k = 0; k < NB; k++) {
-            const int bq = kz + k * S;
-            float4v v[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 // K order: slice q is this workgroup's own (q == kz), or peer q (q < kz) / peer q - 1 (q > kz)
@@ -389,9 +498,26 @@ __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__
                     const float4v below = ld[k][q - 1][j];
                     acc += q == kz ? own[k][j] : (q < kz ? ld[k][q < S - 1 ? q : q - 1][j] : below);
                 }
-                v[j] = acc;
+                vs[k][j] = acc;
             }
-            if (bq < 8) finish(bq, v);
+        }
+        if (ro.on) {
+            // (host: 2 or 4 slices here, so that blocks b and b + 4 -- the two halves of a 128-wide head -- have one owner:
+            // own block k < NB / 2 is (n half 0, row block kz + k S), own block k + NB / 2 its partner in n half 1)
+            if constexpr (NB % 2 == 0) {
+#pragma unroll
+                for (int k = 0; k < NB / 2; k++) {
+                    const int i = kz + k * S;                                                    // < 4
+                    if (ro.d == 128) rope_rows128(rl, i, colw, vs[k], vs[k + NB / 2]);
+                    else { rope_rows64(rl, i, colw, vs[k]); rope_rows64(rl, i, colw + 64, vs[k + NB / 2]); }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                const int bq = kz + k * S;
+                if (bq < 8) finish(bq, vs[k]);
+            }
         }
         stamp(7);
         if (state != 2) return;
@@ -404,16 +530,23 @@ __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                 // (rare path: plain loads behind an acquire)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (int bq = 0; bq < 8; bq++) {
-            if (!((rest >> bq) & 1)) continue;
-            float4v v[4];
+        auto from_memory = [&](int bq, float4v (&v)[4]) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 v[j] = parts[(size_t)(bq * 4 + j) * 256];
 #pragma unroll
                 for (int sl = 1; sl < S; sl++) v[j] += parts[(size_t)sl * H4_TILE_F4 + (size_t)(bq * 4 + j) * 256];
             }
-            finish(bq, v);
+        };
+        for (int bq = 0; bq < (ro.on ? 4 : 8); bq++) {
+            if (!((rest >> bq) & 1)) continue;
+            float4v v[4];
+            from_memory(bq, v);
+            if (!ro.on) { finish(bq, v); continue; }
+            float4v v2[4];                                                  // (an owner abandons both halves of its heads: bit bq + 4 is set too)
+            from_memory(bq + 4, v2);
+            if (ro.d == 128) rope_rows128(rl, bq, colw, v, v2);
+            else { rope_rows64(rl, bq, colw, v); rope_rows64(rl, bq, colw + 64, v2); }
         }
     }
 }
@@ -473,7 +606,7 @@ bool gemm_h4_supported(int64_t T, int64_t N, int64_t K, int ksplit) {
 // Which shapes run here, and in how many K slices (0: not here).  TK_GEMM_H4 = 2 / TK_H4_SPLIT pin the choice (tests, probes).
 int gemm_h4_plan(int64_t T, int64_t N, int64_t K, int epi) {
     const int mode = tune(TK_GEMM_H4);
-    if (mode <= 0 || epi == EPI_QKV_ROPE || T <= 16) return 0;           // (T <= 16: decode batches, whose steps are captured graphs: no host-side launch state)
+    if (mode <= 0 || T <= 16) return 0;           // (T <= 16: decode batches, whose steps are captured graphs: no host-side launch state)
     const int forced = tune(TK_H4_SPLIT);
     const int64_t tiles = ((T + H4_BM - 1) / H4_BM) * ((N + H4_BN - 1) / H4_BN), nk = K / P_BK;
     int ks = forced > 0 ? forced : 1;
@@ -482,6 +615,7 @@ int gemm_h4_plan(int64_t T, int64_t N, int64_t K, int epi) {
         while (ks < H4_MAXS && tiles * (ks + 1) <= 256 && nk / (ks + 1) >= 8) ks++;
     }
     ks = (int)std::min<int64_t>(ks, std::max<int64_t>(1, nk));
+    if (epi == EPI_QKV_ROPE && ks == 3) ks = 2;                     // (the two halves of a 128-wide head need one owner: 1, 2 or 4 slices)
     if (!gemm_h4_supported(T, N, K, ks)) return 0;
     if (mode >= 2) return ks;
     // mode 1: the row-parallel projections (residual epilogue: no slabs, no rmsnorm_add launch) of prompts of 257-640 tokens, where
@@ -489,19 +623,24 @@ int gemm_h4_plan(int64_t T, int64_t N, int64_t K, int epi) {
     // (tools/tune_ab.py, ms without / with): T = 256 6.86 / 7.22, 384 9.00 / 8.55, 512 9.22 / 8.89, 768 12.52 / 13.36, 1024 14.98 / 14.94.
     const int64_t t8 = ((T + 255) / 256) * ((N + 255) / 256);
     // (Qwen2-7B 384 / 512 / 640: 0.987 / 1.000 / 0.958; TinyLlama-1.1B, N = K = 2048: 1.025 / 0.995 / 0.986 -- left where it was)
-    if (epi == EPI_RESID && T > 256 && T <= 640 && t8 < 128 && tiles * ks <= 256 && ks >= 2 && N >= 3072 && K >= 3072) return ks;
+    if ((epi == EPI_RESID || epi == EPI_QKV_ROPE) && T > 256 && T <= 640 && t8 < 128 && tiles * ks <= 256 && ks >= 2 && N >= 3072 && K >= 3072) return ks;
     return 0;
 }
 
 int launch_gemm_h4(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
-                   int epi, const float *row_scale, int ksplit, int64_t ldc, const ResidEpi *resid) {
+                   int epi, const float *row_scale, int ksplit, int64_t ldc, const ResidEpi *resid, const RopeEpi *rope) {
     if (ldc <= 0) ldc = N;
     if (!gemm_h4_supported(T, N, K, ksplit)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_h4: shape / K slices not supported");
     if ((epi == EPI_RESID) != (resid != nullptr) || (resid && (!resid->h || !resid->w || !resid->xn || !resid->part)))
         FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_h4: the residual epilogue takes its operands");
-    if (epi == EPI_QKV_ROPE) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_h4: no RoPE epilogue");
+    if ((epi == EPI_QKV_ROPE) != (rope != nullptr) ||
+        (rope && (ksplit == 3 || (rope->d != 64 && rope->d != 128) || N != (int64_t)(rope->H + 2 * rope->Hkv) * rope->d || !rope->st || !rope->cos_tab ||
+                  !rope->sin_tab || !rope->q_out || !rope->k_cache || !rope->v_cache)))
+        FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_h4: the RoPE epilogue takes its operands, head_dim 64 / 128, and 1, 2 or 4 K slices");
     if (epi == EPI_GATEUP && bias) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_h4: gate/up takes no bias");
     const ResidEpi re = resid ? *resid : ResidEpi{};
+    RopeEpi ro = rope ? *rope : RopeEpi{};
+    ro.on = rope ? 1 : 0;
     const int tiles_m = (int)((T + H4_BM - 1) / H4_BM), tiles_n = (int)((N + H4_BN - 1) / H4_BN);
     H4Space ws{nullptr, nullptr};
     int set = 0;
@@ -510,7 +649,7 @@ int launch_gemm_h4(Launcher &L, const void *W, const void *x, const float *bias,
     static_assert(H4_MAXS == 4, "one instantiation per slice count");
     FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), H4_LDS));
     char tag[32];
-    snprintf(tag, sizeof tag, "h4,%lldx%lld%s%s", (long long)N, (long long)K, ksplit > 1 ? ",sliced" : "", resid ? ",resid" : "");
+    snprintf(tag, sizeof tag, "h4,%lldx%lld%s%s", (long long)N, (long long)K, ksplit > 1 ? ",sliced" : "", resid ? ",resid" : rope ? ",rope" : "");
     Launcher LL = L; LL.tag = tag;
     // groups of four row tiles x columns: the eight tiles an XCD works on per K slice at T = 512 are 4 x 2 (four X panels, two W panels)
     const int group_m = std::max(1, std::min(tiles_m, 4));
@@ -521,7 +660,7 @@ int launch_gemm_h4(Launcher &L, const void *W, const void *x, const float *bias,
     if (stamp_path) { FL_HIP(hipMalloc((void **)&d_st, nwg * 64)); FL_HIP(hipMemsetAsync(d_st, 0, nwg * 64, L.stream)); }
     const int rc = LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, dim3((unsigned)(tiles_m * tiles_n), (unsigned)ksplit), dim3(256), H4_LDS,
                      (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, (int)ldc,
-                     ws, re, group_m, tune(TK_H4_PF), set, tune(TK_H4_WAIT_US) * 100, d_st);
+                     ws, re, ro, group_m, tune(TK_H4_PF), set, tune(TK_H4_WAIT_US) * 100, d_st);
     if (stamp_path) {
         std::vector<unsigned long long> h(nwg * 8);
         FL_HIP(hipStreamSynchronize(L.stream));

@@ -209,7 +209,17 @@ int64_t gemm_8p_workspace_bytes(hipStream_t stream);   // stream-K workspace hel
 void gemm_8p_release_stream(hipStream_t stream);   // frees the stream-K workspace of a stream that is about to be destroyed
 int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
                    int epi, const float *row_scale, int ksplit, int64_t ldc = 0, bool streamk = false, const ResidEpi *resid = nullptr);
-// 128 x 256 tile, K slices summed inside the launch by the tile's last arriver (k_gemm_h4.hip): mid-size prompts
+// EPI_QKV_ROPE (k_gemm_h4.hip): the QKV projection's epilogue applies the row scale and bias, rotates q / k and appends k / v to the
+// cache -- what launch_rope_kv does behind a plain fp32 output
+struct RopeEpi {
+    int on = 0;
+    const StepState *st = nullptr;
+    const float *cos_tab = nullptr, *sin_tab = nullptr;
+    int max_pos = 0;
+    void *q_out = nullptr, *k_cache = nullptr, *v_cache = nullptr;     // bf16: q [T][H*d]; K [Hkv][max_seq][d]; V [Hkv][d][max_seq] (transposed) or as K
+    int H = 0, Hkv = 0, d = 0, max_seq = 0, v_transposed = 0;
+};
+// 128 x 256 tile, K slices summed inside the launch (k_gemm_h4.hip): mid-size prompts
 constexpr int H4_MAXS = 4;             // K slices at most
 struct H4Space {
     float *part;                       // [tile][slice][128 x 256] fp32 partial accumulators, lane-major
@@ -218,7 +228,7 @@ struct H4Space {
 bool gemm_h4_supported(int64_t T, int64_t N, int64_t K, int ksplit);
 int gemm_h4_plan(int64_t T, int64_t N, int64_t K, int epi);   // K slices the kernel would run this shape in; 0: another kernel takes it
 int launch_gemm_h4(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
-                   int epi, const float *row_scale, int ksplit, int64_t ldc = 0, const ResidEpi *resid = nullptr);
+                   int epi, const float *row_scale, int ksplit, int64_t ldc = 0, const ResidEpi *resid = nullptr, const RopeEpi *rope = nullptr);
 int64_t gemm_h4_workspace_bytes(hipStream_t stream);
 void gemm_h4_release_stream(hipStream_t stream);   // before the owner destroys the stream
 bool gemm_skinny_supported(int64_t T, int64_t N, int64_t K);

@@ -1213,10 +1213,19 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             const int qkv_split = tune(TK_QKV_SPLIT);
             // (Qwen2's q/k/v bias moves into the RoPE launch, which sums the slabs anyway: with the bias in the GEMM epilogue the
             // projection could not run in K slices and a mid-size prompt's QKV sat on 128x128 tiles -- T = 512: 63 us at 0.27 PFLOP/s)
-            FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, nullptr, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms,
-                                 std::min(qkv_split, qkv_split_cap(T)), &qkv_slabs));
             const int64_t sa = (int64_t)c->seq_alloc;
-            FL_TRY(launch_rope_kv(L, dt, sc.qkv, cs.st, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, kc, vc, T, sh.Hs, sh.Hkvs, D.d, sa, c->v_transposed, qkv_slabs, ly.bqkv));
+            const int h4_qkv = dt == FL_DTYPE_BF16 ? gemm_h4_plan(T, nq, D.h, EPI_QKV_ROPE) : 0;
+            if (h4_qkv) {
+                // mid-size prompts: RoPE, bias and the KV append ride in the projection's epilogue (k_gemm_h4.hip): no fp32 QKV matrix
+                RopeEpi ro;
+                ro.st = cs.st; ro.cos_tab = sh.cos_tab; ro.sin_tab = sh.sin_tab; ro.max_pos = (int)D.max_pos; ro.q_out = sc.q; ro.k_cache = kc; ro.v_cache = vc;
+                ro.H = (int)sh.Hs; ro.Hkv = (int)sh.Hkvs; ro.d = (int)D.d; ro.max_seq = (int)sa; ro.v_transposed = c->v_transposed ? 1 : 0;
+                FL_TRY(launch_gemm_h4(L, ly.wqkv, sc.xn, ly.bqkv, nullptr, T, nq, D.h, EPI_QKV_ROPE, sc.inv_rms, h4_qkv, nq, nullptr, &ro));
+            } else {
+                FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, nullptr, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms,
+                                     std::min(qkv_split, qkv_split_cap(T)), &qkv_slabs));
+                FL_TRY(launch_rope_kv(L, dt, sc.qkv, cs.st, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, kc, vc, T, sh.Hs, sh.Hkvs, D.d, sa, c->v_transposed, qkv_slabs, ly.bqkv));
+            }
             if (T == 1) {
                 AttnScratch as{cs.part_m, cs.part_l, cs.part_o, cs.counters, c->nsplit, len_hint + 1};
                 if (c->v_transposed) FL_TRY(launch_attn_decode_mfma(L, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, sa, D.scale));
