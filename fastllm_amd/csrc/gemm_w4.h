@@ -56,6 +56,17 @@ template <int A0> __device__ inline float4v w4_read() {                 // (behi
 template <int... Is, class F> __device__ inline void w4_for_impl(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, class F> __device__ inline void w4_for(F &&f) { w4_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
+// row scale of output row `row`: 1/rms from a residual epilogue's partial sums (kernels.h, RsParts), the caller's vector, or 1
+__device__ inline float row_scale_of(const float *__restrict__ row_scale, const RsParts &rsp, int row) {
+    if (rsp.part) {
+        const float4v *p = reinterpret_cast<const float4v *>(rsp.part + (size_t)row * rsp.np);
+        float ss = 0.f;
+        for (int i = 0; i < rsp.np / 4; i++) { const float4v v = p[i]; ss += v[0]; ss += v[1]; ss += v[2]; ss += v[3]; }
+        return 1.0f / sqrtf(ss * rsp.inv_h + rsp.eps);
+    }
+    return row_scale ? row_scale[row] : 1.0f;
+}
+
 // ---- epilogue of one wave's 128 x 64 block, shared by the GEMM kernel and the stream-K fix-up kernel.
 // C/D map of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.  The row scales of the tile go through LDS (one global
 // load per row, not one per accumulator row per lane); whole tiles take a path without bounds checks (the checked one spends a

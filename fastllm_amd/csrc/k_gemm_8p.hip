@@ -88,7 +88,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__
                                                       const float *__restrict__ bias, void *__restrict__ out,
                                                       int T, int N, int K, int epi, int tiles_m, int tiles_n,
                                                       const float *__restrict__ row_scale, int ksplit, int ldc,
-                                                      unsigned long long *__restrict__ stamps, StreamK sk, ResidEpi re) {
+                                                      unsigned long long *__restrict__ stamps, StreamK sk, ResidEpi re, RsParts rsp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [parity][A0 A1 B0 B1]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform values live in SGPRs)
     const int wr = wave >> 2, wc = wave & 3;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__
             void *outz = out;
             if (!SK && ksplit > 1) outz = reinterpret_cast<float *>(out) + (size_t)blockIdx.y * T * N;
             float *rs_lds = reinterpret_cast<float *>(lds);
-            if (tid_e < P_BM) rs_lds[tid_e] = row_scale ? row_scale[min(m0 + tid_e, T - 1)] : 1.0f;
+            if (tid_e < P_BM) rs_lds[tid_e] = row_scale_of(row_scale, rsp, min(m0 + tid_e, T - 1));
             __syncthreads();
             EpiCtx ctx;
             epi_ctx_init(ctx, outz, bias, rs_lds, T, N, epi, ldc, m0, n0, tn, wr, wc, tid_e, re);
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void gemm_4w_kernel(const bf16_t *__restrict__
                                                       const float *__restrict__ bias, void *__restrict__ out,
                                                       int T, int N, int K, int epi, int tiles_m, int tiles_n,
                                                       const float *__restrict__ row_scale, int ksplit, int ldc,
-                                                      StreamK sk, ResidEpi re, int group_m) {
+                                                      StreamK sk, ResidEpi re, int group_m, RsParts rsp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [parity][A0 A1 B0 B1]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wn = wave & 1;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void gemm_4w_kernel(const bf16_t *__restrict__
             void *outz = out;
             if (!SK && ksplit > 1) outz = reinterpret_cast<float *>(out) + (size_t)blockIdx.y * T * N;
             float *rs_lds = reinterpret_cast<float *>(lds);
-            rs_lds[tid_e] = row_scale ? row_scale[min(m0 + tid_e, T - 1)] : 1.0f;       // 256 threads, 256 rows
+            rs_lds[tid_e] = row_scale_of(row_scale, rsp, min(m0 + tid_e, T - 1));       // 256 threads, 256 rows
             __syncthreads();
             const bool whole = m0 + P_BM <= T && n0 + P_BN <= N;
             w4_for<2>([&](auto hc) {
@@ -543,6 +543,7 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
     const ResidEpi re = resid ? *resid : ResidEpi{};
     if (ksplit > 1 && ldc != N) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: K slices write whole slabs (ldc == N)");
     if (streamk && ksplit != 1) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: stream-K takes the whole K");
+    if (streamk && L.rsp.part) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: a stream-K launch's fix-up takes its row scales as a vector (run rms_finalize)");
     const int tiles_m = (int)((T + P_BM - 1) / P_BM), tiles_n = (int)((N + P_BN - 1) / P_BN);
     if (K % P_BK || K / P_BK / ksplit < 2) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: K must give at least two 64-wide tiles per slice");
     if (ksplit > 1 && (bias || epi != EPI_F32)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "split-K GEMM: fp32 epilogue without bias only");
@@ -593,7 +594,7 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         const int group_env = tune(TK_GEMM_GROUPM);
         group_m = std::max(1, std::min(tiles_m, group_env > 0 ? group_env : 4));   // 4: +3-4 % at T = 4096 over the 16 x 2 strip (8: +2-3, 2: +1)
         FL_TRY(LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, k4, grid, dim3(256), P_LDS, (const bf16_t *)W, (const bf16_t *)x,
-                         bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, sk, re, group_m));
+                         bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, sk, re, group_m, L.rsp));
         return fixup();
     }
     const bool stamp = env_str("FL_8P_STAMPS") != nullptr;           // diagnostics only: synchronous, appends one record per launch
@@ -605,7 +606,7 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         unsigned long long *d = nullptr;
         FL_HIP(hipMalloc(&d, nwg * 80));
         const int rc = LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, grid, dim3(512), P_LDS, (const bf16_t *)W,
-                                 (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, d, sk, re);
+                                 (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, d, sk, re, L.rsp);
         if (rc == FL_OK) FL_TRY(fixup());
         std::vector<unsigned long long> h(nwg * 10);
         FL_HIP(hipStreamSynchronize(L.stream));
@@ -622,7 +623,7 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         return rc;
     }
     FL_TRY(LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, grid, dim3(512), P_LDS, (const bf16_t *)W, (const bf16_t *)x,
-                     bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, (unsigned long long *)nullptr, sk, re));
+                     bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, (unsigned long long *)nullptr, sk, re, L.rsp));
     return fixup();
 }
 

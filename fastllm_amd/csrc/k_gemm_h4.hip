@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__
                                                       const float *__restrict__ bias, void *__restrict__ out,
                                                       int T, int N, int K, int epi, int tiles_m, int tiles_n,
                                                       const float *__restrict__ row_scale, int ldc,
-                                                      H4Space ws, ResidEpi re, RopeEpi ro, int group_m, int pf_mode, int set, int wait_ticks, unsigned long long *stamps) {
+                                                      H4Space ws, ResidEpi re, RopeEpi ro, int group_m, int pf_mode, int set, int wait_ticks, unsigned long long *stamps, RsParts rsp) {
     constexpr int ksplit = S;
     const int pf_dist = pf_mode & 255;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [slot][A B0 B1]
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__
     float *rs_lds = reinterpret_cast<float *>(lds);                     // [128] row scales
     int *flag_lds = reinterpret_cast<int *>(lds + 1024);
 
-    if (tid_e < H4_BM) rs_lds[tid_e] = row_scale ? row_scale[min(m0 + tid_e, T - 1)] : 1.0f;
+    if (tid_e < H4_BM) rs_lds[tid_e] = row_scale_of(row_scale, rsp, min(m0 + tid_e, T - 1));
     const bool whole = m0 + H4_BM <= T && n0 + H4_BN <= N;
 
     RopeLane rl{&ro, rs_lds + wr * 64, bias, reinterpret_cast<float *>(lds + 4096) + (tid_e >> 6) * (16 * 132), T, N, m0 + wr * 64, tid_e & 63, 0u, 0u};
@@ -660,7 +660,7 @@ int launch_gemm_h4(Launcher &L, const void *W, const void *x, const float *bias,
     if (stamp_path) { FL_HIP(hipMalloc((void **)&d_st, nwg * 64)); FL_HIP(hipMemsetAsync(d_st, 0, nwg * 64, L.stream)); }
     const int rc = LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, dim3((unsigned)(tiles_m * tiles_n), (unsigned)ksplit), dim3(256), H4_LDS,
                      (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, (int)ldc,
-                     ws, re, ro, group_m, tune(TK_H4_PF), set, tune(TK_H4_WAIT_US) * 100, d_st);
+                     ws, re, ro, group_m, tune(TK_H4_PF), set, tune(TK_H4_WAIT_US) * 100, d_st, L.rsp);
     if (stamp_path) {
         std::vector<unsigned long long> h(nwg * 8);
         FL_HIP(hipStreamSynchronize(L.stream));

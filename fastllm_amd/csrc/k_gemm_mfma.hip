@@ -382,6 +382,20 @@ int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bia
     return launch_gemm_mfma_impl(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit, N, true);
 }
 
+// Would the kernel launch_linear picks for this projection take its row scales from a residual epilogue's partial sums (Launcher::rsp)?
+// Mirrors launch_linear / launch_gemm_mfma: the 128 x 256 kernel, or a plain (no stream-K, no peeled tail) launch of the 256 x 256 ones.
+bool gemm_takes_rs_parts(int dtype, int64_t T, int64_t N, int64_t K, int epi, int max_split) {
+    if (dtype != FL_DTYPE_BF16 || T <= 1 || tune(TK_FORCE_GENERIC_GEMM)) return false;
+    if (gemm_h4_plan(T, N, K, epi) > 0) return true;
+    if (tune(TK_GEMM_SKINNY) && gemm_skinny_supported(T, N, K)) return false;
+    if (!gemm_mfma_supported(dtype, T, N, K)) return false;
+    const int ks = epi == EPI_F32 ? gemm_mfma_ksplit(T, N, K, epi, max_split) : 1;
+    if (ks == 1 && gemm_streamk_whole(T, N, K, epi)) return false;
+    int64_t n_main = 0;
+    if (ks == 1 && peel_plan(T, N, K, &n_main)) return false;
+    return tune(TK_GEMM_8P) >= 1 && (tune(TK_GEMM_8P) >= 2 ? (K % 64 == 0 && (K / 64) / ks >= 2) : pick_kernel(T, N, K, ks) == GK_8P);
+}
+
 // ---- residual epilogue (EPI_RESID, kernels.h): only where the 256x256 kernel takes the whole K in one launch (or a peeled
 // pair of launches): long prompts.  FL_GEMM_RESID=0 keeps the rmsnorm_add launches.
 int gemm_resid_partials(int64_t N) { return (int)((N + 255) / 256) * 4; }
@@ -427,6 +441,7 @@ static int launch_gemm_mfma_impl(Launcher &L, const void *W, const void *x, cons
     if (!use8p && kern == GK_8P) kern = cost_256(T, N, K, ksplit) < cost_128(T, N, K, ksplit) ? GK_256 : GK_128;
     if (use8p >= 2 && K % 64 == 0 && (K / 64) / ksplit >= 2 && splittable) kern = GK_8P;
     if (kern == GK_8P) return launch_gemm_8p(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit, ldc);
+    if (L.rsp.part) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_mfma: the 128-column kernels take their row scales as a vector");
     if (kern == GK_256) {
         const int tm2 = (int)((T + BM2 - 1) / BM2), tn2 = (int)((N + BN - 1) / BN);
         const size_t lds2 = 3 * (size_t)STAGE2;                     // 144 KiB

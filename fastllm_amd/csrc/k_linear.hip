@@ -106,8 +106,11 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
     if (T <= 0 || N <= 0 || K <= 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "launch_linear: bad shape");
     if (epi == EPI_GATEUP && N % 32) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gate/up matrix rows must be a multiple of 32");
     const int force_generic = tune(TK_FORCE_GENERIC_GEMM);
+    // Launcher::rsp (row scales as partial sums): only the kernels gemm_takes_rs_parts() names read it -- any other path would
+    // silently use a stale vector, so it refuses
+    auto no_parts = [&]() -> int { if (L.rsp.part) FL_FAIL(FL_ERR_BAD_ARGUMENT, "launch_linear: this kernel takes its row scales as a vector"); return FL_OK; };
     if (dtype == FL_DTYPE_BF16) {
-        if (T == 1 && gemv_supported(dtype, N, K)) return launch_gemv(L, dtype, plain_args(W, x, bias, y, N, K, epi, row_scale));
+        if (T == 1 && gemv_supported(dtype, N, K)) { FL_TRY(no_parts()); return launch_gemv(L, dtype, plain_args(W, x, bias, y, N, K, epi, row_scale)); }
         // mid-size prompts: 128 x 256 tiles, K slices summed inside the launch (k_gemm_h4.hip) -- one complete output, no slabs
         if (!force_generic && T > 1) {
             const int ks = gemm_h4_plan(T, N, K, epi);
@@ -115,6 +118,7 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
         }
         const int use_skinny = tune(TK_GEMM_SKINNY);
         if (!force_generic && use_skinny && gemm_skinny_supported(T, N, K)) {     // short prompts: a weight stream
+            FL_TRY(no_parts());
             const int ks = (n_split_out && !bias) ? gemm_skinny_ksplit(T, N, K, epi, std::min(max_split, 4)) : 1;   // (more slabs cost the summing launch more than they save here)
             if (n_split_out) *n_split_out = ks;
             return launch_gemm_skinny(L, W, x, bias, y, T, N, K, epi, row_scale, ks);
@@ -124,8 +128,10 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
             if (n_split_out) *n_split_out = ks;
             return launch_gemm_mfma(L, W, x, bias, y, T, N, K, epi, row_scale, ks);
         }
+        FL_TRY(no_parts());
         return launch_gemm_generic<bf16_t, bf16_t>(L, W, x, bias, y, T, N, K, epi, row_scale);
     }
+    FL_TRY(no_parts());
     if (dtype == FL_DTYPE_F32) {
         if (T == 1 && gemv_supported(dtype, N, K)) return launch_gemv(L, dtype, plain_args(W, x, bias, y, N, K, epi, row_scale));
         return launch_gemm_generic<float, float>(L, W, x, bias, y, T, N, K, epi, row_scale);

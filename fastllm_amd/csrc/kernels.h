@@ -15,9 +15,15 @@ const char *kernel_class_name(int kc);
 
 struct ProfRecord { int kc; double bytes, flops; hipEvent_t e0, e1; char tag[32]; };
 
+// 1/rms of the rows a residual epilogue (EPI_RESID) left, taken by the CONSUMING projection itself from the partial sums of squares
+// -- row t: 1 / sqrt(sum_i part[t][i] / h + eps), summed left to right -- instead of an rms_finalize launch in between.  Honoured by
+// the 256 x 256 kernels' plain launches and by the 128 x 256 kernel (gemm_takes_rs_parts tells); everything else ignores it.
+struct RsParts { const float *part = nullptr; int np = 0; float eps = 0.f, inv_h = 0.f; };
+
 // Launch context: the stream a kernel goes to and, while profiling, where its event pair is kept.
 struct Launcher {
     hipStream_t stream = nullptr;
+    RsParts rsp;                               // non-null part: the next projection's row scales come from these partial sums
     std::vector<ProfRecord> *prof = nullptr;   // non-null: bracket every launch with HIP events
     const char *tag = "";                      // optional sub-class label for the profile (shape, variant)
 
@@ -201,6 +207,7 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
                   int64_t T, int64_t N, int64_t K, int epi, const float *row_scale = nullptr,
                   int max_split = 1, int *n_split_out = nullptr);
 // ldc: row stride of y in elements of the FULL output width (0 = N): a launch may cover a column range of a wider matrix
+bool gemm_takes_rs_parts(int dtype, int64_t T, int64_t N, int64_t K, int epi, int max_split);   // would launch_linear's kernel for this shape honour Launcher::rsp?
 bool gemm_resid_supported(int dtype, int64_t T, int64_t N, int64_t K, int max_split);   // k_gemm_mfma.hip: would launch_gemm_resid take this shape?
 int gemm_resid_partials(int64_t N);                                                       // partial sums per row (np)
 int launch_gemm_resid(Launcher &L, const void *W, const void *x, int64_t T, int64_t N, int64_t K, const ResidEpi &re);

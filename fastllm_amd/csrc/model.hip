@@ -118,6 +118,7 @@ static const TuneEntry g_tune_table[TK_COUNT] = {
     {"qkv_split", 8},
     {"tp_graph", 1},
     {"batch_dma_min", 3},
+    {"rs_lazy", 1},
     {"batch_unfused_min", -1},
 };
 static std::atomic<int> g_tune[TK_COUNT];
@@ -1193,11 +1194,22 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
     // writes the next norm's x * w and leaves partial sums of squares (EPI_RESID) -- no delta round trip, no rmsnorm_add launch.
     const bool resid_ok = ns == 1 && m->tp == 1 && !m->shards[0].comm && dt == FL_DTYPE_BF16 && T > 128 && SC(m->shards[0]).rs_part != nullptr;
     bool norm_done = false;               // xn / inv_rms for the upcoming norm were produced by the previous projection
-    auto linear_resid = [&](Launcher &L, Shard &sh, Scratch &sc, const void *W, const void *x, int64_t K, const float *next_norm_w) -> int {
+    // consumer_takes_parts: the projection that follows takes its row scales (1/rms) straight from the partial sums (Launcher::rsp,
+    // kernels.h) -- then there is no rms_finalize launch either; rs_lazy says so until that projection is launched
+    bool rs_lazy = false;
+    auto linear_resid = [&](Launcher &L, Shard &sh, Scratch &sc, const void *W, const void *x, int64_t K, const float *next_norm_w,
+                            bool consumer_takes_parts) -> int {
         ResidEpi re;
         re.h = sc.x_res; re.w = next_norm_w; re.xn = sc.xn; re.part = sc.rs_part; re.np = gemm_resid_partials(D.h);
         FL_TRY(launch_gemm_resid(L, W, x, T, D.h, K, re));
+        // (A/B, whole prefills: Mistral-7B 384 / 512 / 640 tokens 0.987 / 0.997 / 0.999, 4096 tokens 1.011: every workgroup of a long
+        // prompt's grid sums 256 rows' partials again, the finalize launch does it once)
+        rs_lazy = consumer_takes_parts && tune(TK_RS_LAZY) != 0 && T <= 1024;
+        if (rs_lazy) return FL_OK;
         return launch_rms_finalize(L, sc.rs_part, re.np, D.eps, sc.inv_rms, T, D.h);
+    };
+    auto with_parts = [&](Launcher &L, Scratch &sc) {             // the launcher of the projection behind a lazy residual epilogue
+        if (rs_lazy) { L.rsp = RsParts{sc.rs_part, gemm_resid_partials(D.h), D.eps, 1.0f / (float)D.h}; rs_lazy = false; }
     };
     for (int64_t l = 0; l < D.L; l++) {
         for (size_t i = 0; i < ns; i++) {
@@ -1215,6 +1227,7 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             // projection could not run in K slices and a mid-size prompt's QKV sat on 128x128 tiles -- T = 512: 63 us at 0.27 PFLOP/s)
             const int64_t sa = (int64_t)c->seq_alloc;
             const int h4_qkv = dt == FL_DTYPE_BF16 ? gemm_h4_plan(T, nq, D.h, EPI_QKV_ROPE) : 0;
+            with_parts(L, sc);                                       // (the previous layer's down_proj may have left 1/rms as partial sums)
             if (h4_qkv) {
                 // mid-size prompts: RoPE, bias and the KV append ride in the projection's epilogue (k_gemm_h4.hip): no fp32 QKV matrix
                 RopeEpi ro;
@@ -1226,6 +1239,7 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
                                      std::min(qkv_split, qkv_split_cap(T)), &qkv_slabs));
                 FL_TRY(launch_rope_kv(L, dt, sc.qkv, cs.st, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, kc, vc, T, sh.Hs, sh.Hkvs, D.d, sa, c->v_transposed, qkv_slabs, ly.bqkv));
             }
+            L.rsp = RsParts{};
             if (T == 1) {
                 AttnScratch as{cs.part_m, cs.part_l, cs.part_o, cs.counters, c->nsplit, len_hint + 1};
                 if (c->v_transposed) FL_TRY(launch_attn_decode_mfma(L, sc.q, kc, vc, cs.st, sc.ao, as, sh.Hs, sh.Hkvs, D.d, sa, D.scale));
@@ -1236,7 +1250,7 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
                 FL_TRY(launch_attn_prefill(L, dt, sc.q, kc, vc, cs.st, sc.ao, T, sh.Hs, sh.Hkvs, D.d, sa, D.scale, D.window));
             }
             if (resid_ok && gemm_resid_supported(dt, T, D.h, sh.Hs * D.d, max_split)) {
-                FL_TRY(linear_resid(L, sh, sc, ly.wo, sc.ao, sh.Hs * D.d, ly.ln2));
+                FL_TRY(linear_resid(L, sh, sc, ly.wo, sc.ao, sh.Hs * D.d, ly.ln2, gemm_takes_rs_parts(dt, T, 2 * sh.Ip, D.h, EPI_GATEUP, 1)));
                 norm_done = true;
             } else {
                 FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, T, D.h, sh.Hs * D.d, EPI_F32, nullptr, max_split, &nslab));
@@ -1249,9 +1263,15 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             Launcher L = make_launcher(m, sh);
             if (!norm_done) FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, sc.delta, ly.ln2, D.eps, sc.xn, sc.inv_rms, T, D.h, nslab, slab));
             norm_done = false;
+            with_parts(L, sc);
             FL_TRY(launch_linear(L, dt, ly.wgu, sc.xn, nullptr, sc.act, T, 2 * sh.Ip, D.h, EPI_GATEUP, sc.inv_rms));
+            L.rsp = RsParts{};
             if (resid_ok && gemm_resid_supported(dt, T, D.h, sh.Ip, max_split)) {
-                FL_TRY(linear_resid(L, sh, sc, ly.wd, sc.act, sh.Ip, l + 1 < D.L ? sh.layers[l + 1].ln1 : sh.norm));
+                // (the next layer's QKV projection takes the partial sums if its kernel can; the last layer's final norm wants the vector)
+                const int64_t nq = (sh.Hs + 2 * sh.Hkvs) * D.d;
+                const bool next_takes = l + 1 < D.L && (gemm_h4_plan(T, nq, D.h, EPI_QKV_ROPE) > 0 ||
+                                                        gemm_takes_rs_parts(dt, T, nq, D.h, EPI_F32, std::min(tune(TK_QKV_SPLIT), qkv_split_cap(T))));
+                FL_TRY(linear_resid(L, sh, sc, ly.wd, sc.act, sh.Ip, l + 1 < D.L ? sh.layers[l + 1].ln1 : sh.norm, next_takes));
                 norm_done = true;
             } else {
                 FL_TRY(launch_linear(L, dt, ly.wd, sc.act, nullptr, sc.delta, T, D.h, sh.Ip, EPI_F32, nullptr, max_split, &nslab));
