@@ -328,8 +328,8 @@ def test_mid_prompt_in_launch_slices_equal_the_slab_path(env, name, T):
     ids = synth.prompt_ids(cfg, T, seed=19)
     out = {}
     try:
-        for mode in (1, 0):
-            fa.tune("gemm_h4", mode)
+        for mode in (1, 0, 2):                          # 2: the in-launch path with the rms_finalize launches kept (rs_lazy = 0)
+            fa.tune("gemm_h4", min(mode, 1)); fa.tune("rs_lazy", 0 if mode == 2 else 1)
             c = gm.new_cache(T + 8)
             gm.profile_begin()
             lg = gm.forward(c, ids, 0)
@@ -338,6 +338,13 @@ def test_mid_prompt_in_launch_slices_equal_the_slab_path(env, name, T):
             c.close()
     finally:
         fa.tune("reload_env", 0)
+    # 1/rms taken from the partial sums by the consuming projection (Launcher::rsp) against the rms_finalize launch: the same numbers
+    # up to the order a row's partial sums are added in -- a kernel that ignored the request would read a stale vector
+    assert sum(v for n, v in out[1][2].items() if "finalize" in n) == 1, out[1][2]       # (the last layer's: the final norm wants the vector)
+    assert sum(v for n, v in out[2][2].items() if "finalize" in n) == 2 * 3, out[2][2]
+    for k in (0, 1):
+        assert np.linalg.norm(out[1][k] - out[2][k]) <= 1e-2 * np.linalg.norm(out[2][k]), "lazy row scales: rel L2 %.2e" % (    # (3.6e-3 measured: a last-bit 1/rms moves bf16 roundings downstream; a stale vector is O(1))
+            np.linalg.norm(out[1][k] - out[2][k]) / np.linalg.norm(out[2][k]))
     assert not any("h4," in n for n in out[0][2]), out[0][2]
     assert sum(v for n, v in out[1][2].items() if "h4," in n and "rope" in n) == 3, out[1][2]
     assert sum(v for n, v in out[1][2].items() if "h4," in n and "resid" in n) == 2 * 3, out[1][2]
