@@ -340,7 +340,9 @@ def test_mid_prompt_in_launch_slices_equal_the_slab_path(env, name, T):
         fa.tune("reload_env", 0)
     # 1/rms taken from the partial sums by the consuming projection (Launcher::rsp) against the rms_finalize launch: the same numbers
     # up to the order a row's partial sums are added in -- a kernel that ignored the request would read a stale vector
-    assert sum(v for n, v in out[1][2].items() if "finalize" in n) == 1, out[1][2]       # (the last layer's: the final norm wants the vector)
+    # (what stays: the last layer's -- the final norm wants the vector -- and those in front of a projection whose kernel takes a
+    # vector only, e.g. Qwen2-7B's peeled gate/up with its stream-K tail)
+    assert 1 <= sum(v for n, v in out[1][2].items() if "finalize" in n) < 2 * 3, out[1][2]
     assert sum(v for n, v in out[2][2].items() if "finalize" in n) == 2 * 3, out[2][2]
     for k in (0, 1):
         assert np.linalg.norm(out[1][k] - out[2][k]) <= 1e-2 * np.linalg.norm(out[2][k]), "lazy row scales: rel L2 %.2e" % (    # (3.6e-3 measured: a last-bit 1/rms moves bf16 roundings downstream; a stale vector is O(1))
