@@ -627,6 +627,19 @@ int gemm_h4_plan(int64_t T, int64_t N, int64_t K, int epi) {
     return 0;
 }
 
+// The tail columns of a column-peeled GEMM (k_gemm_mfma.hip: whole rounds of 256 x 256 tiles + at most half a round more): instead of the
+// stream-K launch and its fix-up launch, ONE launch of this kernel when the tail's 128 x 256 tiles times 2-4 K slices fill most of the
+// chip -- any epilogue, the slices summed inside.  (Qwen2-7B: the 5120 gate/up columns past 32768 at 512 tokens 31.3 + 13.2 us as
+// stream-K + fix-up; the 512 QKV / 1024 gate/up columns at 4096 tokens 27 + 14 / 36 + 14 us.)
+int gemm_h4_tail_slices(int64_t T, int64_t N, int64_t K) {
+    if (tune(TK_GEMM_H4) <= 0 || !tune(TK_H4_TAIL) || T <= 16 || K % P_BK) return 0;
+    const int64_t tiles = ((T + H4_BM - 1) / H4_BM) * ((N + H4_BN - 1) / H4_BN), nk = K / P_BK;
+    int ks = 1;
+    while (ks < H4_MAXS && tiles * (ks + 1) <= 256 && nk / (ks + 1) >= 8) ks++;
+    if (ks < 2 || tiles * ks < 160 || !gemm_h4_supported(T, N, K, ks)) return 0;
+    return ks;
+}
+
 int launch_gemm_h4(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
                    int epi, const float *row_scale, int ksplit, int64_t ldc, const ResidEpi *resid, const RopeEpi *rope) {
     if (ldc <= 0) ldc = N;

@@ -376,6 +376,7 @@ int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bia
         const bf16_t *Wt = (const bf16_t *)W + (size_t)n_main * K;
         const float *bt = bias ? bias + n_main : nullptr;
         void *yt = (char *)y + (size_t)col_main * es_out;
+        if (const int ks = gemm_h4_tail_slices(T, n_tail, K)) return launch_gemm_h4(L, Wt, x, bt, yt, T, n_tail, K, epi, row_scale, ks, N);
         if (sk) return launch_gemm_8p(L, Wt, x, bt, yt, T, n_tail, K, epi, row_scale, 1, N, true);
         return launch_gemm_mfma_impl(L, Wt, x, bt, yt, T, n_tail, K, epi, row_scale, 1, N, false);
     }
@@ -427,6 +428,8 @@ int launch_gemm_resid(Launcher &L, const void *W, const void *x, int64_t T, int6
         FL_TRY(launch_gemm_8p(L, W, x, nullptr, nullptr, T, n_main, K, EPI_RESID, nullptr, 1, N, false, &re));
         ResidEpi rt = re;                                         // the tail's columns: same rows, later column tiles
         rt.h += n_main; rt.w += n_main; rt.xn = (bf16_t *)rt.xn + n_main; rt.part += (n_main / 256) * 4;
+        if (const int ks = gemm_h4_tail_slices(T, N - n_main, K))
+            return launch_gemm_h4(L, (const bf16_t *)W + (size_t)n_main * K, x, nullptr, nullptr, T, N - n_main, K, EPI_RESID, nullptr, ks, N, &rt);
         return launch_gemm_8p(L, (const bf16_t *)W + (size_t)n_main * K, x, nullptr, nullptr, T, N - n_main, K, EPI_RESID, nullptr, 1, N, true, &rt);
     }
     return launch_gemm_8p(L, W, x, nullptr, nullptr, T, N, K, EPI_RESID, nullptr, 1, N, false, &re);

@@ -192,7 +192,10 @@ def test_linear_dma_ring_kernel(fa, T, N, K, epi, monkeypatch):
 # column-peeled GEMM (k_gemm_mfma.hip launch_gemm_mfma): whole rounds of 256x256 tiles on the phase-interleaved kernel, the
 # remaining columns (<= a quarter round) as a second launch on smaller tiles writing its own column range of the same output
 @pytest.mark.parametrize("T,N,K,epi,bias", [(4096, 4352, 1024, 0, True), (2048, 8448, 1024, 0, False), (4096, 2176, 1024, 1, False),
-                                            (4000, 4300, 1088, 0, True)])
+                                            (4000, 4300, 1088, 0, True),
+                                            # tails that run on the 128 x 256 kernel with their K slices summed in the launch (Qwen2-7B's
+                                            # gate/up at 512 tokens, its QKV / gate/up tails at 4096): bias / SiLU gate behind the sum
+                                            (512, 37888, 1024, 0, True), (512, 18944, 1024, 1, False), (4096, 4608, 2048, 0, True)])
 def test_linear_peeled_columns(fa, T, N, K, epi, bias):
     x, w = _rand((T, K), 51), _rand((N if not epi else 2 * N, K), 52, 0.05)
     b = _rand((N,), 53) if bias else None
