@@ -169,6 +169,44 @@ def secondary_entry(torch, fa, binding, device, local_rank, name, T, gen, dtype=
         m.close()
 
 
+def traffic_live(model_name, prompt, timeout_s=240):
+    """HBM bytes per launch of the weight-streaming kernel, measured NOW: two child runs of this bench (16 decode steps, no CPU baseline,
+    no secondary legs) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, counters alone with --kernel-trace, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes -- and the guide's gfx950 corrections (tools/pmc_traffic.py: KiB units, wide reads
+    reported at half).  Children of this process (never exec); returns None if the profiler is not there or a pass fails."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic
+    out = tempfile.mkdtemp(prefix="fl_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", FL_BENCH_BATCH="0")
+    try:
+        res = {}
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, ctr.lower())
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "16", "--warmup", "4", "--model", model_name, "--prompt", str(prompt), "--no-cpu-baseline", "--no-secondary", "--no-traffic"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            if r.returncode != 0:
+                log("traffic pass %s failed (rc %d): %s" % (ctr, r.returncode, r.stderr.decode(errors="replace")[-300:]))
+                return None
+            res[ctr] = pmc_traffic.per_kernel(d, ctr, "gemv_kernel")
+        (nf, fetch), (nw, write) = res["FETCH_SIZE"], res["WRITE_SIZE"]
+        if not nf or not nw:
+            return None
+        rd, wr = 2.0 * 1024.0 * fetch / nf, 1024.0 * write / nw
+        return {"hbm_bytes_per_launch": rd + wr, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "launches": nf}
+    except Exception as e:                                   # noqa: the headline must not depend on the profiler
+        log("live traffic measurement failed: %r" % (e,))
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` run directly: start `python -m torch.distributed.run --nproc-per-node N bench.py ...`
     as a CHILD process (never exec: under `rocprofv3 -- python3 bench.py` the profiler has already initialised the GPU
@@ -216,6 +254,7 @@ def main():
     ap.add_argument("--prompt", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other single-GPU configs and the fp32-mode figure")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 PMC passes behind roofline.traffic")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -557,8 +596,17 @@ def main():
             # only comparable when the workload is the one they were collected on
             traffic, tsrc = None, None
             import glob
+            live = None
+            if world == 1 and not args.no_traffic and os.environ.get("FL_BENCH_TRAFFIC", "1") == "1":
+                t0 = time.perf_counter()
+                live = traffic_live(args.model, T)
+                log("live HBM traffic passes: %s (%.1fs)" % ("%.1f MB per GEMV launch" % (live["hbm_bytes_per_launch"] / 1e6) if live else "not available", time.perf_counter() - t0))
             tfs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "traffic_gemv.json")))      # newest round's PMC passes
-            if tfs and args.model == "mistral-7b" and world == 1:
+            if live:
+                traffic = round(live["hbm_bytes_per_launch"])
+                tsrc = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this bench as child processes (16 decode steps each, "
+                        "%d launches; separate passes, gfx950 x2 read correction)" % live["launches"])
+            elif tfs and args.model == "mistral-7b" and world == 1:
                 tj = json.load(open(tfs[-1]))
                 traffic = round(tj["hbm_bytes_per_launch"])
                 tsrc = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, separate runs, gfx950 x2 read correction)" % os.path.relpath(tfs[-1], ROOT)
