@@ -180,6 +180,11 @@ def traffic_live(model_name, prompt, timeout_s=240):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
+    # never under a profiler already: its preloaded tool library initialises the GPU in every process it starts, and the inner
+    # profiler's launcher would then replace itself (exec) with that state -- the boxes refuse exactly that
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        log("live HBM traffic passes skipped: this process already runs under a profiler")
+        return None
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_traffic
     out = tempfile.mkdtemp(prefix="fl_traffic_", dir="/tmp")

@@ -30,12 +30,12 @@ else
 cd $R
 timeout -k 10 600 python3 bench.py > $O/bench_mistral7b_decode.json 2> $O/bench_mistral7b.err || exit 1
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 $R/bench.py --steps 64 --no-cpu-baseline --no-secondary > $O/prof_stats_bench.json 2> $O/prof_stats.err || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 $R/bench.py --steps 64 --no-cpu-baseline --no-secondary --no-traffic > $O/prof_stats_bench.json 2> $O/prof_stats.err || exit 1
 f=$(find $O/prof_stats -name '*kernel_stats.csv' | head -1); [ -n "$f" ] || { echo "no kernel stats"; exit 1; }
 cp "$f" $O/rocprofv3_kernel_stats_mistral7b.csv
 python3 $R/tools/rocprof_gemv.py "$f" $O/rocprof_gemv.json > /dev/null || exit 1
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 16 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc_fetch.err || exit 1
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 16 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc_write.err || exit 1
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 16 --no-cpu-baseline --no-secondary --no-traffic > /dev/null 2> $O/pmc_fetch.err || exit 1
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 16 --no-cpu-baseline --no-secondary --no-traffic > /dev/null 2> $O/pmc_write.err || exit 1
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/traffic_gemv.json > /dev/null || exit 1
 fi
 find $O -name '*kernel_trace.csv' -size +4M -delete
