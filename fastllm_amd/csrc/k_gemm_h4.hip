@@ -624,6 +624,15 @@ int gemm_h4_plan(int64_t T, int64_t N, int64_t K, int epi) {
     const int64_t t8 = ((T + 255) / 256) * ((N + 255) / 256);
     // (Qwen2-7B 384 / 512 / 640: 0.987 / 1.000 / 0.958; TinyLlama-1.1B, N = K = 2048: 1.025 / 0.995 / 0.986 -- left where it was)
     if ((epi == EPI_RESID || epi == EPI_QKV_ROPE) && T > 256 && T <= 640 && t8 < 128 && tiles * ks <= 256 && ks >= 2 && N >= 3072 && K >= 3072) return ks;
+    // 129-256 tokens (one row tile of 256 x 256, two of this kernel): per projection, by how much of the chip the grid fills.  Mistral-7B
+    // at 256 tokens, us per launch, old path / this kernel: gate/up (224 tiles, no slices) 83.4 / 76.7; QKV + RoPE 29.8 + 6.5 / 32.2;
+    // o_proj + rmsnorm_add 24.9 + 6.8 / 28.0; down_proj 46.2 + 6.8 / 67.1 (128 workgroups with 56 K steps each: stays where it was).
+    if (T > 128 && T <= 256 && t8 < 128 && N >= 3072 && K >= 3072 && tiles * ks <= 256) {
+        const int64_t fill = tiles * ks;
+        if (epi == EPI_GATEUP && ks == 1 && fill >= 192) return 1;
+        if (epi == EPI_QKV_ROPE && ks >= 2 && fill >= 128) return ks;
+        if (epi == EPI_RESID && ks >= 2 && fill >= 128 && nk / ks <= 24) return ks;
+    }
     return 0;
 }
 

@@ -312,7 +312,8 @@ def test_7b_width_long_prompt_vs_candle_emulation(env, name):
     assert d <= 1.5 * e_cand + 1e-3, (d, e_cand)
 
 
-@pytest.mark.parametrize("name,T", [("mistral-7b", 512), ("mistral-7b", 300), ("qwen2-7b", 640), ("qwen2-7b", 384)])
+@pytest.mark.parametrize("name,T", [("mistral-7b", 512), ("mistral-7b", 300), ("qwen2-7b", 640), ("qwen2-7b", 384),
+                                    ("mistral-7b", 200), ("qwen2-7b", 256)])     # 129-256 tokens: gate/up (no slices), QKV and o_proj on the kernel, down_proj stays
 def test_mid_prompt_in_launch_slices_equal_the_slab_path(env, name, T):
     """257-640 tokens: the QKV projection with RoPE / bias / KV append in its epilogue and o_proj / down_proj with the residual
     epilogue, all on the 128 x 256 kernel whose K slices meet inside the launch (k_gemm_h4.hip), against the path it replaces
@@ -338,18 +339,21 @@ def test_mid_prompt_in_launch_slices_equal_the_slab_path(env, name, T):
             c.close()
     finally:
         fa.tune("reload_env", 0)
+    nres = sum(v for n, v in out[1][2].items() if "h4," in n and "resid" in n)
     # 1/rms taken from the partial sums by the consuming projection (Launcher::rsp) against the rms_finalize launch: the same numbers
     # up to the order a row's partial sums are added in -- a kernel that ignored the request would read a stale vector
     # (what stays: the last layer's -- the final norm wants the vector -- and those in front of a projection whose kernel takes a
     # vector only, e.g. Qwen2-7B's peeled gate/up with its stream-K tail)
-    assert 1 <= sum(v for n, v in out[1][2].items() if "finalize" in n) < 2 * 3, out[1][2]
-    assert sum(v for n, v in out[2][2].items() if "finalize" in n) == 2 * 3, out[2][2]
+    assert sum(v for n, v in out[1][2].items() if "finalize" in n) < max(nres, 1), out[1][2]
+    assert sum(v for n, v in out[2][2].items() if "finalize" in n) == nres, out[2][2]
     for k in (0, 1):
         assert np.linalg.norm(out[1][k] - out[2][k]) <= 1e-2 * np.linalg.norm(out[2][k]), "lazy row scales: rel L2 %.2e" % (    # (3.6e-3 measured: a last-bit 1/rms moves bf16 roundings downstream; a stale vector is O(1))
             np.linalg.norm(out[1][k] - out[2][k]) / np.linalg.norm(out[2][k]))
     assert not any("h4," in n for n in out[0][2]), out[0][2]
     assert sum(v for n, v in out[1][2].items() if "h4," in n and "rope" in n) == 3, out[1][2]
-    assert sum(v for n, v in out[1][2].items() if "h4," in n and "resid" in n) == 2 * 3, out[1][2]
+    assert (nres == 2 * 3) if T > 256 else (nres in (0, 3)), out[1][2]      # (<= 256 tokens: o_proj where its grid covers half the chip, never down_proj)
+    if T <= 256 and name == "mistral-7b":               # (Qwen2-7B's gate/up is 296 of these tiles: more than one round, it stays on 256 x 256)
+        assert sum(v for n, v in out[1][2].items() if n.startswith("gemm_mfma[h4,") and "sliced" not in n) == 3, out[1][2]     # gate/up
     assert not any("rope_kv" in n for n in out[1][2]), out[1][2]
     for k in (0, 1):
         a, b = out[1][k], out[0][k]
