@@ -624,6 +624,11 @@ int gemm_h4_plan(int64_t T, int64_t N, int64_t K, int epi) {
     const int64_t t8 = ((T + 255) / 256) * ((N + 255) / 256);
     // (Qwen2-7B 384 / 512 / 640: 0.987 / 1.000 / 0.958; TinyLlama-1.1B, N = K = 2048: 1.025 / 0.995 / 0.986 -- left where it was)
     if ((epi == EPI_RESID || epi == EPI_QKV_ROPE) && T > 256 && T <= 640 && t8 < 128 && tiles * ks <= 256 && ks >= 2 && N >= 3072 && K >= 3072) return ks;
+    // 641-1024 tokens: o_proj alone (short K: <= 32 steps per slice; down_proj's 112-step slices and the unsliced QKV lose to 256 x 256),
+    // and only where 256-row tiles would waste >= 64 rows (whole Mistral-7B prefills, with / without: 700 tokens 0.981, 896 0.959;
+    // 768 and 1024 -- multiples of 256 -- 1.002 / 1.010)
+    if (epi == EPI_RESID && T > 640 && T <= 1024 && tune(TK_H4_OPROJ_1K) && ((T + 255) / 256) * 256 - T >= 64 && t8 < 128 && ks >= 2 && tiles * ks >= 192 && tiles * ks <= 256 && nk / ks <= 32 &&
+        N >= 3072 && K >= 3072) return ks;
     // 129-256 tokens (one row tile of 256 x 256, two of this kernel): per projection, by how much of the chip the grid fills.  Mistral-7B
     // at 256 tokens, us per launch, old path / this kernel: gate/up (224 tiles, no slices) 83.4 / 76.7; QKV + RoPE 29.8 + 6.5 / 32.2;
     // o_proj + rmsnorm_add 24.9 + 6.8 / 28.0; down_proj 46.2 + 6.8 / 67.1 (128 workgroups with 56 K steps each: stays where it was).
