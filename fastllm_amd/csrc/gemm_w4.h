@@ -89,7 +89,9 @@ __device__ inline void epi_ctx_init(EpiCtx &c, void *out, const float *bias, con
     }
 }
 // rows [16 i, 16 i + 16) of the wave's block: v[j] = the accumulator tile of column block j
-template <bool CHK>
+// CHK: 0 whole tile, no bounds checks; 1 rows and columns checked; 2 rows only (a ragged last row tile of a matrix whose width is whole
+// tiles: the usual ragged case -- one compare per accumulator row instead of a branch pair per store)
+template <int CHK>
 __device__ inline void store_rows(const EpiCtx &c, int i, const float4v (&v)[4]) {
     const int T = c.T, N = c.N, ldc = c.ldc, mw = c.mw, nw = c.nw;
     const float4v rs4 = *reinterpret_cast<const float4v *>(c.rs_rows + i * 16);
@@ -100,7 +102,7 @@ __device__ inline void store_rows(const EpiCtx &c, int i, const float4v (&v)[4])
             if (CHK && mw + i * 16 + rg >= T) continue;
 #pragma unroll
             for (int j = 0; j < 4; j += 2) {
-                if (CHK && nw + j * 16 + 16 >= N) continue;                   // gate column nw + 16 j, up 16 further
+                if (CHK == 1 && nw + j * 16 + 16 >= N) continue;                   // gate column nw + 16 j, up 16 further
                 const float gt = v[j][rg] * rs4[rg], up = v[j + 1][rg] * rs4[rg];
                 // silu(g) * u: v_exp + v_rcp (1 ulp each); the result is rounded to bf16
                 const float av = gt * up * __builtin_amdgcn_rcpf(1.0f + __expf(-gt));
@@ -118,7 +120,7 @@ __device__ inline void store_rows(const EpiCtx &c, int i, const float4v (&v)[4])
         for (int rg = 0; rg < 4; rg++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const bool ok = !CHK || (mw + i * 16 + rg < T && nw + j * 16 < N);
+                const bool ok = !CHK || (mw + i * 16 + rg < T && (CHK == 2 || nw + j * 16 < N));
                 hv[rg][j] = ok ? hb[(size_t)rg * ldc + j * 16] : 0.f;
             }
 #pragma unroll
@@ -126,7 +128,7 @@ __device__ inline void store_rows(const EpiCtx &c, int i, const float4v (&v)[4])
             ss[rg] = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                if (CHK && (mw + i * 16 + rg >= T || nw + j * 16 >= N)) continue;
+                if (CHK && (mw + i * 16 + rg >= T || (CHK == 1 && nw + j * 16 >= N))) continue;
                 const float hn = hv[rg][j] + (v[j][rg] * rs4[rg] + c.bj[j]);
                 hb[(size_t)rg * ldc + j * 16] = hn;
                 xb[(size_t)rg * ldc + j * 16] = float_to_bf16_bits(hn * c.wj[j]);
@@ -147,7 +149,7 @@ __device__ inline void store_rows(const EpiCtx &c, int i, const float4v (&v)[4])
             if (CHK && mw + i * 16 + rg >= T) continue;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                if (CHK && nw + j * 16 >= N) continue;
+                if (CHK == 1 && nw + j * 16 >= N) continue;
                 ob[(size_t)rg * ldc + j * 16] = v[j][rg] * rs4[rg] + c.bj[j];
             }
         }

@@ -217,10 +217,13 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__
             epi_ctx_init(ctx, outz, bias, rs_lds, T, N, epi, ldc, m0, n0, tn, wr, wc, tid_e, re);
             if (m0 + P_BM <= T && n0 + P_BN <= N) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) store_rows<false>(ctx, i, acc[i]);
+                for (int i = 0; i < 8; i++) store_rows<0>(ctx, i, acc[i]);
+            } else if (n0 + P_BN <= N) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) store_rows<2>(ctx, i, acc[i]);
             } else {
 #pragma unroll
-                for (int i = 0; i < 8; i++) store_rows<true>(ctx, i, acc[i]);
+                for (int i = 0; i < 8; i++) store_rows<1>(ctx, i, acc[i]);
             }
         } else {
             float4v *pw = reinterpret_cast<float4v *>(sk.part + ((size_t)wid * 2 + (kt0 > 0 ? 0 : 1)) * (P_BM * P_BN)) + tid_e;
@@ -427,8 +430,9 @@ __global__ __launch_bounds__(256) void gemm_4w_kernel(const bf16_t *__restrict__
                 w4_for<8>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, a0 = 16 * (8 * h + i);
                     const float4v v[4] = {w4_read<a0>(), w4_read<a0 + 4>(), w4_read<a0 + 8>(), w4_read<a0 + 12>()};
-                    if (whole) store_rows<false>(ctx, i, v);
-                    else store_rows<true>(ctx, i, v);
+                    if (whole) store_rows<0>(ctx, i, v);
+                    else if (n0 + P_BN <= N) store_rows<2>(ctx, i, v);
+                    else store_rows<1>(ctx, i, v);
                 });
             });
         } else {
@@ -476,8 +480,9 @@ __global__ __launch_bounds__(512) void gemm_8p_fixup_kernel(const float *__restr
     }
     EpiCtx ctx;
     epi_ctx_init(ctx, out, bias, rs_lds, T, N, epi, ldc, m0, n0, tn, wr, wc, tid, re);
-    if (m0 + P_BM <= T && n0 + P_BN <= N) store_rows<false>(ctx, i, v);
-    else store_rows<true>(ctx, i, v);
+    if (m0 + P_BM <= T && n0 + P_BN <= N) store_rows<0>(ctx, i, v);
+    else if (n0 + P_BN <= N) store_rows<2>(ctx, i, v);
+    else store_rows<1>(ctx, i, v);
 }
 
 // Stream-K workspace of one stream: two partial tiles per workgroup

@@ -372,8 +372,9 @@ __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__
             w4_for<4>([&](auto ic) {
                 constexpr int i = decltype(ic)::value, a0 = 16 * (4 * h + i);
                 const float4v v[4] = {w4_read<a0>(), w4_read<a0 + 4>(), w4_read<a0 + 8>(), w4_read<a0 + 12>()};
-                if (whole) store_rows<false>(ctx, i, v);
-                else store_rows<true>(ctx, i, v);
+                if (whole) store_rows<0>(ctx, i, v);
+                else if (n0 + H4_BN <= N) store_rows<2>(ctx, i, v);
+                else store_rows<1>(ctx, i, v);
             });
         });
         return;
@@ -446,8 +447,9 @@ __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__
         auto finish = [&](int b, const float4v (&v)[4]) {
             EpiCtx ctx;
             epi_ctx_init(ctx, out, bias, rs_lds, T, N, epi, ldc, m0, n0, tn, wr, wn * 2 + (b >> 2), tid_e, re, 64);
-            if (whole) store_rows<false>(ctx, b & 3, v);
-            else store_rows<true>(ctx, b & 3, v);
+            if (whole) store_rows<0>(ctx, b & 3, v);
+            else if (n0 + H4_BN <= N) store_rows<2>(ctx, b & 3, v);
+            else store_rows<1>(ctx, b & 3, v);
         };
         // The other slices' copies of the own blocks: all requested at once, as write-through-coherent (sc1) loads -- with sc1 stores
         // on the other side, the storing waves' vmcnt(0) before their count, and this workgroup's barrier behind thread 0's poll,
