@@ -592,9 +592,18 @@ static int h4_space(hipStream_t stream, size_t tiles, H4Space *out, int *set) {
         FL_HIP(hipMalloc((void **)&sp.part, tiles * H4_BM * H4_BN * sizeof(float)));
         sp.part_tiles = tiles;
     }
-    *set = (int)(sp.launches++ & 1);
+    *set = (int)(sp.launches & 1);                                 // (advanced by h4_launched once the launch is in the stream)
     *out = H4Space{sp.part, sp.ctr};
     return FL_OK;
+}
+// the launch that took word set `launches & 1` is in the stream: the next sliced launch takes the other set.  A launch that failed
+// never ran, so it zeroed nothing: the set it would have used is still clean and is handed out again.
+static void h4_launched(hipStream_t stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(g_h4_mu);
+    auto it = g_h4_spaces.find({dev, stream});
+    if (it != g_h4_spaces.end()) it->second.launches++;
 }
 
 bool gemm_h4_supported(int64_t T, int64_t N, int64_t K, int ksplit) {
@@ -634,9 +643,12 @@ int gemm_h4_plan(int64_t T, int64_t N, int64_t K, int epi) {
     // 129-256 tokens (one row tile of 256 x 256, two of this kernel): per projection, by how much of the chip the grid fills.  Mistral-7B
     // at 256 tokens, us per launch, old path / this kernel: gate/up (224 tiles, no slices) 83.4 / 76.7; QKV + RoPE 29.8 + 6.5 / 32.2;
     // o_proj + rmsnorm_add 24.9 + 6.8 / 28.0; down_proj 46.2 + 6.8 / 67.1 (128 workgroups with 56 K steps each: stays where it was).
-    if (T > 128 && T <= 256 && t8 < 128 && N >= 3072 && K >= 3072 && tiles * ks <= 256) {
+    // ... and, at 257-640 tokens, the same per-projection rule for matrices below 3072 in N or K (TinyLlama-1.1B at 512 tokens, old path /
+    // this kernel: gate/up 44.7 / 37.7 us; QKV + RoPE 25.9 / 21.1; o_proj + rmsnorm_add 25.6 / 21.1; down_proj 33.1 / 34.3; whole prefill
+    // 3.28 -> 2.92 ms; at 384 tokens every grid is below the fill bounds and nothing changes)
+    if (T > 128 && T <= 640 && (T <= 256 || N < 3072 || K < 3072) && t8 < 128 && tiles * ks <= 256) {
         const int64_t fill = tiles * ks;
-        if (epi == EPI_GATEUP && ks == 1 && fill >= 192) return 1;
+        if (epi == EPI_GATEUP && ks == 1 && fill >= 160) return 1;
         if (epi == EPI_QKV_ROPE && ks >= 2 && fill >= 128) return ks;
         if (epi == EPI_RESID && ks >= 2 && fill >= 128 && nk / ks <= 24) return ks;
     }
@@ -690,6 +702,7 @@ int launch_gemm_h4(Launcher &L, const void *W, const void *x, const float *bias,
     const int rc = LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, dim3((unsigned)(tiles_m * tiles_n), (unsigned)ksplit), dim3(256), H4_LDS,
                      (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, (int)ldc,
                      ws, re, ro, group_m, tune(TK_H4_PF), set, tune(TK_H4_WAIT_US) * 100, d_st, L.rsp);
+    if (rc == FL_OK && ksplit > 1) h4_launched(L.stream);
     if (stamp_path) {
         std::vector<unsigned long long> h(nwg * 8);
         FL_HIP(hipStreamSynchronize(L.stream));

@@ -360,3 +360,38 @@ def test_mid_prompt_in_launch_slices_equal_the_slab_path(env, name, T):
         assert np.linalg.norm(a - b) <= 1e-2 * np.linalg.norm(b), "rel L2 %.2e" % (np.linalg.norm(a - b) / np.linalg.norm(b))
         assert oracle.argmax(a) == oracle.argmax(b)
     gm.close()
+
+
+@pytest.mark.parametrize("T", [512, 640])
+def test_mid_prompt_small_hidden_size_on_the_in_launch_kernel(env, T):
+    """TinyLlama-1.1B's widths (h = 2048, d = 64, I = 5632) at 257-640 tokens: gate/up without slices, QKV + RoPE (two 64-wide heads
+    per wave column: the d = 64 form of the RoPE epilogue), o_proj and down_proj with the residual epilogue -- against the path they
+    replace, full width, 3 layers, prefill logits and a decode step on the cache the epilogue appended to."""
+    torch, fa, bench = env
+    from fastllm_amd.configs import MODEL_CONFIGS
+    cfg = dict(MODEL_CONFIGS["tinyllama-1.1b"], num_hidden_layers=3)
+    wts = bench.synth_device_weights(torch, cfg, torch.device("cuda", 0), seed=23)
+    gm = fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16")
+    del wts
+    torch.cuda.empty_cache()
+    ids = synth.prompt_ids(cfg, T, seed=29)
+    out = {}
+    try:
+        for mode in (1, 0):
+            fa.tune("gemm_h4", mode)
+            c = gm.new_cache(T + 8)
+            gm.profile_begin()
+            lg = gm.forward(c, ids, 0)
+            names = {s["name"]: s["launches"] for s in gm.profile_end()}
+            out[mode] = (lg, gm.forward(c, ids[:1], T), names)
+            c.close()
+    finally:
+        fa.tune("reload_env", 0)
+    assert sum(v for n, v in out[1][2].items() if "h4," in n and "rope" in n) == 3, out[1][2]
+    assert sum(v for n, v in out[1][2].items() if "h4," in n and "resid" in n) >= 3, out[1][2]
+    assert not any("h4," in n for n in out[0][2]), out[0][2]
+    for k in (0, 1):
+        a, b = out[1][k], out[0][k]
+        assert np.linalg.norm(a - b) <= 1e-2 * np.linalg.norm(b), "rel L2 %.2e" % (np.linalg.norm(a - b) / np.linalg.norm(b))
+        assert oracle.argmax(a) == oracle.argmax(b)
+    gm.close()
