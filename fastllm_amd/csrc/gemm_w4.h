@@ -91,7 +91,8 @@ __device__ inline void epi_ctx_init(EpiCtx &c, void *out, const float *bias, con
 // rows [16 i, 16 i + 16) of the wave's block: v[j] = the accumulator tile of column block j
 // CHK: 0 whole tile, no bounds checks; 1 rows and columns checked; 2 rows only (a ragged last row tile of a matrix whose width is whole
 // tiles: the usual ragged case -- one compare per accumulator row instead of a branch pair per store)
-template <int CHK>
+// JMAX: column blocks of the group that exist (the fp32 and gate/up epilogues; a 224-column tile's last group is two blocks wide)
+template <int CHK, int JMAX = 4>
 __device__ inline void store_rows(const EpiCtx &c, int i, const float4v (&v)[4]) {
     const int T = c.T, N = c.N, ldc = c.ldc, mw = c.mw, nw = c.nw;
     const float4v rs4 = *reinterpret_cast<const float4v *>(c.rs_rows + i * 16);
@@ -101,7 +102,7 @@ __device__ inline void store_rows(const EpiCtx &c, int i, const float4v (&v)[4])
         for (int rg = 0; rg < 4; rg++) {
             if (CHK && mw + i * 16 + rg >= T) continue;
 #pragma unroll
-            for (int j = 0; j < 4; j += 2) {
+            for (int j = 0; j < JMAX; j += 2) {
                 if (CHK == 1 && nw + j * 16 + 16 >= N) continue;                   // gate column nw + 16 j, up 16 further
                 const float gt = v[j][rg] * rs4[rg], up = v[j + 1][rg] * rs4[rg];
                 // silu(g) * u: v_exp + v_rcp (1 ulp each); the result is rounded to bf16
@@ -148,7 +149,7 @@ __device__ inline void store_rows(const EpiCtx &c, int i, const float4v (&v)[4])
         for (int rg = 0; rg < 4; rg++) {
             if (CHK && mw + i * 16 + rg >= T) continue;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < JMAX; j++) {
                 if (CHK == 1 && nw + j * 16 >= N) continue;
                 ob[(size_t)rg * ldc + j * 16] = v[j][rg] * rs4[rg] + c.bj[j];
             }

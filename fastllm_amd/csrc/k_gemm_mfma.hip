@@ -387,7 +387,7 @@ int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bia
 // Mirrors launch_linear / launch_gemm_mfma: the 128 x 256 kernel, or a plain (no stream-K, no peeled tail) launch of the 256 x 256 ones.
 bool gemm_takes_rs_parts(int dtype, int64_t T, int64_t N, int64_t K, int epi, int max_split) {
     if (dtype != FL_DTYPE_BF16 || T <= 1 || tune(TK_FORCE_GENERIC_GEMM)) return false;
-    if (gemm_h4_plan(T, N, K, epi) > 0) return true;
+    if (gemm_h4_plan(T, N, K, epi) > 0 || gemm_w14_plan(T, N, K, epi)) return true;
     if (tune(TK_GEMM_SKINNY) && gemm_skinny_supported(T, N, K)) return false;
     if (!gemm_mfma_supported(dtype, T, N, K)) return false;
     const int ks = epi == EPI_F32 ? gemm_mfma_ksplit(T, N, K, epi, max_split) : 1;

@@ -115,6 +115,8 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
         if (!force_generic && T > 1) {
             const int ks = gemm_h4_plan(T, N, K, epi);
             if (ks > 0) return launch_gemm_h4(L, W, x, bias, y, T, N, K, epi, row_scale, ks);
+            // 224-column tiles where they fill the chip and 256-column ones do not (k_gemm_w14.hip)
+            if (gemm_w14_plan(T, N, K, epi)) return launch_gemm_w14(L, W, x, bias, y, T, N, K, epi, row_scale);
         }
         const int use_skinny = tune(TK_GEMM_SKINNY);
         if (!force_generic && use_skinny && gemm_skinny_supported(T, N, K)) {     // short prompts: a weight stream

@@ -234,6 +234,10 @@ struct H4Space {
 };
 bool gemm_h4_supported(int64_t T, int64_t N, int64_t K, int ksplit);
 int gemm_h4_plan(int64_t T, int64_t N, int64_t K, int epi);
+// 256 x 224 four-wave tile (k_gemm_w14.hip): fp32 / gate-up epilogues, N whole 224-column tiles
+bool gemm_w14_plan(int64_t T, int64_t N, int64_t K, int epi);
+int launch_gemm_w14(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
+                    int epi, const float *row_scale, int64_t ldc = 0);
 int gemm_h4_tail_slices(int64_t T, int64_t N, int64_t K);     // a peeled GEMM's tail columns on this kernel: K slices, or 0 = the stream-K launch + fix-up   // K slices the kernel would run this shape in; 0: another kernel takes it
 int launch_gemm_h4(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
                    int epi, const float *row_scale, int ksplit, int64_t ldc = 0, const ResidEpi *resid = nullptr, const RopeEpi *rope = nullptr);

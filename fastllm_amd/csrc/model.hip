@@ -45,6 +45,7 @@ int env_int(const char *name, int dflt) { const char *s = env_str(name); return 
 struct TuneEntry { const char *name; int dflt; };
 static const TuneEntry g_tune_table[TK_COUNT] = {
     {"gemm_h4", 1},
+    {"gemm_w14", 1},
     {"h4_split", 0},
     {"h4_pf", 6},
     {"h4_wait_us", 30},

@@ -111,7 +111,7 @@ def test_no_instruction_touches_a_dot_result_too_early(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump of the ROCm toolchain not found")
-@pytest.mark.parametrize("kernel,min_mfma,min_found", [("gemm_4w_kernel", 2 * 256, 2), ("gemm_h4_kernel", 4 * 64, 4)])
+@pytest.mark.parametrize("kernel,min_mfma,min_found", [("gemm_4w_kernel", 2 * 256, 2), ("gemm_h4_kernel", 4 * 64, 4), ("gemm_w14_kernel", 2 * 112, 1)])
 def test_four_wave_gemm_owns_its_accumulator_registers(tmp_path, kernel, min_mfma, min_found):
     """k_gemm_8p.hip's gemm_4w_kernel keeps its 64 accumulator tiles in a[0:255] through inline asm (k_gemm_h4.hip's gemm_h4_kernel its
     32 in a[0:127]); hipcc does not know.  The shipped code must therefore hold no scratch access (a spill could land in those

@@ -362,6 +362,41 @@ def test_mid_prompt_in_launch_slices_equal_the_slab_path(env, name, T):
     gm.close()
 
 
+@pytest.mark.parametrize("T", [512, 300, 2048])
+def test_gate_up_on_224_column_tiles_equals_the_256_column_grid(env, T):
+    """Mistral-7B's fused gate/up matrix (28672 rows = 128 tiles of 224 = 112 of 256) on the 256 x 224 kernel (k_gemm_w14.hip) where
+    that grid fills the chip: against the 256 x 256 grid, full width, 2 layers, prefill logits + a decode step.  Same K order, same
+    epilogue arithmetic, same row scales from the partial sums (Launcher::rsp): the same numbers, up to the K order of the tiles the
+    256-column grid splits between workgroups at 2048 tokens (stream-K: 3.5 rounds of the chip)."""
+    torch, fa, bench = env
+    from fastllm_amd.configs import MODEL_CONFIGS
+    cfg = dict(MODEL_CONFIGS["mistral-7b"], num_hidden_layers=2)
+    wts = bench.synth_device_weights(torch, cfg, torch.device("cuda", 0), seed=31)
+    gm = fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16")
+    del wts
+    torch.cuda.empty_cache()
+    ids = synth.prompt_ids(cfg, T, seed=37)
+    out = {}
+    try:
+        for mode in (1, 0):
+            fa.tune("gemm_w14", mode)
+            c = gm.new_cache(T + 8)
+            gm.profile_begin()
+            lg = gm.forward(c, ids, 0)
+            names = {s["name"]: s["launches"] for s in gm.profile_end()}
+            out[mode] = (lg, gm.forward(c, ids[:1], T), names)
+            c.close()
+    finally:
+        fa.tune("reload_env", 0)
+    assert sum(v for n, v in out[1][2].items() if "w14," in n) == 2, out[1][2]
+    assert not any("w14," in n for n in out[0][2]), out[0][2]
+    for k in (0, 1):
+        a, b = out[1][k], out[0][k]
+        assert np.linalg.norm(a - b) <= 1e-2 * np.linalg.norm(b), "rel L2 %.2e" % (np.linalg.norm(a - b) / np.linalg.norm(b))
+        assert oracle.argmax(a) == oracle.argmax(b)
+    gm.close()
+
+
 @pytest.mark.parametrize("T", [512, 640])
 def test_mid_prompt_small_hidden_size_on_the_in_launch_kernel(env, T):
     """TinyLlama-1.1B's widths (h = 2048, d = 64, I = 5632) at 257-640 tokens: gate/up without slices, QKV + RoPE (two 64-wide heads

@@ -284,6 +284,51 @@ def test_linear_h4_slices_meet_in_the_launch(fa, T, N, K, slices, wait_us):
         fa.tune("reload_env", 0)
 
 
+# 256 x 224 four-wave GEMM (k_gemm_w14.hip), forced on (gemm_w14 = 2): widths of whole 224-column tiles, two / odd / many K tiles,
+# ragged last row tiles.  Integer operands: any wrong fragment, column block or stale LDS half shows as a wrong integer.
+@pytest.mark.parametrize("T,N,K", [(512, 448, 128), (257, 224, 192), (300, 2240, 1024), (1024, 896, 4096), (700, 28672, 256)])
+def test_linear_w14_tiles_of_224_columns(fa, T, N, K):
+    rs = np.random.RandomState(T + N + K)
+    x = rs.randint(-3, 4, size=(T, K)).astype(np.float32)
+    w = rs.randint(-3, 4, size=(N, K)).astype(np.float32)
+    ref = (x.astype(np.float64) @ w.astype(np.float64).T).astype(np.float32)
+    xb, wb = synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w)
+    try:
+        fa.tune("gemm_h4", 0); fa.tune("gemm_w14", 2)
+        y = fa.op_linear(xb, wb, None)
+        np.testing.assert_array_equal(y, ref)
+        for _ in range(3):
+            np.testing.assert_array_equal(fa.op_linear(xb, wb, None), y)
+    finally:
+        fa.tune("reload_env", 0)
+
+
+@pytest.mark.parametrize("T,N,K,epi,bias", [(512, 448, 512, 0, True), (300, 560, 1024, 1, False), (640, 1120, 512, 1, False), (1000, 672, 320, 0, True)])
+def test_linear_w14_epilogues(fa, T, N, K, epi, bias):
+    """bias / the SiLU-gate epilogue on the 224-column tile (its last column group is two blocks wide: one gate/up pair)."""
+    x, w = _rand((T, K), 91), _rand((N if not epi else 2 * N, K), 92, 0.05)
+    b = _rand((N,), 93) if bias else None
+    xb, wb = synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w)
+    ref = _ref(synth.bf16_bits_to_f32(xb), synth.bf16_bits_to_f32(wb), b, epi)
+    try:
+        fa.tune("gemm_h4", 0); fa.tune("gemm_w14", 2)
+        y = fa.op_linear(xb, wb, b, epilogue=epi)
+        fa.tune("gemm_w14", 0)
+        y0 = fa.op_linear(xb, wb, b, epilogue=epi)
+    finally:
+        fa.tune("reload_env", 0)
+    if epi:
+        np.testing.assert_allclose(y, ref, atol=2e-3, rtol=2 ** -7)
+    else:
+        np.testing.assert_allclose(y, ref, atol=2e-5 * np.sqrt(K) + 1e-5, rtol=1e-5)
+    # same K order and the same epilogue arithmetic as the 256-column kernels: identical fp32 results (a gate/up output may differ
+    # from a kernel with another accumulation pattern by one bf16 rounding)
+    if epi:
+        np.testing.assert_allclose(y, y0, atol=1e-6, rtol=2 ** -7)
+    else:
+        np.testing.assert_array_equal(y, y0)
+
+
 @pytest.mark.parametrize("T,N,K,epi,bias", [(512, 4096, 4096, 0, True), (200, 1408, 1024, 1, False), (384, 704, 512, 1, False), (300, 1000, 1024, 0, True)])
 @pytest.mark.parametrize("slices", [1, 2, 4])
 def test_linear_h4_epilogues(fa, T, N, K, epi, bias, slices):
