@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void gemm_4w_kernel(const bf16_t *__restrict__
                                                       const float *__restrict__ bias, void *__restrict__ out,
                                                       int T, int N, int K, int epi, int tiles_m, int tiles_n,
                                                       const float *__restrict__ row_scale, int ksplit, int ldc,
-                                                      StreamK sk, ResidEpi re, int group_m, RsParts rsp) {
+                                                      StreamK sk, ResidEpi re, int group_m, RsParts rsp, RopeEpi ro) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [parity][A0 A1 B0 B1]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wn = wave & 1;
@@ -423,6 +423,21 @@ __global__ __launch_bounds__(256) void gemm_4w_kernel(const bf16_t *__restrict__
             rs_lds[tid_e] = row_scale_of(row_scale, rsp, min(m0 + tid_e, T - 1));       // 256 threads, 256 rows
             __syncthreads();
             const bool whole = m0 + P_BM <= T && n0 + P_BN <= N;
+            if (!SK && ro.on) {
+                // EPI_QKV_ROPE (gemm_w4.h): a wave's 128 columns are one head of 128 or two of 64; 16 rows at a time through the
+                // wave's own LDS staging tile (the K loop's ring is free), out as q / appended K / appended (transposed) V in bf16
+                const RopeLane rl{&ro, rs_lds + wr * 128, bias, reinterpret_cast<float *>(lds + 4096) + (tid_e >> 6) * (16 * 132), T, N, m0 + wr * 128, tid_e & 63,
+                                  ro.st->pos, ro.st->len};
+                const int colw = n0 + wn * 128;
+                w4_for<8>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    const float4v lo[4] = {w4_read<16 * i>(), w4_read<16 * i + 4>(), w4_read<16 * i + 8>(), w4_read<16 * i + 12>()};
+                    const float4v hi[4] = {w4_read<16 * (8 + i)>(), w4_read<16 * (8 + i) + 4>(), w4_read<16 * (8 + i) + 8>(), w4_read<16 * (8 + i) + 12>()};
+                    if (ro.d == 128) rope_rows128(rl, i, colw, lo, hi);
+                    else { rope_rows64(rl, i, colw, lo); rope_rows64(rl, i, colw + 64, hi); }
+                });
+                return;
+            }
             w4_for<2>([&](auto hc) {
                 constexpr int h = decltype(hc)::value;
                 EpiCtx ctx;
@@ -540,6 +555,12 @@ static int cu_count() {
     return cached[dev];
 }
 
+// does the four-wave form take this launch (the rule of the comment in launch_gemm_8p)?
+bool gemm_4w_rule(int64_t T, int64_t N, int64_t K, int64_t ksteps, bool streamk) {
+    const int four = tune(TK_GEMM_4W);
+    return four && (four > 1 || (T >= 768 && ksteps >= 10 && K >= 3072 && (streamk || N >= 3072)));
+}
+
 int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
                    int epi, const float *row_scale, int ksplit, int64_t ldc, bool streamk, const ResidEpi *resid) {
     if (ldc <= 0) ldc = N;
@@ -578,7 +599,6 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         return LF.launch(KC_GEMM_MFMA, 0.0, 0.0, gemm_8p_fixup_kernel, dim3((unsigned)(tiles_m * tiles_n * 8)), dim3(512), 0, bias, y, (int)T, (int)N,
                          (int)K, epi, tiles_m, tiles_n, row_scale, (int)ldc, (int)grid.x, sk, re, group_m);
     };
-    const int four = tune(TK_GEMM_4W);
     // the four-wave form of the same tile (same grid, workspace and fix-up).  FL_GEMM_4W: 0 never, 2 always, 1 (default) from 768
     // tokens, stream-K pieces and K slices of ten or more steps.  The rule comes from an A/B inside one process, whole prefills back
     // to back (tools/prefill_ab.py; ms, eight waves / four waves): Mistral-7B T = 512 8.75 / 8.83, 768 12.19 / 12.11, 1024 14.92 /
@@ -591,7 +611,7 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
     // 3.5-5 % at 768-2048 tokens with it on either projection; with this rule it is untouched, Mistral-7B and Qwen2-7B keep
     // their gains (768 tokens -0.6 / -3.6 %, 1024 -5.2 / -4.2 %, 4096 -7.7..-8.6 / -6.9..-7.9 %)
     const int64_t ksteps = streamk ? K / P_BK : (K / P_BK) / ksplit;
-    if (four && fits32 && !env_str("FL_8P_STAMPS") && (four > 1 || (T >= 768 && ksteps >= 10 && K >= 3072 && (streamk || N >= 3072)))) {   // (N of a peeled tail is small: stream-K pieces go by K alone)
+    if (fits32 && !env_str("FL_8P_STAMPS") && gemm_4w_rule(T, N, K, ksteps, streamk)) {   // (N of a peeled tail is small: stream-K pieces go by K alone)
         auto k4 = streamk ? gemm_4w_kernel<true> : gemm_4w_kernel<false>;
         FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(k4), P_LDS));
         snprintf(tag, sizeof tag, "4w,%lldx%lld%s%s", (long long)N, (long long)K, streamk ? ",streamK" : ksplit > 1 ? ",splitK" : "", resid ? ",resid" : "");
@@ -599,7 +619,7 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         const int group_env = tune(TK_GEMM_GROUPM);
         group_m = std::max(1, std::min(tiles_m, group_env > 0 ? group_env : 4));   // 4: +3-4 % at T = 4096 over the 16 x 2 strip (8: +2-3, 2: +1)
         FL_TRY(LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, k4, grid, dim3(256), P_LDS, (const bf16_t *)W, (const bf16_t *)x,
-                         bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, sk, re, group_m, L.rsp));
+                         bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, sk, re, group_m, L.rsp, RopeEpi{}));
         return fixup();
     }
     const bool stamp = env_str("FL_8P_STAMPS") != nullptr;           // diagnostics only: synchronous, appends one record per launch
@@ -630,6 +650,33 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
     FL_TRY(LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, grid, dim3(512), P_LDS, (const bf16_t *)W, (const bf16_t *)x,
                      bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, (unsigned long long *)nullptr, sk, re, L.rsp));
     return fixup();
+}
+
+// The QKV projection of a long prompt with EPI_QKV_ROPE on the four-wave kernel: whole K, plain tiles, no fp32 output -- the epilogue
+// writes q, the appended K and the appended V (k_gemm_h4.hip does the same for mid-size prompts and for the peeled tail columns).
+// N here is the column range this launch covers (whole heads: a multiple of 128); its heads are numbered from column 0 of W.
+bool gemm_4w_rope_supported(int64_t T, int64_t N, int64_t K) {
+    const bool fits32 = (double)std::max(T, N) * (double)K * 2.0 + (double)K * 2.0 + 8192.0 < 4294967296.0;
+    return tune(TK_GEMM_4W) >= 1 && tune(TK_GEMM_8P) >= 1 && fits32 && K % P_BK == 0 && K / P_BK >= 2 && N % 128 == 0 && T >= 1 && !env_str("FL_8P_STAMPS");
+}
+int launch_gemm_4w_rope(Launcher &L, const void *W, const void *x, const float *bias, int64_t T, int64_t N, int64_t K, const float *row_scale,
+                        const RopeEpi &rope) {
+    if (!gemm_4w_rope_supported(T, N, K)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_4w: RoPE epilogue: shape not supported");
+    if ((rope.d != 64 && rope.d != 128) || !rope.st || !rope.cos_tab || !rope.sin_tab || !rope.q_out || !rope.k_cache || !rope.v_cache)
+        FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_4w: the RoPE epilogue takes its operands, head_dim 64 / 128");
+    RopeEpi ro = rope;
+    ro.on = 1;
+    const int tiles_m = (int)((T + P_BM - 1) / P_BM), tiles_n = (int)((N + P_BN - 1) / P_BN);
+    auto k4 = gemm_4w_kernel<false>;
+    FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(k4), P_LDS));
+    char tag[32];
+    snprintf(tag, sizeof tag, "4w,%lldx%lld,rope", (long long)N, (long long)K);
+    Launcher LL = L; LL.tag = tag;
+    const int group_env = tune(TK_GEMM_GROUPM);
+    const int group_m = std::max(1, std::min(tiles_m, group_env > 0 ? group_env : 4));
+    return LL.launch(KC_GEMM_MFMA, ((double)N * K + (double)T * K) * 2.0, 2.0 * T * N * K, k4, dim3((unsigned)(tiles_m * tiles_n), 1), dim3(256), P_LDS,
+                     (const bf16_t *)W, (const bf16_t *)x, bias, (void *)nullptr, (int)T, (int)N, (int)K, (int)EPI_QKV_ROPE, tiles_m, tiles_n, row_scale, 1, (int)N,
+                     StreamK{nullptr}, ResidEpi{}, group_m, L.rsp, ro);
 }
 
 }  // namespace fl

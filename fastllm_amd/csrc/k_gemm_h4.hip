@@ -51,100 +51,7 @@ constexpr int H4_MAX_TILES = 4096;                     // tiles of one launch (w
 
 #define H4_AGPRS "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135"
 
-// ---- EPI_QKV_ROPE: the QKV projection's epilogue does what rope_kv_vec_kernel does behind a plain fp32 output -- row scale, bias,
-// rotate-half RoPE of the q and k heads, q to the activation buffer, k / v appended to the cache (v transposed for the MFMA
-// attention) -- so the fp32 QKV matrix never exists and the launch goes away (candle_nn::rotary_emb::rope, App. A.4; K5 in place).
-// A head's columns belong to ONE wave: d = 128: the wave's 128 columns = n half 0 | n half 1 (blocks b and b + 4: one owner for 1,
-// 2 or 4 slices); d = 64: one n half.  The accumulator layout (a lane: 4 rows x one column per 16-column block) would make 2-byte
-// stores and one cos / sin load per element (measured: 16 us per launch at 512 tokens), so the wave's 16 x d part goes through a
-// wave-private LDS tile (fp32, padded rows: conflict-free both ways) and comes back ROW-major: a lane then holds 8 consecutive
-// columns of a row and their 8 partners, reads cos / sin as float4s and stores 16 bytes per half -- or, for the transposed value
-// cache, 8 consecutive tokens of one column.
-struct RopeLane {
-    const RopeEpi *ro; const float *rs_w; const float *bias;      // rs_w: LDS row scales of this wave's 64 rows
-    float *wlds;                                                   // this wave's staging tile: 16 x (128 + 4) floats
-    int T, N, t0w, lane; uint32_t pos0, len;
-};
-__device__ inline uint4v pack8(const float (&y)[8]) {
-    return uint4v{(uint32_t)float_to_bf16_bits(y[0]) | ((uint32_t)float_to_bf16_bits(y[1]) << 16), (uint32_t)float_to_bf16_bits(y[2]) | ((uint32_t)float_to_bf16_bits(y[3]) << 16),
-                  (uint32_t)float_to_bf16_bits(y[4]) | ((uint32_t)float_to_bf16_bits(y[5]) << 16), (uint32_t)float_to_bf16_bits(y[6]) | ((uint32_t)float_to_bf16_bits(y[7]) << 16)};
-}
-// rows [16 i, 16 i + 16) of a head of width D (128: lo = n half 0, hi = n half 1; 64: lo only, hi unused); col0 = the head's first column
-template <int D>
-__device__ inline void rope_head(const RopeLane &c, int i, int col0, const float4v (&lo)[4], const float4v (&hi)[4]) {
-    constexpr int HALF = D / 2, LD = D + 4, CH = HALF / 8;        // CH: 8-column chunks per half row
-    const RopeEpi &ro = *c.ro;
-    if (col0 >= c.N) return;                                       // (wave-uniform: N is a multiple of the head width)
-    float *w = c.wlds;
-    {
-        const int cn = c.lane & 15, rg0 = ((c.lane >> 4) & 3) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int rg = 0; rg < 4; rg++) {
-                w[(rg0 + rg) * LD + j * 16 + cn] = lo[j][rg];
-                if (D == 128) w[(rg0 + rg) * LD + 64 + j * 16 + cn] = hi[j][rg];
-            }
-    }
-    asm volatile("" ::: "memory");                                 // (one wave, in-order LDS: the tile is complete for the reads below)
-    const int hd = col0 / D, tb = c.t0w + i * 16;
-    const bool rot = hd < ro.H + ro.Hkv;
-    if (rot || !ro.v_transposed) {
-        // q / k (rotated) or a row-major value cache: 16 rows x CH chunks of 8 (column, partner) pairs
-#pragma unroll
-        for (int u = 0; u < (16 * CH + 63) / 64; u++) {
-            const int item = c.lane + 64 * u, row = item / CH, c8 = (item % CH) * 8, t = tb + row;
-            if (item >= 16 * CH) break;
-            const float rs = c.rs_w[i * 16 + row];
-            float x0[8], x1[8], cs[8], sn[8], y0[8], y1[8];
-            *reinterpret_cast<float4v *>(x0) = *reinterpret_cast<const float4v *>(w + row * LD + c8);
-            *reinterpret_cast<float4v *>(x0 + 4) = *reinterpret_cast<const float4v *>(w + row * LD + c8 + 4);
-            *reinterpret_cast<float4v *>(x1) = *reinterpret_cast<const float4v *>(w + row * LD + HALF + c8);
-            *reinterpret_cast<float4v *>(x1 + 4) = *reinterpret_cast<const float4v *>(w + row * LD + HALF + c8 + 4);
-            if (rot) {
-                const uint32_t pos = c.pos0 + (uint32_t)t, p = pos < (uint32_t)ro.max_pos ? pos : (uint32_t)ro.max_pos - 1;   // host validates range
-                const float *ct = ro.cos_tab + (size_t)p * HALF + c8, *st = ro.sin_tab + (size_t)p * HALF + c8;
-                *reinterpret_cast<float4v *>(cs) = *reinterpret_cast<const float4v *>(ct); *reinterpret_cast<float4v *>(cs + 4) = *reinterpret_cast<const float4v *>(ct + 4);
-                *reinterpret_cast<float4v *>(sn) = *reinterpret_cast<const float4v *>(st); *reinterpret_cast<float4v *>(sn + 4) = *reinterpret_cast<const float4v *>(st + 4);
-            }
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const float a = x0[e] * rs + (c.bias ? c.bias[col0 + c8 + e] : 0.f), b = x1[e] * rs + (c.bias ? c.bias[col0 + HALF + c8 + e] : 0.f);
-                if (rot) rope_rotate(a, b, cs[e], sn[e], y0[e], y1[e]);
-                else { y0[e] = a; y1[e] = b; }
-            }
-            if (t < c.T) {
-                bf16_t *o = hd < ro.H ? reinterpret_cast<bf16_t *>(ro.q_out) + ((size_t)t * ro.H + hd) * D
-                          : hd < ro.H + ro.Hkv ? reinterpret_cast<bf16_t *>(ro.k_cache) + ((size_t)(hd - ro.H) * ro.max_seq + c.len + t) * D
-                                               : reinterpret_cast<bf16_t *>(ro.v_cache) + ((size_t)(hd - ro.H - ro.Hkv) * ro.max_seq + c.len + t) * D;
-                *reinterpret_cast<uint4v *>(o + c8) = pack8(y0);
-                *reinterpret_cast<uint4v *>(o + HALF + c8) = pack8(y1);
-            }
-        }
-    } else {
-        // transposed value cache [Hkv][D][max_seq]: a lane takes one column and 8 consecutive tokens
-        const int hv = hd - ro.H - ro.Hkv;
-#pragma unroll
-        for (int u = 0; u < (2 * D) / 64; u++) {
-            const int item = c.lane + 64 * u, col = item >> 1, r8 = (item & 1) * 8, t = tb + r8;
-            const float bcol = c.bias ? c.bias[col0 + col] : 0.f;
-            float y[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) y[e] = w[(r8 + e) * LD + col] * c.rs_w[i * 16 + r8 + e] + bcol;
-            bf16_t *o = reinterpret_cast<bf16_t *>(ro.v_cache) + ((size_t)hv * D + col) * ro.max_seq + c.len + t;
-            if (t + 7 < c.T && ((c.len + t) & 7) == 0) {
-                *reinterpret_cast<uint4v *>(o) = pack8(y);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; e++)
-                    if (t + e < c.T) o[e] = float_to_bf16_bits(y[e]);
-            }
-        }
-    }
-    asm volatile("" ::: "memory");                                 // (the next call rewrites the tile behind these reads: in-order LDS)
-}
-__device__ inline void rope_rows128(const RopeLane &c, int i, int colw, const float4v (&lo)[4], const float4v (&hi)[4]) { rope_head<128>(c, i, colw, lo, hi); }
-__device__ inline void rope_rows64(const RopeLane &c, int i, int colh, const float4v (&v)[4]) { rope_head<64>(c, i, colh, v, v); }
+// (EPI_QKV_ROPE, the RoPE / bias / KV-append epilogue: gemm_w4.h, shared with the four-wave 256 x 256 kernel)
 
 template <int S>
 __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
@@ -675,7 +582,7 @@ int launch_gemm_h4(Launcher &L, const void *W, const void *x, const float *bias,
     if ((epi == EPI_RESID) != (resid != nullptr) || (resid && (!resid->h || !resid->w || !resid->xn || !resid->part)))
         FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_h4: the residual epilogue takes its operands");
     if ((epi == EPI_QKV_ROPE) != (rope != nullptr) ||
-        (rope && (ksplit == 3 || (rope->d != 64 && rope->d != 128) || N != (int64_t)(rope->H + 2 * rope->Hkv) * rope->d || !rope->st || !rope->cos_tab ||
+        (rope && (ksplit == 3 || (rope->d != 64 && rope->d != 128) || N % rope->d || rope->col_base % 128 || rope->col_base + N > (int64_t)(rope->H + 2 * rope->Hkv) * rope->d || !rope->st || !rope->cos_tab ||
                   !rope->sin_tab || !rope->q_out || !rope->k_cache || !rope->v_cache)))
         FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_h4: the RoPE epilogue takes its operands, head_dim 64 / 128, and 1, 2 or 4 K slices");
     if (epi == EPI_GATEUP && bias) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_h4: gate/up takes no bias");

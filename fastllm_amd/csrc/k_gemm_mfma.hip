@@ -383,6 +383,38 @@ int launch_gemm_mfma(Launcher &L, const void *W, const void *x, const float *bia
     return launch_gemm_mfma_impl(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit, N, true);
 }
 
+// ---- a long prompt's QKV projection with the RoPE / bias / KV-append epilogue (EPI_QKV_ROPE) on the four-wave kernel: where launch_linear
+// would run it as ONE plain grid of 256 x 256 tiles, or as whole rounds + tail columns on the 128 x 256 kernel (1, 2 or 4 in-launch
+// slices).  K slabs and stream-K pieces keep the fp32 output and the rope_kv_append launch (which sums the slabs anyway).
+static bool qkv_rope_long_parts(int64_t T, int64_t N, int64_t K, int max_split, int64_t *n_main, int *tail_ks) {
+    *n_main = N; *tail_ks = 0;
+    if (!tune(TK_GEMM_ROPE_4W) || T < 768 || tune(TK_FORCE_GENERIC_GEMM) || tune(TK_GEMM_8P) != 1 || !gemm_mfma_supported(FL_DTYPE_BF16, T, N, K)) return false;
+    if (gemm_streamk_whole(T, N, K, EPI_F32)) return false;
+    int64_t nm = 0;
+    if (peel_plan(T, N, K, &nm)) {
+        const int ks = gemm_h4_tail_slices(T, N - nm, K);
+        if (!ks || ks == 3 || nm % 128 || (N - nm) % 128) return false;
+        *n_main = nm; *tail_ks = ks;
+    } else if (gemm_mfma_ksplit(T, N, K, EPI_F32, max_split) != 1 || pick_kernel(T, N, K, 1) != GK_8P) {
+        return false;
+    }
+    return gemm_4w_rope_supported(T, *n_main, K) && gemm_4w_rule(T, *n_main, K, K / 64, false);
+}
+bool gemm_qkv_rope_long_plan(int64_t T, int64_t N, int64_t K, int max_split) {
+    int64_t nm; int ks;
+    return qkv_rope_long_parts(T, N, K, max_split, &nm, &ks);
+}
+int launch_gemm_qkv_rope_long(Launcher &L, const void *W, const void *x, const float *bias, int64_t T, int64_t N, int64_t K, const float *row_scale,
+                              const RopeEpi &rope, int max_split) {
+    int64_t nm; int ks;
+    if (!qkv_rope_long_parts(T, N, K, max_split, &nm, &ks)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_qkv_rope_long: not planned for this shape");
+    FL_TRY(launch_gemm_4w_rope(L, W, x, bias, T, nm, K, row_scale, rope));
+    if (nm == N) return FL_OK;
+    RopeEpi rt = rope;
+    rt.col_base = (int)nm;
+    return launch_gemm_h4(L, (const bf16_t *)W + (size_t)nm * K, x, bias ? bias + nm : nullptr, nullptr, T, N - nm, K, EPI_QKV_ROPE, row_scale, ks, N - nm, nullptr, &rt);
+}
+
 // Would the kernel launch_linear picks for this projection take its row scales from a residual epilogue's partial sums (Launcher::rsp)?
 // Mirrors launch_linear / launch_gemm_mfma: the 128 x 256 kernel, or a plain (no stream-K, no peeled tail) launch of the 256 x 256 ones.
 bool gemm_takes_rs_parts(int dtype, int64_t T, int64_t N, int64_t K, int epi, int max_split) {

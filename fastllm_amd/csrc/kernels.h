@@ -225,6 +225,7 @@ struct RopeEpi {
     int max_pos = 0;
     void *q_out = nullptr, *k_cache = nullptr, *v_cache = nullptr;     // bf16: q [T][H*d]; K [Hkv][max_seq][d]; V [Hkv][d][max_seq] (transposed) or as K
     int H = 0, Hkv = 0, d = 0, max_seq = 0, v_transposed = 0;
+    int col_base = 0;                  // first column of this launch in the whole QKV matrix (a column-peeled projection's tail launch)
 };
 // 128 x 256 tile, K slices summed inside the launch (k_gemm_h4.hip): mid-size prompts
 constexpr int H4_MAXS = 4;             // K slices at most
@@ -236,6 +237,16 @@ bool gemm_h4_supported(int64_t T, int64_t N, int64_t K, int ksplit);
 int gemm_h4_plan(int64_t T, int64_t N, int64_t K, int epi);
 // 256 x 224 four-wave tile (k_gemm_w14.hip): fp32 / gate-up epilogues, N whole 224-column tiles
 bool gemm_w14_plan(int64_t T, int64_t N, int64_t K, int epi);
+// the four-wave 256 x 256 kernel with the RoPE / bias / KV-append epilogue (k_gemm_8p.hip): a long prompt's QKV projection, whole K
+bool gemm_4w_rule(int64_t T, int64_t N, int64_t K, int64_t ksteps, bool streamk);
+bool gemm_4w_rope_supported(int64_t T, int64_t N, int64_t K);
+int launch_gemm_4w_rope(Launcher &L, const void *W, const void *x, const float *bias, int64_t T, int64_t N, int64_t K, const float *row_scale,
+                        const RopeEpi &rope);
+// the launches of a long prompt's QKV projection with that epilogue (k_gemm_mfma.hip): one plain grid, or whole rounds + peeled tail columns
+// on the 128 x 256 kernel -- false where launch_linear would cut K into slabs or run stream-K (rope_kv_append then sums / rotates)
+bool gemm_qkv_rope_long_plan(int64_t T, int64_t N, int64_t K, int max_split);
+int launch_gemm_qkv_rope_long(Launcher &L, const void *W, const void *x, const float *bias, int64_t T, int64_t N, int64_t K, const float *row_scale,
+                              const RopeEpi &rope, int max_split);
 int launch_gemm_w14(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
                     int epi, const float *row_scale, int64_t ldc = 0);
 int gemm_h4_tail_slices(int64_t T, int64_t N, int64_t K);     // a peeled GEMM's tail columns on this kernel: K slices, or 0 = the stream-K launch + fix-up   // K slices the kernel would run this shape in; 0: another kernel takes it

@@ -46,6 +46,7 @@ struct TuneEntry { const char *name; int dflt; };
 static const TuneEntry g_tune_table[TK_COUNT] = {
     {"gemm_h4", 1},
     {"gemm_w14", 1},
+    {"gemm_rope_4w", 1},
     {"h4_split", 0},
     {"h4_pf", 6},
     {"h4_wait_us", 30},
@@ -1237,6 +1238,12 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
                 ro.st = cs.st; ro.cos_tab = sh.cos_tab; ro.sin_tab = sh.sin_tab; ro.max_pos = (int)D.max_pos; ro.q_out = sc.q; ro.k_cache = kc; ro.v_cache = vc;
                 ro.H = (int)sh.Hs; ro.Hkv = (int)sh.Hkvs; ro.d = (int)D.d; ro.max_seq = (int)sa; ro.v_transposed = c->v_transposed ? 1 : 0;
                 FL_TRY(launch_gemm_h4(L, ly.wqkv, sc.xn, ly.bqkv, nullptr, T, nq, D.h, EPI_QKV_ROPE, sc.inv_rms, h4_qkv, nq, nullptr, &ro));
+            } else if (dt == FL_DTYPE_BF16 && gemm_qkv_rope_long_plan(T, nq, D.h, std::min(qkv_split, qkv_split_cap(T)))) {
+                // long prompts: the same epilogue on the four-wave 256 x 256 kernel (+ the 128 x 256 kernel for peeled tail columns)
+                RopeEpi ro;
+                ro.st = cs.st; ro.cos_tab = sh.cos_tab; ro.sin_tab = sh.sin_tab; ro.max_pos = (int)D.max_pos; ro.q_out = sc.q; ro.k_cache = kc; ro.v_cache = vc;
+                ro.H = (int)sh.Hs; ro.Hkv = (int)sh.Hkvs; ro.d = (int)D.d; ro.max_seq = (int)sa; ro.v_transposed = c->v_transposed ? 1 : 0;
+                FL_TRY(launch_gemm_qkv_rope_long(L, ly.wqkv, sc.xn, ly.bqkv, T, nq, D.h, sc.inv_rms, ro, std::min(qkv_split, qkv_split_cap(T))));
             } else {
                 FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, nullptr, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms,
                                      std::min(qkv_split, qkv_split_cap(T)), &qkv_slabs));

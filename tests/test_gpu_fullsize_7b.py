@@ -397,6 +397,43 @@ def test_gate_up_on_224_column_tiles_equals_the_256_column_grid(env, T):
     gm.close()
 
 
+@pytest.mark.parametrize("name,T", [("mistral-7b", 2048), ("mistral-7b", 1900), ("qwen2-7b", 4096)])
+def test_long_prompt_rope_in_the_qkv_epilogue_equals_the_rope_launch(env, name, T):
+    """Long prompts: RoPE, the q/k/v bias and the KV append in the epilogue of the four-wave 256 x 256 kernel (Qwen2-7B at 4096 tokens:
+    whole rounds there + the 512 tail columns -- its value heads -- on the 128 x 256 kernel with in-launch slices) against the fp32 QKV
+    matrix + rope_kv_append launch they replace: full width, 2 layers, prefill logits and a decode step on the cache the epilogue wrote."""
+    torch, fa, bench = env
+    from fastllm_amd.configs import MODEL_CONFIGS
+    cfg = dict(MODEL_CONFIGS[name], num_hidden_layers=2)
+    wts = bench.synth_device_weights(torch, cfg, torch.device("cuda", 0), seed=41)
+    gm = fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16")
+    del wts
+    torch.cuda.empty_cache()
+    ids = synth.prompt_ids(cfg, T, seed=43)
+    out = {}
+    try:
+        for mode in (1, 0):
+            fa.tune("gemm_rope_4w", mode)
+            c = gm.new_cache(T + 8)
+            gm.profile_begin()
+            lg = gm.forward(c, ids, 0)
+            names = {s["name"]: s["launches"] for s in gm.profile_end()}
+            out[mode] = (lg, gm.forward(c, ids[:1], T), names)
+            c.close()
+    finally:
+        fa.tune("reload_env", 0)
+    assert sum(v for n, v in out[1][2].items() if "4w," in n and "rope" in n) == 2, out[1][2]
+    assert not any("rope_kv" in n for n in out[1][2]), out[1][2]
+    assert sum(v for n, v in out[0][2].items() if "rope_kv" in n) == 2, out[0][2]
+    if name == "qwen2-7b":
+        assert sum(v for n, v in out[1][2].items() if "h4," in n and "rope" in n) == 2, out[1][2]      # the peeled tail columns
+    for k in (0, 1):
+        a, b = out[1][k], out[0][k]
+        assert np.linalg.norm(a - b) <= 1e-2 * np.linalg.norm(b), "rel L2 %.2e" % (np.linalg.norm(a - b) / np.linalg.norm(b))
+        assert oracle.argmax(a) == oracle.argmax(b)
+    gm.close()
+
+
 @pytest.mark.parametrize("T", [512, 640])
 def test_mid_prompt_small_hidden_size_on_the_in_launch_kernel(env, T):
     """TinyLlama-1.1B's widths (h = 2048, d = 64, I = 5632) at 257-640 tokens: gate/up without slices, QKV + RoPE (two 64-wide heads
