@@ -107,7 +107,7 @@ enum TuneKey {
     TK_TP_GRAPH,
     TK_BATCH_DMA_MIN,
     TK_H4_OPROJ_1K,   // o_proj of 641-1024-token prompts on the 128 x 256 kernel
-    TK_H4_TAIL,   // a peeled GEMM's tail columns on the 128 x 256 kernel instead of stream-K + fix-up
+    TK_H4_TAIL,   // a peeled GEMM's tail columns on the 128 x 256 kernel instead of stream-K + fix-up: 0 never, 1 with 2-4 in-launch slices, 2 (default) also unsliced when the tail alone fills the chip
     TK_RS_LAZY,   // 1/rms behind a residual epilogue: taken from the partial sums by the consuming projection (0: rms_finalize launch)
     TK_BATCH_UNFUSED_MIN,   // first batch size on the prefill-shaped step (-1: 3 with the ring kernel, else 7)
     TK_COUNT

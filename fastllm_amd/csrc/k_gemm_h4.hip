@@ -571,7 +571,8 @@ int gemm_h4_tail_slices(int64_t T, int64_t N, int64_t K) {
     const int64_t tiles = ((T + H4_BM - 1) / H4_BM) * ((N + H4_BN - 1) / H4_BN), nk = K / P_BK;
     int ks = 1;
     while (ks < H4_MAXS && tiles * (ks + 1) <= 256 && nk / (ks + 1) >= 8) ks++;
-    if (ks < 2 || tiles * ks < 160 || !gemm_h4_supported(T, N, K, ks)) return 0;
+    // (h4_tail = 2: also unsliced when the tail's tiles alone fill the chip -- Mistral-7B's 2048 QKV tail columns at 4096 tokens, 256 tiles)
+    if ((ks < 2 && !(tune(TK_H4_TAIL) >= 2 && tiles >= 224)) || tiles * ks < 160 || !gemm_h4_supported(T, N, K, ks)) return 0;
     return ks;
 }
 

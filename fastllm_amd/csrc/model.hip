@@ -121,7 +121,7 @@ static const TuneEntry g_tune_table[TK_COUNT] = {
     {"tp_graph", 1},
     {"batch_dma_min", 3},
     {"h4_oproj_1k", 1},
-    {"h4_tail", 1},
+    {"h4_tail", 2},
     {"rs_lazy", 1},
     {"batch_unfused_min", -1},
 };

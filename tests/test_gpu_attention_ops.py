@@ -113,6 +113,9 @@ def test_prefill32_key_split(fa, monkeypatch, d, H, Hkv, T, s_past, window):
     check(got, reference(q, k, v, s_past, H, Hkv, d, window), "prefill32 ks2 d=%d G=%d T=%d past=%d w=%d" % (d, H // Hkv, T, s_past, window))
 
 
+_SCHED_REF = {}
+
+
 @pytest.mark.parametrize("d,H,Hkv", [(128, 32, 8), (128, 28, 4)])
 @pytest.mark.parametrize("sched", [0, 1, 2])
 def test_prefill32_schedules(fa, monkeypatch, d, H, Hkv, sched):
@@ -122,10 +125,13 @@ def test_prefill32_schedules(fa, monkeypatch, d, H, Hkv, sched):
     monkeypatch.setenv("FL_ATTN_PF32_PAIRED", str(sched))
     monkeypatch.setenv("FL_ATTN_PF32_KS2", "0")
     T = 2100
-    q, k, v = make(T, 0, H, Hkv, d, seed=77 + sched, spike=True)
+    q, k, v = make(T, 0, H, Hkv, d, seed=77, spike=True)              # (the same inputs for the three schedules: one numpy reference)
     for window in (-1, 1000):
         got = fa.op_attention(q, k, v, 0, H, Hkv, d, window=window, kernel=3)
-        check(got, reference(q, k, v, 0, H, Hkv, d, window), "prefill32 schedule %d window %d" % (sched, window))
+        key = (d, H, Hkv, window)
+        if key not in _SCHED_REF:
+            _SCHED_REF[key] = reference(q, k, v, 0, H, Hkv, d, window)
+        check(got, _SCHED_REF[key], "prefill32 schedule %d window %d" % (sched, window))
 
 
 def test_bad_arguments_are_errors(fa):

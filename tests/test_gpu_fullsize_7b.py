@@ -245,6 +245,9 @@ def test_long_prompt_residual_epilogue_equals_rmsnorm_launches(env, monkeypatch,
     gm.close()
 
 
+_ORACLE_LONG = {}
+
+
 @pytest.mark.parametrize("name,T,tp", [("mistral-7b", 1100, 1), ("qwen2-7b", 1100, 1), ("mistral-7b", 4100, 1), ("qwen2-7b", 4096, 1),
                                        ("mistral-7b", 512, 8), ("qwen2-7b", 4096, 4)])      # the last two: BASELINE configs C4 / C5, emulated ranks
 def test_7b_width_long_prompt_vs_oracle(env, name, T, tp):
@@ -267,7 +270,10 @@ def test_7b_width_long_prompt_vs_oracle(env, name, T, tp):
     ids = synth.prompt_ids(cfg, T + 4, seed=9)
     gc, oc = g16.new_cache(T + 16), o32.new_cache(T + 16)
     t0 = time.time()
-    ref = o32.forward(oc, ids[:T], 0)
+    if (name, T) not in _ORACLE_LONG:                     # (the same seeded weights and ids for every tp: one oracle run per (model, length))
+        _ORACLE_LONG[(name, T)] = [o32.forward(oc, ids[:T], 0)] + [o32.forward(oc, ids[i:i + 1], i) for i in range(T, T + 4)]
+    refs = _ORACLE_LONG[(name, T)]
+    ref = refs[0]
     print("oracle prefill of %d tokens: %.1f s" % (T, time.time() - t0))
     got = g16.forward(gc, ids[:T], 0)
     n = np.linalg.norm(ref)
@@ -276,7 +282,7 @@ def test_7b_width_long_prompt_vs_oracle(env, name, T, tp):
     assert np.linalg.norm(got - ref) <= 2e-2 * n, "%s prefill(%d): rel L2 %.4f" % (name, T, np.linalg.norm(got - ref) / n)
     assert oracle.argmax(got) == oracle.argmax(ref)
     for i in range(T, T + 4):
-        ref, got = o32.forward(oc, ids[i:i + 1], i), g16.forward(gc, ids[i:i + 1], i)
+        ref, got = refs[1 + i - T], g16.forward(gc, ids[i:i + 1], i)
         n = np.linalg.norm(ref)
         assert np.linalg.norm(got - ref) <= 2e-2 * n, "%s decode at %d: rel L2 %.4f" % (name, i, np.linalg.norm(got - ref) / n)
     g16.close()
@@ -397,7 +403,7 @@ def test_gate_up_on_224_column_tiles_equals_the_256_column_grid(env, T):
     gm.close()
 
 
-@pytest.mark.parametrize("name,T", [("mistral-7b", 2048), ("mistral-7b", 1900), ("qwen2-7b", 4096)])
+@pytest.mark.parametrize("name,T", [("mistral-7b", 2048), ("mistral-7b", 1900), ("qwen2-7b", 4096), ("mistral-7b", 4096)])
 def test_long_prompt_rope_in_the_qkv_epilogue_equals_the_rope_launch(env, name, T):
     """Long prompts: RoPE, the q/k/v bias and the KV append in the epilogue of the four-wave 256 x 256 kernel (Qwen2-7B at 4096 tokens:
     whole rounds there + the 512 tail columns -- its value heads -- on the 128 x 256 kernel with in-launch slices) against the fp32 QKV
@@ -425,8 +431,8 @@ def test_long_prompt_rope_in_the_qkv_epilogue_equals_the_rope_launch(env, name, 
     assert sum(v for n, v in out[1][2].items() if "4w," in n and "rope" in n) == 2, out[1][2]
     assert not any("rope_kv" in n for n in out[1][2]), out[1][2]
     assert sum(v for n, v in out[0][2].items() if "rope_kv" in n) == 2, out[0][2]
-    if name == "qwen2-7b":
-        assert sum(v for n, v in out[1][2].items() if "h4," in n and "rope" in n) == 2, out[1][2]      # the peeled tail columns
+    if T == 4096:                                        # the peeled tail columns: Qwen2-7B's 512 (4 slices), Mistral-7B's 2048 (unsliced, 256 tiles)
+        assert sum(v for n, v in out[1][2].items() if "h4," in n and "rope" in n) == 2, out[1][2]
     for k in (0, 1):
         a, b = out[1][k], out[0][k]
         assert np.linalg.norm(a - b) <= 1e-2 * np.linalg.norm(b), "rel L2 %.2e" % (np.linalg.norm(a - b) / np.linalg.norm(b))
