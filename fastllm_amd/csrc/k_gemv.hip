@@ -601,7 +601,8 @@ static int launch_gemv_ru(Launcher &L, const GemvArgs &a) {
         if (sizeof(WT) == 2) U = (a.K >> 3) >= 512 ? 8 : 4;
         // the QKV projection is short enough for every wave to own ONE row group: with U = K / 512 its whole share is one block,
         // requested before the norm prologue runs (the SMALL form): Mistral-7B 11.8 -> 10.5 us
-        if (R == 2 && a.epi == EPI_QKV_ROPE && a.pro == PRO_NORM && (a.K == 4096 || a.K == 3584)) U = a.K / 512;
+        // (bf16 only: with fp32 weights eight chunks per row are 128 VGPRs of stream buffers -- the fp32 mode's QKV ran at 1.4 TB/s from scratch spills)
+        if (sizeof(WT) == 2 && R == 2 && a.epi == EPI_QKV_ROPE && a.pro == PRO_NORM && (a.K == 4096 || a.K == 3584)) U = a.K / 512;
     }
     if (R == 4 && U == 2) return launch_gemv_t<WT, XT, 4, 2, PRO>(L, a);
     if (R == 2 && U == 7) return launch_gemv_t<WT, XT, 2, 7, PRO>(L, a);

@@ -14,7 +14,8 @@ if len(sys.argv) > 3:
     cfg["num_hidden_layers"] = int(sys.argv[3])
 wts = bench.synth_device_weights(torch, cfg, torch.device("cuda", 0))
 tp = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-gm = fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16") if tp == 1 else fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16", tp_mode=fa.binding.TP_EMULATED, tp_size=tp)
+DT = os.environ.get("PP_DTYPE", "bf16")
+gm = fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype=DT) if tp == 1 else fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16", tp_mode=fa.binding.TP_EMULATED, tp_size=tp)
 del wts; torch.cuda.empty_cache()
 p = np.random.RandomState(0).randint(0, cfg["vocab_size"], size=T).astype(np.uint32)
 c = gm.new_cache(T + 8)
