@@ -236,6 +236,10 @@ struct H4Space {
 bool gemm_h4_supported(int64_t T, int64_t N, int64_t K, int ksplit);
 int gemm_h4_plan(int64_t T, int64_t N, int64_t K, int epi);
 // 256 x 224 four-wave tile (k_gemm_w14.hip): fp32 / gate-up epilogues, N whole 224-column tiles
+// fp32 operands on the matrix cores (k_gemm_f32.hip): the fp32 mode's prompt GEMM, bit-identical to gemm_generic_kernel's fmaf chains
+bool gemm_f32_mfma_supported(int64_t T, int64_t N, int64_t K);
+int launch_gemm_f32_mfma(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
+                         int epi, const float *row_scale);
 bool gemm_w14_plan(int64_t T, int64_t N, int64_t K, int epi);
 // the four-wave 256 x 256 kernel with the RoPE / bias / KV-append epilogue (k_gemm_8p.hip): a long prompt's QKV projection, whole K
 bool gemm_4w_rule(int64_t T, int64_t N, int64_t K, int64_t ksteps, bool streamk);

@@ -47,6 +47,7 @@ static const TuneEntry g_tune_table[TK_COUNT] = {
     {"gemm_h4", 1},
     {"gemm_w14", 1},
     {"gemm_rope_4w", 1},
+    {"gemm_f32_mfma", 1},
     {"h4_split", 0},
     {"h4_pf", 6},
     {"h4_wait_us", 30},

@@ -284,6 +284,24 @@ def test_linear_h4_slices_meet_in_the_launch(fa, T, N, K, slices, wait_us):
         fa.tune("reload_env", 0)
 
 
+# fp32 mode's prompt GEMM on v_mfma_f32_32x32x2_f32 (k_gemm_f32.hip): exact fp32 products summed as an fmaf chain in k order -- bit for
+# bit the 64 x 64 VALU kernel (gemm_f32_mfma = 0) on ragged T and N, both tile heights (64 / 128 rows), one and many K tiles
+@pytest.mark.parametrize("T,N,K,epi,bias", [(2, 100, 32, 0, True), (64, 4096, 4096, 0, False), (300, 1000, 1040, 0, True), (130, 6144, 16, 0, False),
+                                            (512, 8192, 512, 1, False), (77, 352, 256, 1, False), (1025, 13000, 192, 1, False), (2100, 4608, 3584, 0, True)])
+def test_linear_f32_mfma_is_the_fmaf_chain(fa, T, N, K, epi, bias):
+    x, w = _rand((T, K), 101), _rand((N if not epi else 2 * N, K), 102, 0.05)
+    b = _rand((N,), 103) if bias else None
+    try:
+        fa.tune("gemm_f32_mfma", 1)
+        y = fa.op_linear(x, w, b, epilogue=epi)
+        fa.tune("gemm_f32_mfma", 0)
+        y0 = fa.op_linear(x, w, b, epilogue=epi)
+    finally:
+        fa.tune("reload_env", 0)
+    np.testing.assert_array_equal(y, y0)
+    np.testing.assert_allclose(y, _ref(x, w, b, epi), atol=2e-5 * np.sqrt(K) + 1e-5, rtol=1e-5)
+
+
 # 256 x 224 four-wave GEMM (k_gemm_w14.hip), forced on (gemm_w14 = 2): widths of whole 224-column tiles, two / odd / many K tiles,
 # ragged last row tiles.  Integer operands: any wrong fragment, column block or stale LDS half shows as a wrong integer.
 @pytest.mark.parametrize("T,N,K", [(512, 448, 128), (257, 224, 192), (300, 2240, 1024), (1024, 896, 4096), (700, 28672, 256)])
