@@ -595,7 +595,9 @@ static int launch_gemv_ru(Launcher &L, const GemvArgs &a) {
     // K <= 4096 (Mistral-7B: o_proj 7.96 -> 7.48 us, lm_head 43.8 -> 42.0, QKV 11.95 -> 11.82; down_proj at K = 14336
     // 19.9 vs 20.9 and gate/up 38.2 vs 38.1 stay on four)
     if (U <= 0) {
-        U = (a.epi != EPI_GATEUP && a.K > 2560 && a.K <= 4096) ? 2 : 4;             // fp32 weights (TinyLlama's K = 2048: four is 1 % better)
+        // fp32 weights: two 2-KiB chunks per row -- the four-chunk instantiations spill 20-48 VGPRs under the 168-register cap of a
+        // 768-thread workgroup (Mistral-7B fp32 decode: gate/up 5.11 -> 5.41 TB/s, down_proj 5.03 -> 5.69, step 6.12 -> 5.78 ms)
+        U = 2;
         // bf16 (two register buffers of the stream, dot2 arithmetic: 152-166 VGPRs at U = 8, no spills): 8 KiB per row group
         // and request round from K = 4096 (Mistral-7B: down_proj 19.9 -> 19.05 us, the others equal or better), 4 below
         if (sizeof(WT) == 2) U = (a.K >> 3) >= 512 ? 8 : 4;
