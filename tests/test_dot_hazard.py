@@ -167,3 +167,34 @@ def test_four_wave_gemm_owns_its_accumulator_registers(tmp_path, kernel, min_mfm
                     since_mfma += 1
         assert nmfma >= min_mfma, "expected the instantiations' K loops, found %d MFMAs" % nmfma
     assert found >= min_found, "%s not found in the library" % kernel
+
+
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+@pytest.mark.skipif(not os.path.exists(READELF), reason="llvm-readelf of the ROCm toolchain not found")
+def test_no_dispatched_kernel_spills(tmp_path):
+    """No kernel the default dispatch can launch holds spilled VGPRs (a spill turns a weight stream into scratch traffic: the fp32
+    mode's QKV GEMV ran at 1.4 TB/s instead of 4.5 with one, round 4).  Exempt: instantiations only a tuning switch reaches -- the fp32
+    GEMV with 4 / 7 / 8 chunks per row or four rows per wave (FL_GEMV_U / FL_GEMV_R; fp32 defaults to two chunks, two rows) and the
+    32-row prefill attention for groups of five query heads (no model here has them)."""
+    blob = open(LIB, "rb").read()
+    bad, seen = [], 0
+    for n, co in enumerate(gfx950_code_objects(blob)):
+        p = tmp_path / ("n%d.elf" % n)
+        p.write_bytes(co)
+        md = subprocess.run([READELF, "--notes", str(p)], capture_output=True, text=True, check=True).stdout
+        for blk in md.split(".args:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            spill = re.search(r"\.vgpr_spill_count:\s+(\d+)", blk)
+            if not name or not spill:
+                continue
+            seen += 1
+            if int(spill.group(1)) == 0:
+                continue
+            k = name.group(1)
+            if re.search(r"gemv_kernelIffLi(2ELi[478]|4ELi2)E", k) or "attn_prefill32_kernelILi128ELi5ELb0E" in k:
+                continue
+            bad.append("%s: %s VGPRs spilled" % (k, spill.group(1)))
+    assert seen > 100, "kernel metadata not found (%d entries)" % seen
+    assert not bad, "\n".join(bad)
