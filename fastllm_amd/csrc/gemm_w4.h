@@ -17,9 +17,12 @@ __device__ inline int a_row(int h, int r) { return (r >> 6) * 128 + h * 64 + (r 
 typedef int int4w __attribute__((ext_vector_type(4)));
 constexpr int W4_BIAS = 3072;
 __device__ inline void w4_set_m0(unsigned m0v) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(m0v) : "memory"); }
-template <int S>
+// NT: the non-temporal form, for bytes no other workgroup will ask for again (tools/micro/ingest_bench.hip: an HBM stream through
+// LDS-DMA runs at 5.97 TB/s plain and 6.89 with nt; bytes another workgroup of the XCD re-reads should stay plain: they are its L2 hits)
+template <int S, bool NT = false>
 __device__ inline void w4_piece(int4w rsrc, unsigned voff, unsigned soff) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%c3 lds" : : "v"(voff), "s"(rsrc), "s"(soff), "i"(S * 1024) : "memory");
+    if constexpr (NT) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%c3 nt lds" : : "v"(voff), "s"(rsrc), "s"(soff), "i"(S * 1024) : "memory");
+    else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%c3 lds" : : "v"(voff), "s"(rsrc), "s"(soff), "i"(S * 1024) : "memory");
 }
 __device__ inline int4w w4_rsrc(const void *base) {                     // raw buffer over [base - 3072, +4 GiB): no stride, no swizzle
     const unsigned long long b = (unsigned long long)base - W4_BIAS;

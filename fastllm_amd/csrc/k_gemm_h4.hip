@@ -53,7 +53,7 @@ constexpr int H4_MAX_TILES = 4096;                     // tiles of one launch (w
 
 // (EPI_QKV_ROPE, the RoPE / bias / KV-append epilogue: gemm_w4.h, shared with the four-wave 256 x 256 kernel)
 
-template <int S>
+template <int S, bool WNT>
 __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
                                                       const float *__restrict__ bias, void *__restrict__ out,
                                                       int T, int N, int K, int epi, int tiles_m, int tiles_n,
@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__
     w4_for<8>([&](auto c) { w4_zero16<decltype(c)::value * 16>(); });
 
     const int4w rsX = w4_rsrc(Xs), rsW = w4_rsrc(Ws);
+#define H4_WP(S_, OFF_, KO_) w4_piece<S_, WNT>(rsW, OFF_, KO_)      /* a W piece: non-temporal where few row tiles share the panel */
     auto koff = [&](int tile) { return (unsigned)(min(tile, nk - 1) * (P_BK * 2)); };   // byte offset of a K tile (clamped past the end)
     auto koffW = [&](int tile) { return blocked ? (unsigned)((kt0 + min(tile, nk - 1)) * 32768 - kt0 * (P_BK * 2)) : koff(tile); };
     const unsigned lds0 = (unsigned)(size_t)lds + wave * 4096;          // this wave's piece 0 of half 0 of slot 0 (LDS byte address)
@@ -131,7 +132,8 @@ __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__
         const unsigned ko = which == 0 ? koff(tile) : koffW(tile);
         const int4w rs = which == 0 ? rsX : rsW;
         const unsigned *of = which == 0 ? offA : offB[which - 1];
-        w4_piece<0>(rs, of[0], ko); w4_piece<1>(rs, of[1], ko); w4_piece<2>(rs, of[2], ko); w4_piece<3>(rs, of[3], ko);
+        if (which == 0) { w4_piece<0>(rs, of[0], ko); w4_piece<1>(rs, of[1], ko); w4_piece<2>(rs, of[2], ko); w4_piece<3>(rs, of[3], ko); }
+        else { w4_piece<0, WNT>(rs, of[0], ko); w4_piece<1, WNT>(rs, of[1], ko); w4_piece<2, WNT>(rs, of[2], ko); w4_piece<3, WNT>(rs, of[3], ko); }
     };
 
     // prologue: the first eight half tiles of the request order
@@ -193,9 +195,9 @@ __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__
             w4_set_m0(m0of(S2, 2));                                                                         \
             H4_FENCE                                                                                        \
             H4_Q(0, 0, FA, fb0, fb1[0][0] = rdB(S0, 1, 0, 0), fb1[0][1] = rdB(S0, 1, 0, 1), fb1[1][0] = rdB(S0, 1, 1, 0),          \
-                 w4_piece<0>(rsW, offB[1][0], ko2), w4_piece<1>(rsW, offB[1][1], ko2))                      \
+                 H4_WP(0, offB[1][0], ko2), H4_WP(1, offB[1][1], ko2))                      \
             H4_Q(0, 1, FA, fb0, fb1[1][1] = rdB(S0, 1, 1, 1), fb1[2][0] = rdB(S0, 1, 2, 0), fb1[2][1] = rdB(S0, 1, 2, 1),          \
-                 w4_piece<2>(rsW, offB[1][2], ko2), w4_piece<3>(rsW, offB[1][3], ko2))                      \
+                 H4_WP(2, offB[1][2], ko2), H4_WP(3, offB[1][3], ko2))                      \
             w4_set_m0(m0of(S0, 0));                                                                         \
             H4_FENCE                                                                                        \
             H4_Q(0, 2, FA, fb0, fb1[3][0] = rdB(S0, 1, 3, 0), fb1[3][1] = rdB(S0, 1, 3, 1), FN[0][0] = rdA(S1, 0, 0),              \
@@ -215,9 +217,9 @@ __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__
             w4_set_m0(m0of(S0, 1));                                                                         \
             H4_FENCE                                                                                        \
             H4_Q(1, 2, FA, fb1, fb0[1][0] = rdB(S1, 0, 1, 0), fb0[1][1] = rdB(S1, 0, 1, 1), fb0[2][0] = rdB(S1, 0, 2, 0),          \
-                 w4_piece<0>(rsW, offB[0][0], ko3w), w4_piece<1>(rsW, offB[0][1], ko3w))                      \
+                 H4_WP(0, offB[0][0], ko3w), H4_WP(1, offB[0][1], ko3w))                      \
             H4_Q(1, 3, FA, fb1, fb0[2][1] = rdB(S1, 0, 2, 1), fb0[3][0] = rdB(S1, 0, 3, 0), fb0[3][1] = rdB(S1, 0, 3, 1),          \
-                 w4_piece<2>(rsW, offB[0][2], ko3w), w4_piece<3>(rsW, offB[0][3], ko3w))                      \
+                 H4_WP(2, offB[0][2], ko3w), H4_WP(3, offB[0][3], ko3w))                      \
             asm volatile("s_waitcnt vmcnt(17)" ::: "memory");                                               \
             __builtin_amdgcn_s_waitcnt(0xC07F);                                                             \
             H4_FENCE                                                                                        \
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__
 #undef H4_Q
 #undef H4_NONE
 #undef H4_FENCE
+#undef H4_WP
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the clamped re-stages past the last tile; the last MFMAs' results
     __builtin_amdgcn_s_barrier();                                       // LDS is free
     stamp(2);
@@ -594,7 +597,14 @@ int launch_gemm_h4(Launcher &L, const void *W, const void *x, const float *bias,
     H4Space ws{nullptr, nullptr};
     int set = 0;
     if (ksplit > 1) FL_TRY(h4_space(L.stream, (size_t)tiles_m * tiles_n * ksplit, &ws, &set));
-    auto kern = ksplit == 1 ? gemm_h4_kernel<1> : ksplit == 2 ? gemm_h4_kernel<2> : ksplit == 3 ? gemm_h4_kernel<3> : gemm_h4_kernel<4>;
+    // W pieces non-temporal (h4_nt: 1 always, 0 never, -1 up to 256 tokens = two row tiles per panel): an HBM stream through LDS-DMA
+    // is 15 % faster with nt (tools/micro/ingest_bench.hip) and does not push the activations out of the caches, but the second
+    // reader of a panel then misses more often.  Whole prefills, plain / nt: Mistral-7B 200 / 256 tokens 6.40 / 6.24, 6.58 / 6.42 ms;
+    // 300 / 384 / 512 / 640 tokens (3-5 row tiles) x 1.013 / 1.007 / 1.009 / 1.050; Qwen2-7B 384-640 x 1.04-1.06
+    const int nt_mode = tune(TK_H4_NT);
+    const bool wnt = nt_mode == 1 || (nt_mode < 0 && T <= 256);
+    auto kern = wnt ? (ksplit == 1 ? gemm_h4_kernel<1, true> : ksplit == 2 ? gemm_h4_kernel<2, true> : ksplit == 3 ? gemm_h4_kernel<3, true> : gemm_h4_kernel<4, true>)
+                    : (ksplit == 1 ? gemm_h4_kernel<1, false> : ksplit == 2 ? gemm_h4_kernel<2, false> : ksplit == 3 ? gemm_h4_kernel<3, false> : gemm_h4_kernel<4, false>);
     static_assert(H4_MAXS == 4, "one instantiation per slice count");
     FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), H4_LDS));
     char tag[32];

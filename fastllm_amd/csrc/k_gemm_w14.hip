@@ -38,6 +38,7 @@ constexpr int W14_LDS = 2 * W14_SLOT;                  // 128 KiB
 
 #define W14_AGPRS "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143","a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159","a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191","a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207","a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223"
 
+template <bool WNT>
 __global__ __launch_bounds__(256) void gemm_w14_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
                                                        const float *__restrict__ bias, void *__restrict__ out,
                                                        int T, int N, int K, int epi, int tiles_m, int tiles_n,
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(256) void gemm_w14_kernel(const bf16_t *__restrict_
     w4_for<14>([&](auto c) { w4_zero16<decltype(c)::value * 16>(); });
 
     const int4w rsX = w4_rsrc(X), rsW = w4_rsrc(W);
+#define W14_WP(S_, OFF_) w4_piece<S_, WNT>(rsW, OFF_, ko)      /* a W piece: non-temporal where no other workgroup re-reads the panel */
     auto koff = [&](int tile) { return (unsigned)(min(tile, nk - 1) * (P_BK * 2)); };   // byte offset of a K tile (clamped past the end)
     const unsigned ldsw4 = (unsigned)(size_t)lds + wave * 4096, ldsw3 = (unsigned)(size_t)lds + wave * 3072;
     // which: 0 A0, 1 A1, 2 B0, 3 B1
@@ -80,8 +82,8 @@ __global__ __launch_bounds__(256) void gemm_w14_kernel(const bf16_t *__restrict_
         w4_set_m0(m0of(slot, which));
         const unsigned ko = koff(tile);
         if (which < 2) { w4_piece<0>(rsX, offA[which][0], ko); w4_piece<1>(rsX, offA[which][1], ko); w4_piece<2>(rsX, offA[which][2], ko); w4_piece<3>(rsX, offA[which][3], ko); }
-        else if (which == 2) { w4_piece<0>(rsW, offB0[0], ko); w4_piece<1>(rsW, offB0[1], ko); w4_piece<2>(rsW, offB0[2], ko); w4_piece<3>(rsW, offB0[3], ko); }
-        else { w4_piece<0>(rsW, offB1[0], ko); w4_piece<1>(rsW, offB1[1], ko); w4_piece<2>(rsW, offB1[2], ko); }
+        else if (which == 2) { W14_WP(0, offB0[0]); W14_WP(1, offB0[1]); W14_WP(2, offB0[2]); W14_WP(3, offB0[3]); }
+        else { W14_WP(0, offB1[0]); W14_WP(1, offB1[1]); W14_WP(2, offB1[2]); }
     };
     // prologue: tiles 0 and 1 whole, in the order of the loop's requests (15 pieces per wave and tile)
     stage_half(0, 0, 0); stage_half(1, 0, 0); stage_half(2, 0, 0); stage_half(3, 0, 0);
@@ -176,19 +178,19 @@ __global__ __launch_bounds__(256) void gemm_w14_kernel(const bf16_t *__restrict_
             W14_FENCE                                                                                       \
             w4_set_m0(m0of(S0, 2));                                                                         \
             W14_FENCE                                                                                       \
-            W14_Q3(0, 8, FA, fbx, fby[0][0] = rdB(S0, 11, 0), fby[0][1] = rdB(S0, 11, 1), w4_piece<0>(rsW, offB0[0], ko), fby[1][0] = rdB(S0, 12, 0)) \
-            W14_Q3(1, 8, FA, fbx, fby[1][1] = rdB(S0, 12, 1), fby[2][0] = rdB(S0, 13, 0), w4_piece<1>(rsW, offB0[1], ko), fby[2][1] = rdB(S0, 13, 1)) \
-            W14_Q3(2, 8, FA, fbx, FN[1][0] = rdA(S1, 1, 0), FN[1][1] = rdA(S1, 1, 1), w4_piece<2>(rsW, offB0[2], ko), W14_NONE)        \
-            W14_Q3(3, 8, FA, fbx, FN[2][0] = rdA(S1, 2, 0), FN[2][1] = rdA(S1, 2, 1), w4_piece<3>(rsW, offB0[3], ko), W14_NONE)        \
+            W14_Q3(0, 8, FA, fbx, fby[0][0] = rdB(S0, 11, 0), fby[0][1] = rdB(S0, 11, 1), W14_WP(0, offB0[0]), fby[1][0] = rdB(S0, 12, 0)) \
+            W14_Q3(1, 8, FA, fbx, fby[1][1] = rdB(S0, 12, 1), fby[2][0] = rdB(S0, 13, 0), W14_WP(1, offB0[1]), fby[2][1] = rdB(S0, 13, 1)) \
+            W14_Q3(2, 8, FA, fbx, FN[1][0] = rdA(S1, 1, 0), FN[1][1] = rdA(S1, 1, 1), W14_WP(2, offB0[2]), W14_NONE)        \
+            W14_Q3(3, 8, FA, fbx, FN[2][0] = rdA(S1, 2, 0), FN[2][1] = rdA(S1, 2, 1), W14_WP(3, offB0[3]), W14_NONE)        \
             W14_END(15)                                                                                     \
             /* ---- phase 4: columns 176-223 ---- */                                                        \
             __builtin_amdgcn_s_barrier();                                                                   \
             W14_FENCE                                                                                       \
             w4_set_m0(m0of(S0, 3));                                                                         \
             W14_FENCE                                                                                       \
-            W14_Q3(0, 11, FA, fby, fbx[0][0] = rdB(S1, 0, 0), fbx[0][1] = rdB(S1, 0, 1), w4_piece<0>(rsW, offB1[0], ko), fbx[1][0] = rdB(S1, 1, 0)) \
-            W14_Q3(1, 11, FA, fby, fbx[1][1] = rdB(S1, 1, 1), fbx[2][0] = rdB(S1, 2, 0), w4_piece<1>(rsW, offB1[1], ko), fbx[2][1] = rdB(S1, 2, 1)) \
-            W14_Q3(2, 11, FA, fby, fbx[3][0] = rdB(S1, 3, 0), fbx[3][1] = rdB(S1, 3, 1), w4_piece<2>(rsW, offB1[2], ko), W14_NONE)     \
+            W14_Q3(0, 11, FA, fby, fbx[0][0] = rdB(S1, 0, 0), fbx[0][1] = rdB(S1, 0, 1), W14_WP(0, offB1[0]), fbx[1][0] = rdB(S1, 1, 0)) \
+            W14_Q3(1, 11, FA, fby, fbx[1][1] = rdB(S1, 1, 1), fbx[2][0] = rdB(S1, 2, 0), W14_WP(1, offB1[1]), fbx[2][1] = rdB(S1, 2, 1)) \
+            W14_Q3(2, 11, FA, fby, fbx[3][0] = rdB(S1, 3, 0), fbx[3][1] = rdB(S1, 3, 1), W14_WP(2, offB1[2]), W14_NONE)     \
             W14_Q3(3, 11, FA, fby, FN[3][0] = rdA(S1, 3, 0), FN[3][1] = rdA(S1, 3, 1), W14_NONE, W14_NONE)                             \
             W14_END(18)                                                                                     \
         }
@@ -205,6 +207,7 @@ __global__ __launch_bounds__(256) void gemm_w14_kernel(const bf16_t *__restrict_
 #undef W14_Q4
 #undef W14_NONE
 #undef W14_FENCE
+#undef W14_WP
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the clamped re-stages past the last tile; the last MFMAs' results
     __builtin_amdgcn_s_barrier();                                       // LDS is free
 
@@ -248,13 +251,15 @@ int launch_gemm_w14(Launcher &L, const void *W, const void *x, const float *bias
     if (N % W14_BN || K % P_BK || K / P_BK < 2 || (epi != EPI_F32 && epi != EPI_GATEUP)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_w14: N must be whole 224-column tiles, fp32 or gate/up epilogue");
     if ((double)std::max(T, N) * (double)K * 2.0 + (double)K * 2.0 + 8192.0 >= 4294967296.0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_w14: matrices below 4 GiB");
     const int tiles_m = (int)((T + W14_BM - 1) / W14_BM), tiles_n = (int)(N / W14_BN);
-    FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(gemm_w14_kernel), W14_LDS));
+    const bool wnt = tune(TK_W14_NT) == 1 || (tune(TK_W14_NT) < 0 && T <= 512);   // (two row tiles: 512 tokens 94.6 -> 90.4 us; from three on the re-reads want the panel in L2: 1024 tokens 195 -> 202)
+    auto kern = wnt ? gemm_w14_kernel<true> : gemm_w14_kernel<false>;
+    FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), W14_LDS));
     char tag[32];
     snprintf(tag, sizeof tag, "w14,%lldx%lld", (long long)N, (long long)K);
     Launcher LL = L; LL.tag = tag;
     const int group_env = tune(TK_GEMM_GROUPM);
     const int group_m = std::max(1, std::min(tiles_m, group_env > 0 ? group_env : 4));
-    return LL.launch(KC_GEMM_MFMA, ((double)N * K + (double)T * K) * 2.0, 2.0 * T * N * K, gemm_w14_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), W14_LDS,
+    return LL.launch(KC_GEMM_MFMA, ((double)N * K + (double)T * K) * 2.0, 2.0 * T * N * K, kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), W14_LDS,
                      (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, (int)ldc, group_m, L.rsp);
 }
 

@@ -48,6 +48,8 @@ static const TuneEntry g_tune_table[TK_COUNT] = {
     {"gemm_w14", 1},
     {"gemm_rope_4w", 1},
     {"gemm_f32_mfma", 1},
+    {"w14_nt", -1},
+    {"h4_nt", -1},
     {"h4_split", 0},
     {"h4_pf", 6},
     {"h4_wait_us", 30},
