@@ -54,7 +54,11 @@ __device__ inline bf16x8p frag(const unsigned char *half, int row, int chunk) {
 __device__ inline int b_row(int h, int r) { return (r >> 5) * 64 + h * 32 + (r & 31); }
 
 // one half tile = 16 wave-instructions of 1 KiB (8 rows): two per wave
-template <bool IS_A>
+__device__ inline void glds16p_nt(const void *g, unsigned char *lds_wave_base) {   // non-temporal: a W panel nobody re-reads (one row tile)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 2);
+}
+template <bool IS_A, bool NT = false>
 __device__ inline void stage_half(const bf16_t *__restrict__ M, int nrows, int K, int row0, int k0, int h,
                                   unsigned char *half, int wave, int lane) {
 #pragma unroll
@@ -63,7 +67,8 @@ __device__ inline void stage_half(const bf16_t *__restrict__ M, int nrows, int K
         const int r = rb + (lane >> 3), pc = lane & 7, c = pc ^ ((r >> 1) & 7);
         int gr = row0 + (IS_A ? a_row(h, r) : b_row(h, r));
         if (gr > nrows - 1) gr = nrows - 1;
-        glds16p(M + (size_t)gr * K + k0 + c * 8, half + rb * 128);
+        if constexpr (NT) glds16p_nt(M + (size_t)gr * K + k0 + c * 8, half + rb * 128);
+        else glds16p(M + (size_t)gr * K + k0 + c * 8, half + rb * 128);
     }
 }
 
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__
                                                       const float *__restrict__ bias, void *__restrict__ out,
                                                       int T, int N, int K, int epi, int tiles_m, int tiles_n,
                                                       const float *__restrict__ row_scale, int ksplit, int ldc,
-                                                      unsigned long long *__restrict__ stamps, StreamK sk, ResidEpi re, RsParts rsp) {
+                                                      unsigned long long *__restrict__ stamps, StreamK sk, ResidEpi re, RsParts rsp, int wnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [parity][A0 A1 B0 B1]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform values live in SGPRs)
     const int wr = wave >> 2, wc = wave & 3;
@@ -132,7 +137,11 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(const bf16_t *__restrict__
 
         auto hbuf = [&](int tile, int which) -> unsigned char * { return lds + ((tile & 1) * 4 + which) * P_HALF; };   // which: 0 A0, 1 A1, 2 B0, 3 B1
         auto stA = [&](int h, int tile) { if (tile < nk) stage_half<true>(Xs, T, K, m0, tile * P_BK, h, hbuf(tile, h), wave, lane); };
-        auto stB = [&](int h, int tile) { if (tile < nk) stage_half<false>(Ws, N, K, n0, tile * P_BK, h, hbuf(tile, 2 + h), wave, lane); };
+        auto stB = [&](int h, int tile) {
+            if (tile >= nk) return;
+            if (wnt) stage_half<false, true>(Ws, N, K, n0, tile * P_BK, h, hbuf(tile, 2 + h), wave, lane);
+            else stage_half<false>(Ws, N, K, n0, tile * P_BK, h, hbuf(tile, 2 + h), wave, lane);
+        };
 
         // prologue: tile 0 whole, A0 / B0 of tile 1 (what phases 3, 4 of "tile -1" would have staged)
         stA(0, 0); stB(0, 0); stB(1, 0); stA(1, 0); stA(0, 1); stB(0, 1);
@@ -622,6 +631,7 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
                          bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, sk, re, group_m, L.rsp, RopeEpi{}));
         return fixup();
     }
+    const int wnt8 = !streamk && tiles_m == 1 && T >= 192 && tune(TK_H4_NT) != 0;   // one row tile: the W panels are read once -- non-temporal
     const bool stamp = env_str("FL_8P_STAMPS") != nullptr;           // diagnostics only: synchronous, appends one record per launch
     auto kern = streamk ? (stamp ? gemm_8p_kernel<true, true> : gemm_8p_kernel<false, true>) : (stamp ? gemm_8p_kernel<true, false> : gemm_8p_kernel<false, false>);
     FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), P_LDS));
@@ -631,7 +641,7 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         unsigned long long *d = nullptr;
         FL_HIP(hipMalloc(&d, nwg * 80));
         const int rc = LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, grid, dim3(512), P_LDS, (const bf16_t *)W,
-                                 (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, d, sk, re, L.rsp);
+                                 (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, d, sk, re, L.rsp, wnt8);
         if (rc == FL_OK) FL_TRY(fixup());
         std::vector<unsigned long long> h(nwg * 10);
         FL_HIP(hipStreamSynchronize(L.stream));
@@ -648,7 +658,7 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
         return rc;
     }
     FL_TRY(LL.launch(KC_GEMM_MFMA, bytes, 2.0 * T * N * K, kern, grid, dim3(512), P_LDS, (const bf16_t *)W, (const bf16_t *)x,
-                     bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, (unsigned long long *)nullptr, sk, re, L.rsp));
+                     bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, (unsigned long long *)nullptr, sk, re, L.rsp, wnt8));
     return fixup();
 }
 

@@ -29,6 +29,11 @@ __device__ inline void glds16(const void *g, unsigned char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
+// non-temporal: a W panel one workgroup reads once (profiles/r04/README.md, ingest path)
+__device__ inline void glds16_nt(const void *g, unsigned char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 2);
+}
 
 // stage one 128x64 tile: rows [row0, row0+128) of a [nrows][K] matrix at columns [k0, k0+64)
 __device__ inline void stage_tile(const bf16_t *__restrict__ M, int nrows, int K, int row0, int k0,
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const bf16_t *__restrict
 constexpr int BM2 = 256, STAGE2 = (BM2 + BN) * BK * 2;       // 48 KiB per stage
 
 // stage `rows` x 64 of a [nrows][K] matrix; 8 waves, rows/64 LDS-DMA instructions per wave
-template <int ROWS>
+template <int ROWS, bool NT = false>
 __device__ inline void stage_rows8(const bf16_t *__restrict__ M, int nrows, int K, int row0, int k0,
                                    unsigned char *lds_tile, int wave, int lane) {
 #pragma unroll
@@ -153,14 +158,15 @@ __device__ inline void stage_rows8(const bf16_t *__restrict__ M, int nrows, int 
         const int rb = (i * 8 + wave) * 8;                       // 8 rows (1 KiB) per instruction
         const int r = rb + (lane >> 3), pc = lane & 7, c = pc ^ ((r >> 1) & 7);
         int gr = row0 + r; if (gr > nrows - 1) gr = nrows - 1;
-        glds16(M + (size_t)gr * K + k0 + c * 8, lds_tile + rb * 128);
+        if constexpr (NT) glds16_nt(M + (size_t)gr * K + k0 + c * 8, lds_tile + rb * 128);
+        else glds16(M + (size_t)gr * K + k0 + c * 8, lds_tile + rb * 128);
     }
 }
 
 __global__ __launch_bounds__(512) void gemm_mfma256_kernel(const bf16_t *__restrict__ W, const bf16_t *__restrict__ X,
                                                            const float *__restrict__ bias, void *__restrict__ out,
                                                            int T, int N, int K, int epi, int tiles_m, int tiles_n,
-                                                           const float *__restrict__ row_scale, int ksplit, int ldc) {
+                                                           const float *__restrict__ row_scale, int ksplit, int ldc, int wnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [3 stages][X 256x64 | W 128x64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -185,7 +191,8 @@ __global__ __launch_bounds__(512) void gemm_mfma256_kernel(const bf16_t *__restr
     auto stage = [&](int kt, int slot) {                          // 4 + 2 = 6 LDS-DMA instructions per wave
         unsigned char *base = lds + slot * STAGE2;
         stage_rows8<BM2>(X, T, K, m0, kt * BK, base, wave, lane);
-        stage_rows8<BN>(W, N, K, n0, kt * BK, base + BM2 * BK * 2, wave, lane);
+        if (wnt) stage_rows8<BN, true>(W, N, K, n0, kt * BK, base + BM2 * BK * 2, wave, lane);   // (one row tile: nobody re-reads the panel)
+        else stage_rows8<BN>(W, N, K, n0, kt * BK, base + BM2 * BK * 2, wave, lane);
     };
     stage(0, 0);
     if (nk > 1) stage(1, 1);
@@ -486,7 +493,8 @@ static int launch_gemm_mfma_impl(Launcher &L, const void *W, const void *x, cons
         snprintf(tag2, sizeof tag2, "256x128,%lldx%lld%s", (long long)N, (long long)K, ksplit > 1 ? ",splitK" : "");
         Launcher L2 = L; L2.tag = tag2;
         return L2.launch(KC_GEMM_MFMA, bytes2, 2.0 * T * N * K, gemm_mfma256_kernel, dim3((unsigned)(tm2 * tn2), (unsigned)ksplit), dim3(512),
-                        lds2, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tm2, tn2, row_scale, ksplit, (int)ldc);
+                        lds2, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tm2, tn2, row_scale, ksplit, (int)ldc,
+                        (int)(tune(TK_H4_NT) == 1 || (tune(TK_H4_NT) < 0 && tm2 == 1 && T >= 192)));
     }
     const int tiles_m = (int)((T + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
     if (ksplit > 1 && bias) FL_FAIL(FL_ERR_BAD_ARGUMENT, "split-K GEMM cannot add a bias");

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void ingest_kernel(const unsigned char *buf, s
     auto piece = [&](int i) {
         const unsigned m0 = ldsw + (i % P) * 1024;
         asm volatile("s_mov_b32 m0, %0" ::"s"(m0) : "memory");
-        const bool hot = mode == 1 || (mode == 2 && (i & 7) >= 3);
+        //   mode 3: every wave alternates HBM / L2 pieces (1 : 1); mode 4: waves 0, 1 stream HBM only, waves 2, 3 L2 only (the same bytes)
+        const bool hot = mode == 1 || (mode == 2 && (i & 7) >= 3) || (mode == 3 && (i & 1)) || (mode == 4 && wave >= 2);
         if (hot) {
             const unsigned so = (unsigned)((i * 1024) & 32767);
             asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rl), "s"(so) : "memory");
@@ -105,7 +106,7 @@ static void run(const unsigned char *buf, size_t region, int ppw, int mode, int 
     float ms = 0.f;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double bytes = (double)nwg * 4 * ppw * 1024.0 * reps;
-    printf("%-28s LDS-DMA%s P=%2d wgs=%4d: %7.1f us per launch, %6.2f TB/s total, %6.1f GB/s per workgroup\n", what, NT ? " nt" : "   ", P, nwg, ms * 1e3 / reps, bytes / ms / 1e9,
+    printf("%-32s LDS-DMA%s P=%2d wgs=%4d: %7.1f us per launch, %6.2f TB/s total, %6.1f GB/s per workgroup\n", what, NT ? " nt" : "   ", P, nwg, ms * 1e3 / reps, bytes / ms / 1e9,
            bytes / ms / 1e6 / nwg);
 }
 
@@ -126,6 +127,10 @@ int main() {
             if (wpc == 1) run<32>(buf, region, ppw, mode, cus * wpc, sink, names[mode]);
         }
     }
+    run<16>(buf, region, ppw, 3, cus, sink, "1/2 HBM + 1/2 L2, every wave");
+    run<16>(buf, region, ppw, 4, cus, sink, "1/2 HBM + 1/2 L2, by wave");
+    run<16, true>(buf, region, ppw, 3, cus, sink, "1/2 HBM + 1/2 L2, every wave");
+    run<16, true>(buf, region, ppw, 4, cus, sink, "1/2 HBM + 1/2 L2, by wave");
     run<16, true>(buf, region, ppw, 0, cus, sink, names[0]);
     run<16, true>(buf, region, ppw, 2, cus, sink, names[2]);
     run_v<16, false>(buf, region, ppw, 0, cus, sink, names[0]);
