@@ -386,7 +386,11 @@ static int launch_skinny_t(Launcher &L, const void *W, const void *x, const floa
     // deepest ring: LDS (<= 152 KB) and the 6-bit vmcnt field
     constexpr int kFit = 152 * 1024 / STG, kCnt = 63 / PW + 2;
     constexpr int kDeep = kFit < kCnt ? (kFit < 12 ? kFit : 12) : (kCnt < 12 ? kCnt : 12);
-    const bool nt = (kSkinnyNt_() == 1 && T <= 32) || kSkinnyNt_() == 2;
+    // non-temporal W pieces (skinny_nt: 0 never, 2 always, 1 = by rule): up to 32 tokens, and on the large matrices at any length -- per
+    // launch, cold weights, plain / nt at 64 and 128 tokens (tools/skinny_nt_probe.py): Mistral-7B gate/up 54.7 / 50.9, 62.9 / 58.2 us,
+    // down_proj 27.2 / 26.0, 37.0 / 36.6; the 16-24 Mi-element matrices a tie; TinyLlama's (4-22 Mi) +1 ... +26 % (short launches:
+    // the higher first-byte latency of the streaming path shows).  Whole Mistral-7B prefills 33-64 tokens -5 %, 96-128 -2.6 %.
+    const bool nt = (kSkinnyNt_() == 1 && (T <= 32 || N * K >= ((int64_t)32 << 20))) || kSkinnyNt_() == 2;
     if constexpr (BM >= 64) {
         // wave rows: 2 for the 4-column workgroups; the narrow (2-column) strips of small matrices get 4 (128 tokens, gate/up
         // pairs: 24 staging instructions per K tile over 8 waves instead of 2) or 2 where the instruction count divides
