@@ -2,7 +2,7 @@
 // (v_mfma_f32_32x32x2_f32: exact fp32 products, the sum over k an fmaf chain in k order -- bit for bit what gemm_generic_kernel's
 // scalar fmaf loop computes, at the matrix pipe's 64 FLOP / clk / SIMD with two operand VGPRs per 2048 FMAs instead of one per FMA).
 //
-// The fp32 mode is the one the literal parity bar is stated on (logits within 1e-3 of the oracle, identical greedy ids:
+// The fp32 mode is the one the literal parity bar is stated on (logits within 1e-3 of the CPU reference, identical greedy ids:
 // tests/test_gpu_literal_configs.py); its 512-token Mistral-7B prefill spent 238 of 243 ms in the 64 x 64 VALU kernel at 30 TFLOP/s.
 //
 // Tile BM x 128 (BM = 128, or 64 where 128-row tiles would not fill the chip), BK = 16, four waves as 2 x 2, each (BM / 2) x 64 =

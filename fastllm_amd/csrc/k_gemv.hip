@@ -56,8 +56,12 @@ constexpr bool kGemvDot2 = FL_GEMV_DOT2 != 0;
 #endif
 constexpr bool kGemvPipe = FL_GEMV_PIPE != 0 && kGemvDot2;
 
+#ifndef FL_GEMV_PLAIN_LOADS
+#define FL_GEMV_PLAIN_LOADS 0              // (timing experiment: the weight stream through plain instead of non-temporal loads)
+#endif
 __device__ inline void load_raw_nt(const bf16_t *p, RawChunk<bf16_t> &r) {
-    r.v[0] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(p));
+    if constexpr (FL_GEMV_PLAIN_LOADS != 0) r.v[0] = *reinterpret_cast<const uint4v *>(p);
+    else r.v[0] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(p));
 }
 __device__ inline void load_raw_nt(const float *p, RawChunk<float> &r) {
     r.v[0] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(p));
