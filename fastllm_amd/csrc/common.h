@@ -35,7 +35,7 @@ enum TuneKey {
     TK_GEMM_ROPE_4W,   // long prompts (>= 768 tokens): the QKV projection's RoPE / bias / KV append in the four-wave kernel's epilogue (0: fp32 output + rope_kv_append)
     TK_GEMM_F32_MFMA,   // fp32 mode: prompt GEMMs on v_mfma_f32_32x32x2_f32 (k_gemm_f32.hip); 0: the 64 x 64 VALU kernel
     TK_W14_NT,   // 256 x 224 kernel: W pieces non-temporal (1), plain (0), -1: up to 512 tokens (two row tiles per W panel)
-    TK_H4_NT,   // 128 x 256 kernel: W pieces non-temporal (1), plain (0), -1: at 192-256 tokens (a W panel read by at most two row tiles; also the 256 x 128 / 256 x 256 kernels' single row tile)
+    TK_H4_NT,   // 128 x 256 kernel: W pieces non-temporal (1), plain (0), -1: at 176-256 tokens (a W panel read by at most two row tiles; also the 256 x 128 / 256 x 256 kernels' single row tile)
     TK_H4_SPLIT,   // 0: as the rule; 1..4: K slices it uses (probes, tests)
     TK_H4_PF,   // its L2 prefetch of the W panel: K tiles ahead + 256 x lanes per 128-byte line (0 lanes: off; measured neutral)
     TK_H4_WAIT_US,   // how long an early K slice waits for the others before it leaves its blocks to the last one

@@ -631,7 +631,7 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
                          bias, y, (int)T, (int)N, (int)K, epi, tiles_m, tiles_n, row_scale, ksplit, (int)ldc, sk, re, group_m, L.rsp, RopeEpi{}));
         return fixup();
     }
-    const int wnt8 = !streamk && tiles_m == 1 && T >= 192 && tune(TK_H4_NT) != 0;   // one row tile: the W panels are read once -- non-temporal
+    const int wnt8 = !streamk && tiles_m == 1 && T >= 176 && tune(TK_H4_NT) != 0;   // one row tile: the W panels are read once -- non-temporal
     const bool stamp = env_str("FL_8P_STAMPS") != nullptr;           // diagnostics only: synchronous, appends one record per launch
     auto kern = streamk ? (stamp ? gemm_8p_kernel<true, true> : gemm_8p_kernel<false, true>) : (stamp ? gemm_8p_kernel<true, false> : gemm_8p_kernel<false, false>);
     FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), P_LDS));

@@ -597,12 +597,12 @@ int launch_gemm_h4(Launcher &L, const void *W, const void *x, const float *bias,
     H4Space ws{nullptr, nullptr};
     int set = 0;
     if (ksplit > 1) FL_TRY(h4_space(L.stream, (size_t)tiles_m * tiles_n * ksplit, &ws, &set));
-    // W pieces non-temporal (h4_nt: 1 always, 0 never, -1 at 192-256 tokens: two full row tiles per panel): an HBM stream through LDS-DMA
+    // W pieces non-temporal (h4_nt: 1 always, 0 never, -1 at 176-256 tokens: two nearly full row tiles per panel): an HBM stream through LDS-DMA
     // is 15 % faster with nt (tools/micro/ingest_bench.hip) and does not push the activations out of the caches, but the second
     // reader of a panel then misses more often.  Whole prefills, plain / nt: Mistral-7B 200 / 256 tokens 6.40 / 6.24, 6.58 / 6.42 ms;
     // 300 / 384 / 512 / 640 tokens (3-5 row tiles) x 1.013 / 1.007 / 1.009 / 1.050; Qwen2-7B 384-640 x 1.04-1.06
     const int nt_mode = tune(TK_H4_NT);
-    const bool wnt = nt_mode == 1 || (nt_mode < 0 && T >= 192 && T <= 256);   // (130-144 tokens x 1.02-1.03 with nt, 160 a tie, 200-256 x 0.98)
+    const bool wnt = nt_mode == 1 || (nt_mode < 0 && T >= 176 && T <= 256);   // (Mistral-7B: 130-150 tokens x 1.02-1.03 with nt, 160 a tie, 176-256 x 0.98-0.96; Qwen2-7B +-1 %)
     auto kern = wnt ? (ksplit == 1 ? gemm_h4_kernel<1, true> : ksplit == 2 ? gemm_h4_kernel<2, true> : ksplit == 3 ? gemm_h4_kernel<3, true> : gemm_h4_kernel<4, true>)
                     : (ksplit == 1 ? gemm_h4_kernel<1, false> : ksplit == 2 ? gemm_h4_kernel<2, false> : ksplit == 3 ? gemm_h4_kernel<3, false> : gemm_h4_kernel<4, false>);
     static_assert(H4_MAXS == 4, "one instantiation per slice count");

@@ -494,7 +494,7 @@ static int launch_gemm_mfma_impl(Launcher &L, const void *W, const void *x, cons
         Launcher L2 = L; L2.tag = tag2;
         return L2.launch(KC_GEMM_MFMA, bytes2, 2.0 * T * N * K, gemm_mfma256_kernel, dim3((unsigned)(tm2 * tn2), (unsigned)ksplit), dim3(512),
                         lds2, (const bf16_t *)W, (const bf16_t *)x, bias, y, (int)T, (int)N, (int)K, epi, tm2, tn2, row_scale, ksplit, (int)ldc,
-                        (int)(tune(TK_H4_NT) == 1 || (tune(TK_H4_NT) < 0 && tm2 == 1 && T >= 192)));
+                        (int)(tune(TK_H4_NT) == 1 || (tune(TK_H4_NT) < 0 && tm2 == 1 && T >= 176)));
     }
     const int tiles_m = (int)((T + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
     if (ksplit > 1 && bias) FL_FAIL(FL_ERR_BAD_ARGUMENT, "split-K GEMM cannot add a bias");

@@ -242,7 +242,11 @@ bool gemm_w14_plan(int64_t T, int64_t N, int64_t K, int epi) {
     if ((double)std::max(T, N) * (double)K * 2.0 + (double)K * 2.0 + 8192.0 >= 4294967296.0) return false;     // 32-bit lane offsets
     if (mode >= 2) return true;
     const int64_t tm = (T + 255) / 256, t224 = tm * (N / W14_BN), t256 = tm * ((N + 255) / 256);
-    return N >= 8192 && (t224 + 255) / 256 <= (t256 + 255) / 256 && t224 % 256 == 0;
+    if (N < 8192 || (t224 + 255) / 256 > (t256 + 255) / 256) return false;
+    // ... and the 224-column grid whole rounds -- or three row tiles below 768 tokens, where the 256-column grid would run on the
+    // eight-wave kernel (whole Mistral-7B prefills, 256- / 224-column gate/up: 513 tokens 11.03 / 10.73 ms, 600 11.65 / 11.32,
+    // 700 12.30 / 12.15; against the four-wave kernel from 768 tokens on it loses: 768 12.51 / 12.67, 1025 16.79 / 17.09)
+    return t224 % 256 == 0 || (tm == 3 && T < 768);
 }
 
 int launch_gemm_w14(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,

@@ -372,7 +372,7 @@ def test_mid_prompt_in_launch_slices_equal_the_slab_path(env, name, T):
     gm.close()
 
 
-@pytest.mark.parametrize("T", [512, 300, 2048])
+@pytest.mark.parametrize("T", [512, 300, 2048, 600])
 def test_gate_up_on_224_column_tiles_equals_the_256_column_grid(env, T):
     """Mistral-7B's fused gate/up matrix (28672 rows = 128 tiles of 224 = 112 of 256) on the 256 x 224 kernel (k_gemm_w14.hip) where
     that grid fills the chip: against the 256 x 256 grid, full width, 2 layers, prefill logits + a decode step.  Same K order, same
