@@ -12,6 +12,8 @@
 // one barrier per K tile.  A lane's A / B operand of k-step s is element [2 s + (lane >> 5)][lane & 31] of the tile: natural k order.
 // Epilogues as gemm_generic_kernel (row scale, bias; SiLU(gate) * up on the interleaved 16-column groups -- a 32-column block holds a
 // gate group in lanes 0-15 and its up group in lanes 16-31: one shuffle).
+// Measured (Mistral-7B, 512 tokens): gate/up on 128-row tiles 109 TFLOP/s, the 64-row grids (256-384 workgroups) 82-84 -- neither 32-deep K
+// tiles nor eight waves per workgroup moved the latter (80 / 83); below ~128 tokens the grids are a fraction of the chip (no K slices here).
 #include <algorithm>
 
 #include "kernels.h"
@@ -120,7 +122,9 @@ int launch_gemm_f32_mfma(Launcher &L, const void *W, const void *x, const float 
     if (epi == EPI_GATEUP && (N % 32 || bias)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_f32_mfma: gate/up rows in groups of 32, no bias");
     const int64_t tn = (N + 127) / 128, t128 = ((T + 127) / 128) * tn;
     const double bytes = ((double)N * K + (double)T * K) * 4.0;
-    Launcher LL = L; LL.tag = "f32mfma";
+    char tag[40];
+    snprintf(tag, sizeof tag, "f32mfma,%lldx%lld", (long long)N, (long long)K);
+    Launcher LL = L; LL.tag = tag;
     // 128-row tiles once they give every CU two workgroups (two waves per SIMD hide the global loads), else 64-row tiles
     if ((T + 63) / 64 > 65535) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_f32_mfma: too many row tiles");
     if (t128 >= 512)
