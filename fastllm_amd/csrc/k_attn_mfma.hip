@@ -464,13 +464,17 @@ typedef unsigned short ushort4v __attribute__((ext_vector_type(4)));
 // key tiles -- a step stages two tiles -- and meet through LDS at the end: the causal chain of the longest block, which sets the
 // launch's duration when there are too few (block, kv head) items for the snake to even out, is half as long, and the 32-token
 // blocks make twice as many items.  (Mistral-7B T = 2048: 64 blocks x 8 kv heads = 512 items, two balanced rounds.)
-template <int D, int NW, bool KS2>
+// KSF = 4 (since round 4): FOUR waves per (head, token block) on every fourth key tile, two ring slots of four tiles -- with subgroups of
+// two query heads (gsub = 2) the items double again: prompts below ~2048 tokens, whose (block, kv head) items are too few for the
+// snake, halve the longest block's chain once more and fill the chip (Mistral-7B T = 1024: 512 items instead of 256).
+template <int D, int NW, int KSF>
 __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kc,
                                                                  const bf16_t *__restrict__ vT, const StepState *__restrict__ st,
                                                                  bf16_t *__restrict__ out, int T, int H, int Hkv, int seq_alloc,
                                                                  float scale_log2e, int window, int paired, int gsub) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // 3 x KSF x (K tile | V^T tile)
-    constexpr int TILE = 2 * 32 * D * 2, KSF = KS2 ? 2 : 1, SLOT = KSF * TILE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // NSLOT x KSF x (K tile | V^T tile)
+    constexpr bool KS2 = KSF > 1;                                            // (the key-split form: partner waves meet through LDS)
+    constexpr int TILE = 2 * 32 * D * 2, SLOT = KSF * TILE, NSLOT = KSF == 4 ? 2 : 3;
     constexpr int NK = D / 16, NV = D / 16, NI = NK + NV;                  // 1-KiB wave-instructions per tile
     constexpr int PER = (NI + NW - 1) / NW;                                // issued by every wave (wrapping: duplicates are benign)
     constexpr int CPR = D / 8;
@@ -574,17 +578,18 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *_
         for (int f = 0; f < KSF; f++) stage(kstart + 32 * min(s_ * KSF + f, ntiles - 1), slot + f * TILE);
     };
     stage_step(0, lds);
-    if (nsteps > 1) stage_step(1, lds + SLOT);
+    if (NSLOT == 3 && nsteps > 1) stage_step(1, lds + SLOT);
 
     for (int sidx = 0; sidx < nsteps; sidx++) {
-        if (sidx + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * KSF) : "memory");
+        // three slots: two steps in flight, the younger one's loads stay outstanding; two slots (KSF = 4): one step in flight
+        if (NSLOT == 3 && sidx + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * KSF) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (sidx + 2 < nsteps) stage_step(sidx + 2, lds + ((sidx + 2) % 3) * SLOT);
+        if (sidx + NSLOT - 1 < nsteps) stage_step(sidx + NSLOT - 1, lds + ((sidx + NSLOT - 1) % NSLOT) * SLOT);
         const int jt = sidx * KSF + ksub;                                   // this wave's key tile of the step
         const int kbase = kstart + 32 * jt;
         if (jt >= ntiles || !(kbase + 32 > wstart && kbase < wend)) continue;   // wave-uniform
-        const unsigned char *kt = lds + (sidx % 3) * SLOT + ksub * TILE, *vt = kt + 32 * D * 2;
+        const unsigned char *kt = lds + (sidx % NSLOT) * SLOT + ksub * TILE, *vt = kt + 32 * D * 2;
 
         // all K fragments are requested before the first MFMA (one register set per fragment: a shared one would
         // expose the LDS latency D/16 times per tile), the V fragments right behind them
@@ -668,8 +673,10 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *_
     if constexpr (KS2) {
         // the two waves of a (head, token block) meet: the odd one hands (m, l, O) over through the ring's memory
         __builtin_amdgcn_s_barrier();                                       // every wave is done with the key tiles
-        float *mx = reinterpret_cast<float *>(lds) + (size_t)(tok_sub * Gs + wave % Gs) * (64 * (D / 2 + 2));
-        if (wave_on && ksub == 1) {
+        constexpr int MXF = 64 * (D / 2 + 2);                               // floats of one partner's (m, l, O)
+        float *mx0 = reinterpret_cast<float *>(lds) + (size_t)(tok_sub * Gs + wave % Gs) * (KSF - 1) * MXF;
+        if (wave_on && ksub >= 1) {
+            float *mx = mx0 + (size_t)(ksub - 1) * MXF;
             mx[lane] = mrow; mx[64 + lane] = lrow;
 #pragma unroll
             for (int db = 0; db < D / 32; db++)
@@ -681,14 +688,19 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *_
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wave_on && ksub == 0) {
-            const float m1 = mx[lane], l1 = mx[64 + lane];
-            const float mn = fmaxf(mrow, m1);
-            const float a0 = mrow == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mrow - mn), a1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m1 - mn);
-            lrow = lrow * a0 + l1 * a1;
+#pragma nounroll
+            for (int p = 0; p < KSF - 1; p++) {                             // partners in key-tile order: the sum does not depend on timing
+                const float *mx = mx0 + (size_t)p * MXF;
+                const float m1 = mx[lane], l1 = mx[64 + lane];
+                const float mn = fmaxf(mrow, m1);
+                const float a0 = mrow == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mrow - mn), a1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m1 - mn);
+                lrow = lrow * a0 + l1 * a1;
+                mrow = mn;
 #pragma unroll
-            for (int db = 0; db < D / 32; db++)
+                for (int db = 0; db < D / 32; db++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) O[db][r] = O[db][r] * a0 + mx[(2 + db * 16 + r) * 64 + lane] * a1;
+                    for (int r = 0; r < 16; r++) O[db][r] = O[db][r] * a0 + mx[(2 + db * 16 + r) * 64 + lane] * a1;
+            }
         }
     }
     const float ltot = lrow + __shfl_xor(lrow, 32, 64);
@@ -710,7 +722,7 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill32_kernel(const bf16_t *_
     }
 }
 
-template <int D, int NW, bool KS2 = false>
+template <int D, int NW, int KSF = 1>
 static int launch_pf32(Launcher &L, const void *q, const void *k_cache, const void *v_cache_T, const StepState *st, void *out,
                        int64_t T, int64_t H, int64_t Hkv, int64_t seq_alloc, float scale, int64_t window, int TB, int paired, int gsub = 0) {
     const int64_t nb = (T + 32 * TB - 1) / (32 * TB);
@@ -729,11 +741,11 @@ static int launch_pf32(Launcher &L, const void *q, const void *k_cache, const vo
         }
         grid = dim3((unsigned)cus, 1);
     }
-    const size_t lds = 3 * (size_t)(2 * 32 * D * 2) * (KS2 ? 2 : 1);
+    const size_t lds = (KSF == 4 ? 2 : 3) * (size_t)(2 * 32 * D * 2) * KSF;
     const double flops = 2.0 * (double)T * T * H * D;
-    Launcher LL = L; LL.tag = KS2 ? "32row,ks2" : "32row";
-    FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(attn_prefill32_kernel<D, NW, KS2>), lds));
-    return LL.launch(KC_ATTN_PREFILL, 0, flops, attn_prefill32_kernel<D, NW, KS2>, grid, dim3(NW * 64), lds, (const bf16_t *)q,
+    Launcher LL = L; LL.tag = KSF == 4 ? "32row,ks4" : KSF == 2 ? "32row,ks2" : "32row";
+    FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(attn_prefill32_kernel<D, NW, KSF>), lds));
+    return LL.launch(KC_ATTN_PREFILL, 0, flops, attn_prefill32_kernel<D, NW, KSF>, grid, dim3(NW * 64), lds, (const bf16_t *)q,
                      (const bf16_t *)k_cache, (const bf16_t *)v_cache_T, st, (bf16_t *)out, (int)T, (int)H, (int)Hkv, (int)seq_alloc,
                      scale * 1.44269504088896340736f, (int)window, paired, gsub);
 }
@@ -750,9 +762,12 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
     // (with wave pairs from 640 tokens for G = 1, 2, 4: Mistral-7B T = 768 31.9 -> 24.8 us per layer, T = 512 a tie, below slower;
     // from 256 tokens for the groups dealt as subgroups of four heads: Qwen2-7B T = 512 23.2 -> 18.3, TinyLlama 16.5 -> 13.2, T = 256 a tie)
     const int pf32_min_env = tune(TK_ATTN_PF32_MIN_T);
-    const int pf32_min_t = pf32_min_env > 0 ? pf32_min_env : ((G == 1 || G == 2 || G == 4) ? 640 : (G > 4 ? 256 : 1024));
+    // (since round 4, with four waves per (head, block) up to 576 tokens: from 352 tokens for G = 1, 2, 4 as well)
+    const int pf32_min_t = pf32_min_env > 0 ? pf32_min_env : ((G == 1 || G == 2 || G == 4) ? 352 : (G > 4 ? 256 : 1024));
     const int force = g_prefill_force.load();                        // fl_op_attention pins one kernel (unit tests)
-    if ((force == 3 || (force == 0 && T >= pf32_min_t)) && scale > 0.f) {
+    // (577-639 tokens, G = 1, 2, 4: the four-wave form ends at 576 tokens, the wave pairs pay from 640: the 16-row kernel in between)
+    const bool gap = pf32_min_env <= 0 && (G == 1 || G == 2 || G == 4) && T > 576 && T < 640;
+    if ((force == 3 || (force == 0 && T >= pf32_min_t && !gap)) && scale > 0.f) {
         // waves per workgroup: 8 (G = 1, 2, 4), 6 (G = 3), else G.  Paired (balanced) grids win as soon as they cover
         // ~3/4 of the chip -- Mistral-7B per layer: T = 3072 134 us paired (192 workgroups) vs 197 unpaired, T = 4096
         // 177 vs 305, T = 8192 681 vs 693; T = 2048 (128 paired workgroups) 98 vs 85.  4-wave workgroups (half the K/V
@@ -766,13 +781,29 @@ int launch_attn_prefill_mfma(Launcher &L, const void *q, const void *k_cache, co
         int gsub = 0;
         if (!ks2 && G > 4 && (ks2_mode >= 0 ? ks2_mode != 0 : ((T + 31) / 32) * Hkv < 2 * 256)) { ks2 = true; gsub = 4; TB = 2; }
         if (ks2) TB /= 2;
+        // ... and when even the wave pairs leave fewer than two rounds of items: FOUR waves per (head, block), groups of four or more
+        // heads dealt two heads at a time -- twice the items again, the longest block's chain a quarter (attn_pf32_ks2 = 4 forces it)
+        int ksf = ks2 ? 2 : 1;
+        if (ks2 && G != 3) {
+            const int64_t items2 = ((T + 32 * TB - 1) / (32 * TB)) * Hkv * (gsub ? (G + gsub - 1) / gsub : 1);
+            // Whole prefills, wave pairs / four waves: Mistral-7B 384 / 512 tokens x 0.994 / 0.988 (against the 16-row kernel it replaces
+            // there), 600-1536 a tie, 2048 x 1.019; Qwen2-7B 257-512 x 0.986-0.993, 640-1024 a tie; TinyLlama 300 / 512 x 0.986 / 0.972,
+            // 640 a tie: on up to 576 tokens.  (Per launch at 512 tokens, Mistral-7B: 16-row kernel 18.6 us, wave pairs 19.2, four waves 15.6.)
+            if (ks2_mode == 4 || (ks2_mode < 0 && items2 < 2 * 256 && T <= 576)) {
+                ksf = 4;
+                gsub = G >= 4 ? 2 : 0;
+                TB = 8 / (gsub ? gsub : G) / 4;
+            }
+        }
         const int64_t nb = (T + 32 * TB - 1) / (32 * TB);
         const int64_t nhs = Hkv * (gsub ? (G + gsub - 1) / gsub : 1);
         const int force_pair = tune(TK_ATTN_PF32_PAIRED);
         // two rounds or more of (block, kv head) items: persistent workgroups, snake order (launch_pf32)
         const int paired = force_pair >= 0 ? force_pair : (nb * nhs >= 2 * 256 ? 2 : ((nb + 1) / 2 * nhs >= 180 ? 1 : 0));
-        if (ks2 && d == 128) return launch_pf32<128, 8, true>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired, gsub);
-        if (ks2 && d == 64) return launch_pf32<64, 8, true>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired, gsub);
+        if (ksf == 4 && d == 128) return launch_pf32<128, 8, 4>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired, gsub);
+        if (ksf == 4 && d == 64) return launch_pf32<64, 8, 4>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired, gsub);
+        if (ks2 && d == 128) return launch_pf32<128, 8, 2>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired, gsub);
+        if (ks2 && d == 64) return launch_pf32<64, 8, 2>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired, gsub);
 #define FL_PF32(DD, WW) if (d == DD && NW == WW) return launch_pf32<DD, WW>(L, q, k_cache, v_cache_T, st, out, T, H, Hkv, seq_alloc, scale, window, TB, paired);
         FL_PF32(128, 8) FL_PF32(128, 7) FL_PF32(128, 6) FL_PF32(128, 5) FL_PF32(64, 8) FL_PF32(64, 7) FL_PF32(64, 6) FL_PF32(64, 5)
 #undef FL_PF32

@@ -106,11 +106,15 @@ def test_baseline_shapes_and_the_rescale_branch(fa, d, H, Hkv):
 def test_prefill32_key_split(fa, monkeypatch, d, H, Hkv, T, s_past, window):
     """KS2: two waves per (head, 32-token block) on alternate key tiles, merged through LDS (what prompts of ~1-4 k tokens
     get when there are too few blocks to balance): odd and even tile counts, a single tile, cached prefix, window, a ragged
-    last block; T = 2100 with 8 kv heads is 528 items: the snake's second round as well."""
-    monkeypatch.setenv("FL_ATTN_PF32_KS2", "1")
+    last block; T = 2100 with 8 kv heads is 528 items: the snake's second round as well.  Then the same with FOUR waves per
+    (head, block) on every fourth key tile (two ring slots of four tiles, groups of >= 4 heads dealt two heads at a time,
+    three partners merged in key-tile order): tile counts 1 .. 3 below the wave count leave partner waves without a tile."""
     q, k, v = make(T, s_past, H, Hkv, d, seed=T + s_past + d + H, spike=T > 1000)
-    got = fa.op_attention(q, k, v, s_past, H, Hkv, d, window=window, kernel=3)
-    check(got, reference(q, k, v, s_past, H, Hkv, d, window), "prefill32 ks2 d=%d G=%d T=%d past=%d w=%d" % (d, H // Hkv, T, s_past, window))
+    ref = reference(q, k, v, s_past, H, Hkv, d, window)
+    for ks in (1, 4):
+        monkeypatch.setenv("FL_ATTN_PF32_KS2", str(ks))
+        got = fa.op_attention(q, k, v, s_past, H, Hkv, d, window=window, kernel=3)
+        check(got, ref, "prefill32 ks%d d=%d G=%d T=%d past=%d w=%d" % (2 if ks == 1 else 4, d, H // Hkv, T, s_past, window))
 
 
 _SCHED_REF = {}
