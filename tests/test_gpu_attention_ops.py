@@ -109,6 +109,8 @@ def test_prefill32_key_split(fa, monkeypatch, d, H, Hkv, T, s_past, window):
     last block; T = 2100 with 8 kv heads is 528 items: the snake's second round as well.  Then the same with FOUR waves per
     (head, block) on every fourth key tile (two ring slots of four tiles, groups of >= 4 heads dealt two heads at a time,
     three partners merged in key-tile order): tile counts 1 .. 3 below the wave count leave partner waves without a tile."""
+    if T > 2000 and (H, Hkv) not in ((32, 8), (28, 4)):
+        pytest.skip("the 2100-token case (the snake's second round) runs on the two benchmark head layouts: its numpy reference is 3.5 s a case")
     q, k, v = make(T, s_past, H, Hkv, d, seed=T + s_past + d + H, spike=T > 1000)
     ref = reference(q, k, v, s_past, H, Hkv, d, window)
     for ks in (1, 4):
