@@ -444,6 +444,40 @@ def test_long_prompt_rope_in_the_qkv_epilogue_equals_the_rope_launch(env, name, 
     gm.close()
 
 
+def test_selection_thresholds_from_both_sides(env):
+    """The prefill's kernel-selection thresholds (attention forms at 352 / 576 / 640, the 128 x 256 kernel's 256 / 640, the 224-column
+    grid's 512 / 768, the non-temporal rule's 176, the RoPE epilogue's 768, ...) from both sides: the default selection against the
+    conservative one (round-4 kernels and rules off) on the same prompt, Mistral-7B width, 2 layers, prefill logits + a decode step.
+    tools/policy_boundaries.py is the long form (three models, 39 lengths; profiles/r04/policy_boundaries.txt)."""
+    torch, fa, bench = env
+    from fastllm_amd.configs import MODEL_CONFIGS
+    cfg = dict(MODEL_CONFIGS["mistral-7b"], num_hidden_layers=2)
+    wts = bench.synth_device_weights(torch, cfg, torch.device("cuda", 0), seed=3)
+    gm = fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16")
+    del wts
+    torch.cuda.empty_cache()
+    off = {"gemm_h4": 0, "gemm_w14": 0, "gemm_rope_4w": 0, "attn_pf32_ks2": 1, "attn_pf32_min_t": 640, "h4_nt": 0, "w14_nt": 0, "skinny_nt": 0, "rs_lazy": 0}
+    rs = np.random.RandomState(7)
+    try:
+        for T in (175, 176, 256, 257, 351, 352, 512, 513, 576, 577, 639, 640, 641, 767, 768, 1025):
+            ids = rs.randint(0, cfg["vocab_size"], size=T + 1).astype(np.uint32)
+            out = []
+            for conservative in (False, True):
+                fa.tune("reload_env", 0)
+                if conservative:
+                    for k, v in off.items():
+                        fa.tune(k, v)
+                c = gm.new_cache(T + 8)
+                out.append((gm.forward(c, ids[:T], 0), gm.forward(c, ids[T:T + 1], T)))
+                c.close()
+            for k in (0, 1):
+                a, b = out[0][k], out[1][k]
+                assert np.linalg.norm(a - b) <= 1.5e-2 * np.linalg.norm(b), "T=%d %s: rel L2 %.2e" % (T, ("prefill", "decode")[k], np.linalg.norm(a - b) / np.linalg.norm(b))
+    finally:
+        fa.tune("reload_env", 0)
+    gm.close()
+
+
 @pytest.mark.parametrize("T", [512, 640])
 def test_mid_prompt_small_hidden_size_on_the_in_launch_kernel(env, T):
     """TinyLlama-1.1B's widths (h = 2048, d = 64, I = 5632) at 257-640 tokens: gate/up without slices, QKV + RoPE (two 64-wide heads
