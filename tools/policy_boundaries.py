@@ -12,10 +12,13 @@ OFF = {"gemm_h4": 0, "gemm_w14": 0, "gemm_rope_4w": 0, "attn_pf32_ks2": 1, "attn
 TS = [2, 16, 17, 32, 33, 64, 65, 128, 129, 175, 176, 191, 192, 255, 256, 257, 351, 352, 511, 512, 513, 576, 577, 639, 640, 641, 703, 704, 767, 768, 769,
       1023, 1024, 1025, 1535, 1536, 2040, 2047]
 worst = 0.0
+TP = int(os.environ.get("PB_TP", "1"))                  # > 1: FL_TP_EMULATED ranks (every rank's shard on this GPU: the per-rank shapes)
+if os.environ.get("PB_TS"):
+    TS = [int(t) for t in os.environ["PB_TS"].split(",")]
 for name in sys.argv[1:] or ["mistral-7b", "qwen2-7b", "tinyllama-1.1b"]:
     cfg = dict(MODEL_CONFIGS[name], num_hidden_layers=2)
     wts = bench.synth_device_weights(torch, cfg, torch.device("cuda", 0), seed=3)
-    gm = fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16")
+    gm = fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16") if TP == 1 else fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16", tp_mode=fa.binding.TP_EMULATED, tp_size=TP)
     del wts; torch.cuda.empty_cache()
     rs = np.random.RandomState(7)
     for T in TS:
