@@ -8,7 +8,11 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <array>
 #include <memory>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 namespace fl {
 
@@ -16,6 +20,21 @@ namespace fl {
 constexpr size_t kCommFlagBytes = 4096;
 static int comm_connect_impl(Model *m, const void *handles);
 static int comm_export_impl(Shard &sh, void *handle_out);
+
+// Handles exported by models of THIS process.  A process may host several ranks of one group (tests and rehearsals of an 8-rank
+// group on a one-GPU box, which admits fewer GPU processes than that: 4 processes x 2 ranks); hipIpcOpenMemHandle does not open
+// a handle in the process that exported it, so such a peer is reached through its plain device pointer instead.
+static std::mutex g_exported_mu;
+static std::vector<std::pair<std::array<char, FL_IPC_HANDLE_BYTES>, void *>> g_exported;
+static void *comm_exported_here(const void *handle) {
+    std::lock_guard<std::mutex> lock(g_exported_mu);
+    for (auto &e : g_exported) if (!memcmp(e.first.data(), handle, FL_IPC_HANDLE_BYTES)) return e.second;
+    return nullptr;
+}
+void comm_forget(void *local) {
+    std::lock_guard<std::mutex> lock(g_exported_mu);
+    g_exported.erase(std::remove_if(g_exported.begin(), g_exported.end(), [&](auto &e) { return e.second == local; }), g_exported.end());
+}
 
 int comm_alloc(Model *m, Shard &sh) {
     PeerComm &pc = sh.pc;
@@ -67,6 +86,11 @@ static int comm_export_impl(Shard &sh, void *handle_out) {
     FL_HIP(hipIpcGetMemHandle(&h, sh.pc.local));
     memset(handle_out, 0, FL_IPC_HANDLE_BYTES);
     memcpy(handle_out, &h, sizeof h);
+    comm_forget(sh.pc.local);
+    std::array<char, FL_IPC_HANDLE_BYTES> key;
+    memcpy(key.data(), handle_out, FL_IPC_HANDLE_BYTES);
+    std::lock_guard<std::mutex> lock(g_exported_mu);
+    g_exported.emplace_back(key, sh.pc.local);
     return FL_OK;
 }
 
@@ -84,6 +108,20 @@ static int comm_connect_impl(Model *m, const void *handles) {
     FL_HIP(hipSetDevice(sh.device));
     for (int r = 0; r < m->tp; r++) {
         if (r == sh.rank) { comm_set_entry(pc, r, pc.local); continue; }
+        if (void *here = comm_exported_here((const char *)handles + (size_t)r * FL_IPC_HANDLE_BYTES)) {
+            // a rank hosted by this same process (on this same GPU or a peer-accessible one): no mapping to open or close
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, here) == hipSuccess) {
+                if (at.device == sh.device) pc.shares_device = true;
+                else {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(at.device, 0);
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); FL_FAIL(FL_ERR_HIP, "no peer access to rank %d's GPU: %s", r, hipGetErrorString(pe)); }
+                    (void)hipGetLastError();
+                }
+            } else (void)hipGetLastError();
+            comm_set_entry(pc, r, here);
+            continue;
+        }
         hipIpcMemHandle_t h;
         memcpy(&h, (const char *)handles + (size_t)r * FL_IPC_HANDLE_BYTES, sizeof h);
         void *p = nullptr;

@@ -199,6 +199,7 @@ void debug_inject(const char *site);     // FL_DEBUG_THROW fault injection (test
 Launcher make_launcher(Model *m, Shard &sh);
 // comm.hip: inbox / LL region of one shard, its table entries, and the group-level steps
 int comm_alloc(Model *m, Shard &sh);
+void comm_forget(void *local);                         // a destroyed shard's inbox leaves the table of handles exported by this process
 void comm_set_entry(PeerComm &pc, int r, void *base);
 int comm_ll_publish(Model *m, Shard &sh);              // every entry is set: hand the fused all-reduce's table to the device
 int comm_bootstrap_over_rccl(Model *m);                // all-gather the handles through RCCL, connect, self-test, vote

@@ -266,7 +266,7 @@ Model::~Model() {
         if (s.comm_stream) { (void)hipStreamSynchronize(s.comm_stream); (void)hipStreamDestroy(s.comm_stream); }
         for (auto &e : s.ev) if (e) (void)hipEventDestroy(e);
         for (void *mp : s.pc.mapped) if (mp) (void)hipIpcCloseMemHandle(mp);
-        if (s.pc.local) (void)hipFree(s.pc.local);
+        if (s.pc.local) { comm_forget(s.pc.local); (void)hipFree(s.pc.local); }
         if (s.pc.epoch) (void)hipFree(s.pc.epoch);
         if (s.pc.ll_dev) (void)hipFree(s.pc.ll_dev);
         if (s.pc.err) (void)hipHostFree(s.pc.err);

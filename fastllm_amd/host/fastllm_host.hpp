@@ -157,6 +157,13 @@ struct JsonFlat {                             // top-level object: numbers, stri
         return v;
     }
     std::optional<double> opt(const std::string &k) const { return has(k) ? std::optional<double>(num(k)) : std::nullopt; }
+    // serde into usize: a non-negative integer; negative, fractional or out-of-range numbers are a type error, never a cast
+    size_t usize(const std::string &k) const {
+        const double v = num(k);
+        if (!(v >= 0.0) || !(v <= 9007199254740992.0) || (double)(uint64_t)v != v) throw Error(FL_ERR_BAD_CONFIG, "invalid value for field `" + k + "`: expected usize");
+        return (size_t)v;
+    }
+    std::optional<size_t> opt_usize(const std::string &k) const { return has(k) ? std::optional<size_t>(usize(k)) : std::nullopt; }
     std::optional<std::string> str(const std::string &k) const {
         auto it = raw.find(k);
         if (it == raw.end() || it->second.empty() || it->second[0] != '"') return std::nullopt;
@@ -178,16 +185,16 @@ struct BaseModelConfig {                      // config.rs:6-18 (also llama::Con
     static BaseModelConfig from_json(const std::string &text) {          // serde_json::from_str (huggingface.rs:78-79)
         detail::JsonFlat j(text);
         BaseModelConfig c;
-        c.hidden_size = (size_t)j.num("hidden_size");
-        c.intermediate_size = (size_t)j.num("intermediate_size");
-        c.vocab_size = (size_t)j.num("vocab_size");
-        c.num_hidden_layers = (size_t)j.num("num_hidden_layers");
-        c.num_attention_heads = (size_t)j.num("num_attention_heads");
-        if (auto v = j.opt("num_key_value_heads")) c.num_key_value_heads = (size_t)*v;
+        c.hidden_size = j.usize("hidden_size");
+        c.intermediate_size = j.usize("intermediate_size");
+        c.vocab_size = j.usize("vocab_size");
+        c.num_hidden_layers = j.usize("num_hidden_layers");
+        c.num_attention_heads = j.usize("num_attention_heads");
+        c.num_key_value_heads = j.opt_usize("num_key_value_heads");
         c.rms_norm_eps = j.num("rms_norm_eps");
         c.rope_theta = j.opt("rope_theta");
-        if (auto v = j.opt("max_position_embeddings")) c.max_position_embeddings = (size_t)*v;
-        if (auto v = j.opt("sliding_window")) c.sliding_window = (size_t)*v;
+        c.max_position_embeddings = j.opt_usize("max_position_embeddings");
+        c.sliding_window = j.opt_usize("sliding_window");
         c.torch_dtype = j.str("torch_dtype");
         return c;
     }

@@ -17,6 +17,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <fstream>
 #include <map>
 #include <set>
@@ -39,9 +40,10 @@ struct Json {
         for (auto &kv : obj) if (kv.first == k) return &kv.second;
         return nullptr;
     }
+    static constexpr int kMaxDepth = 64;                  // checkpoint headers nest two levels; a bound keeps hostile input off the stack
     static Json parse(const std::string &s) {
         size_t i = 0;
-        Json j = value(s, i);
+        Json j = value(s, i, 0);
         ws(s, i);
         if (i != s.size()) throw Error(FL_ERR_BAD_ARGUMENT, "trailing characters in JSON");
         return j;
@@ -49,9 +51,10 @@ struct Json {
 
    private:
     static void ws(const std::string &s, size_t &i) { while (i < s.size() && std::isspace((unsigned char)s[i])) i++; }
-    static Json value(const std::string &s, size_t &i) {
+    static Json value(const std::string &s, size_t &i, int depth) {
         ws(s, i);
         if (i >= s.size()) throw Error(FL_ERR_BAD_ARGUMENT, "unexpected end of JSON");
+        if (depth > kMaxDepth) throw Error(FL_ERR_BAD_ARGUMENT, "JSON nested too deeply");
         Json j;
         char c = s[i];
         if (c == '{') {
@@ -59,12 +62,12 @@ struct Json {
             if (i < s.size() && s[i] == '}') { i++; return j; }
             while (true) {
                 ws(s, i);
-                Json k = value(s, i);
+                Json k = value(s, i, depth + 1);
                 if (k.kind != Str) throw Error(FL_ERR_BAD_ARGUMENT, "JSON object key must be a string");
                 ws(s, i);
                 if (i >= s.size() || s[i] != ':') throw Error(FL_ERR_BAD_ARGUMENT, "JSON: expected ':'");
                 i++;
-                j.obj.emplace_back(k.str, value(s, i));
+                j.obj.emplace_back(k.str, value(s, i, depth + 1));
                 ws(s, i);
                 if (i < s.size() && s[i] == ',') { i++; continue; }
                 if (i < s.size() && s[i] == '}') { i++; return j; }
@@ -75,7 +78,7 @@ struct Json {
             j.kind = Arr; i++; ws(s, i);
             if (i < s.size() && s[i] == ']') { i++; return j; }
             while (true) {
-                j.arr.push_back(value(s, i));
+                j.arr.push_back(value(s, i, depth + 1));
                 ws(s, i);
                 if (i < s.size() && s[i] == ',') { i++; continue; }
                 if (i < s.size() && s[i] == ']') { i++; return j; }
@@ -90,7 +93,9 @@ struct Json {
                     switch (e) {
                         case 'n': j.str += '\n'; break; case 't': j.str += '\t'; break; case 'r': j.str += '\r'; break;
                         case 'b': j.str += '\b'; break; case 'f': j.str += '\f'; break;
-                        case 'u': j.str += '?'; i += 4; break;            // names in checkpoints are ASCII
+                        case 'u':                                          // names in checkpoints are ASCII
+                            if (i + 4 >= s.size()) throw Error(FL_ERR_BAD_ARGUMENT, "JSON: truncated \\u escape");
+                            j.str += '?'; i += 4; break;
                         default: j.str += e;
                     }
                     i++;
@@ -111,24 +116,53 @@ struct Json {
     }
 };
 
+// a JSON number that must be a non-negative integer below 2^53 (shape entries, data offsets): what serde gives the
+// safetensors crate as usize; anything else -- negative, fractional, NaN, 1e300 -- is refused, never cast
+inline bool json_index(const Json &j, uint64_t *out) {
+    if (j.kind != Json::Num || !(j.num >= 0.0) || !(j.num <= 9007199254740992.0)) return false;
+    const uint64_t v = (uint64_t)j.num;
+    if ((double)v != j.num) return false;
+    *out = v;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------ one file
+// Validation follows the safetensors crate's (what candle_core::safetensors::load_buffer runs, huggingface.rs:88,125): header
+// length bounded, every tensor's byte range equal to shape x dtype size (checked multiplication), ranges inside the data
+// section, non-overlapping and without holes, and the last one ending at the end of the file.
 class SafetensorsFile {
    public:
     explicit SafetensorsFile(const std::string &path) : path_(path) {
+        try { load(path); } catch (...) { release(); throw; }      // (a throwing constructor's destructor never runs)
+    }
+    ~SafetensorsFile() { release(); }
+    SafetensorsFile(const SafetensorsFile &) = delete;
+    const std::map<std::string, Tensor> &tensors() const { return tensors_; }
+    static constexpr uint64_t kMaxHeader = 100000000;        // the safetensors crate's MAX_HEADER_SIZE
+
+   private:
+    void release() {
+        if (map_ && map_ != MAP_FAILED) ::munmap(map_, size_);
+        if (fd_ >= 0) ::close(fd_);
+        map_ = nullptr; fd_ = -1;
+    }
+    void load(const std::string &path) {
         fd_ = ::open(path.c_str(), O_RDONLY);
         if (fd_ < 0) throw Error(FL_ERR_BAD_ARGUMENT, "Failed to read " + path);
         struct stat st;
-        if (fstat(fd_, &st) != 0 || st.st_size < 8) { ::close(fd_); throw Error(FL_ERR_BAD_ARGUMENT, "Failed to load tensors from safetensors: " + path + " is too short"); }
+        if (fstat(fd_, &st) != 0 || st.st_size < 8) throw Error(FL_ERR_BAD_ARGUMENT, "Failed to load tensors from safetensors: " + path + " is too short");
         size_ = (size_t)st.st_size;
         map_ = ::mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
-        if (map_ == MAP_FAILED) { ::close(fd_); throw Error(FL_ERR_OOM, "mmap failed for " + path); }
+        if (map_ == MAP_FAILED) { map_ = nullptr; throw Error(FL_ERR_OOM, "mmap failed for " + path); }
         const unsigned char *p = static_cast<const unsigned char *>(map_);
         uint64_t n = 0;
         for (int i = 7; i >= 0; i--) n = (n << 8) | p[i];                     // little-endian u64
         if (n > size_ - 8) fail("header length exceeds the file");
+        if (n > kMaxHeader) fail("header too large");
         Json hdr = Json::parse(std::string(reinterpret_cast<const char *>(p + 8), (size_t)n));
         if (hdr.kind != Json::Obj) fail("header is not a JSON object");
         const size_t data0 = 8 + (size_t)n, data_len = size_ - data0;
+        std::vector<std::pair<uint64_t, uint64_t>> spans;
         for (auto &kv : hdr.obj) {
             if (kv.first == "__metadata__") continue;
             const Json *dt = kv.second.get("dtype"), *sh = kv.second.get("shape"), *off = kv.second.get("data_offsets");
@@ -140,23 +174,30 @@ class SafetensorsFile {
             else if (dt->str == "F16") { t.dtype = DType::F16; esz = 2; }
             else if (dt->str == "F32") { t.dtype = DType::F32; esz = 4; }
             else fail("unsupported dtype " + dt->str + " for tensor " + kv.first);
-            size_t cnt = 1;
-            for (auto &d : sh->arr) { t.shape.push_back((int64_t)d.num); cnt *= (size_t)d.num; }
-            const size_t b = (size_t)off->arr[0].num, e = (size_t)off->arr[1].num;
-            if (e < b || e > data_len || e - b != cnt * esz) fail("data_offsets of " + kv.first + " do not match its shape");
+            if (sh->arr.size() > 8) fail("tensor " + kv.first + " has too many dimensions");
+            uint64_t bytes = esz;
+            for (auto &d : sh->arr) {
+                uint64_t v = 0;
+                if (!json_index(d, &v)) fail("shape of " + kv.first + " is not a list of non-negative integers");
+                if (__builtin_mul_overflow(bytes, v, &bytes)) fail("shape of " + kv.first + " overflows");
+                t.shape.push_back((int64_t)v);
+            }
+            uint64_t b = 0, e = 0;
+            if (!json_index(off->arr[0], &b) || !json_index(off->arr[1], &e)) fail("data_offsets of " + kv.first + " are not non-negative integers");
+            if (e < b || e > data_len || e - b != bytes) fail("data_offsets of " + kv.first + " do not match its shape");
             t.data = p + data0 + b;
             t.device = -1;
-            tensors_[kv.first] = t;
+            if (!tensors_.emplace(kv.first, t).second) fail("tensor " + kv.first + " appears twice");
+            spans.emplace_back(b, e);
         }
+        std::sort(spans.begin(), spans.end());
+        uint64_t at = 0;
+        for (auto &sp : spans) {
+            if (sp.first != at) fail(sp.first < at ? "tensor byte ranges overlap" : "tensor byte ranges leave a hole");
+            at = sp.second;
+        }
+        if (at != data_len) fail("tensor data does not cover the file");
     }
-    ~SafetensorsFile() {
-        if (map_ && map_ != MAP_FAILED) ::munmap(map_, size_);
-        if (fd_ >= 0) ::close(fd_);
-    }
-    SafetensorsFile(const SafetensorsFile &) = delete;
-    const std::map<std::string, Tensor> &tensors() const { return tensors_; }
-
-   private:
     [[noreturn]] void fail(const std::string &m) const { throw Error(FL_ERR_BAD_ARGUMENT, "Failed to load tensors from safetensors (" + path_ + "): " + m); }
     std::string path_;
     int fd_ = -1;
@@ -190,7 +231,14 @@ struct Checkpoint {
             const Json *wm = j.get("weight_map");
             if (!wm || wm->kind != Json::Obj) throw Error(FL_ERR_BAD_ARGUMENT, "Invalid index file format: missing or invalid weight_map");
             std::set<std::string> uniq;
-            for (auto &kv : wm->obj) if (kv.second.kind == Json::Str) uniq.insert(kv.second.str);
+            for (auto &kv : wm->obj) {
+                if (kv.second.kind != Json::Str) continue;
+                // a shard is a file of THIS directory (the reference fetches each name from the same hub repository)
+                const std::string &fn = kv.second.str;
+                if (fn.empty() || fn[0] == '/' || fn.find("..") != std::string::npos)
+                    throw Error(FL_ERR_BAD_ARGUMENT, "Invalid index file format: shard name " + fn + " leaves the checkpoint directory");
+                uniq.insert(fn);
+            }
             names.assign(uniq.begin(), uniq.end());
         }
         for (auto &n : names) {

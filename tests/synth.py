@@ -71,6 +71,10 @@ CONFIGS = {
     "llama_tp4": dict(family="llama", hidden_size=512, intermediate_size=1024, vocab_size=512,
                       num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=4,
                       rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=512),
+    # ... and for an 8-way one (BASELINE config C4's degree): GQA 2, one kv head and 64 vocabulary rows per rank
+    "llama_tp8": dict(family="llama", hidden_size=1024, intermediate_size=2048, vocab_size=512,
+                      num_hidden_layers=2, num_attention_heads=16, num_key_value_heads=8,
+                      rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=512),
     # Mistral-7B's layer shape (h 4096, i 14336, 32/8 heads of 128), two layers, small vocabulary: full-size GEMV grids
     "mistral_wide": dict(family="mistral", hidden_size=4096, intermediate_size=14336, vocab_size=1024,
                          num_hidden_layers=2, num_attention_heads=32, num_key_value_heads=8,

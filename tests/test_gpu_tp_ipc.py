@@ -21,12 +21,17 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run_group(tmp_path, name, dtype, tp, T=10, n_tf=4, n_greedy=6, env_extra=None):
+def run_group(tmp_path, name, dtype, tp, T=10, n_tf=4, n_greedy=6, env_extra=None, ranks_per_proc=None):
+    """tp ranks as tp / ranks_per_proc worker processes.  The GPU boxes admit at most six processes on the card, so groups of more
+    than four ranks run two ranks (threads) per process: every rank still reaches six of its seven peers through hipIpc mappings."""
+    rpp = ranks_per_proc or (1 if tp <= 4 else 2)
+    assert tp % rpp == 0 and tp // rpp <= 5
     env = dict(os.environ, FL_AR_TIMEOUT_MS="8000")
     env.update(env_extra or {})
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "tp_ipc_worker.py"), str(r), str(tp), name, dtype,
+    groups = [",".join(str(r) for r in range(p * rpp, (p + 1) * rpp)) for p in range(tp // rpp)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "tp_ipc_worker.py"), g, str(tp), name, dtype,
                                str(tmp_path), str(T), str(n_tf), str(n_greedy)], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(tp)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for g in groups]
     outs = []
     try:
         for p in procs:
@@ -36,13 +41,14 @@ def run_group(tmp_path, name, dtype, tp, T=10, n_tf=4, n_greedy=6, env_extra=Non
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    for r, p in enumerate(procs):
-        assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
+    for g, p, o in zip(groups, procs, outs):
+        assert p.returncode == 0, "ranks %s failed:\n%s" % (g, o[-3000:])
     return [np.load(os.path.join(str(tmp_path), "out_%d.npz" % r)) for r in range(tp)]
 
 
 @pytest.mark.parametrize("name,tp,dtype", [("llama_a", 2, "bf16"), ("mistral_a", 2, "f32"), ("qwen2_a", 2, "bf16"),
-                                           ("llama_mha", 2, "f32"), ("llama_tp4", 4, "bf16")])
+                                           ("llama_mha", 2, "f32"), ("llama_tp4", 4, "bf16"), ("llama_tp8", 8, "bf16"),
+                                           ("llama_tp8", 8, "f32"), ("llama_tp4", 4, "f32")])
 def test_multiprocess_oneshot_matches_emulated_and_oracle(tmp_path, name, tp, dtype):
     import fastllm_amd as fa
     from fastllm_amd import binding
@@ -150,6 +156,7 @@ def test_overlapped_prefill_multiprocess_and_single_process(tmp_path, monkeypatc
 
 @pytest.mark.parametrize("name,tp,dtype,tune", [("llama_tp4", 2, "bf16", ""), ("llama_tp4", 4, "bf16", ""), ("qwen2_a", 2, "f32", ""),
                                                 ("llama_tp4", 2, "bf16", "gemv_blocks=6,gemv_waves=4"),
+                                                ("llama_tp8", 8, "bf16", "gemv_blocks=16,gemv_waves=4"),
                                                 ("mistral_wide", 2, "bf16", "gemv_blocks=96,gemv_waves=4")])
 def test_all_reduce_fused_into_gemv_epilogue(tmp_path, name, tp, dtype, tune, monkeypatch):
     """Decode steps of a connected group exchange o_proj / down_proj partial sums in the GEMV epilogue (comm_ll.h)
@@ -160,8 +167,13 @@ def test_all_reduce_fused_into_gemv_epilogue(tmp_path, name, tp, dtype, tune, mo
     cfg = synth.CONFIGS[name]
     T, n_s = 12, 40
     (tmp_path / "fused").mkdir(); (tmp_path / "plain").mkdir()
-    fused = run_group(tmp_path / "fused", name, dtype, tp, T, 2, 24, env_extra={"TP_WORKER_SAMPLED": str(n_s), "FL_TP_FUSED_AR": "2", "TP_WORKER_TUNE": tune})
-    plain = run_group(tmp_path / "plain", name, dtype, tp, T, 2, 24, env_extra={"TP_WORKER_SAMPLED": str(n_s), "FL_TP_FUSED_AR": "0", "TP_WORKER_TUNE": tune})
+    # Eight ranks on ONE card: a waiting wave needs its peers' waves resident, and only the GEMV grids can be cut (gemv_blocks).  The
+    # short-cache form of the o_proj launch (k_attn_rep.hip) is one row per wave -- 128 workgroups x 8 ranks here, more than the card
+    # holds (found by this test's first run: every rank's resident waves waited for rows of workgroups not yet dispatched, bounded
+    # wait, FL_ERR_RCCL) -- so the 8-rank group keeps attention and o_proj apart; with a GPU per rank the grid is that GPU's alone.
+    rep = {"FL_ATTN_REP": "0"} if tp > 4 else {}
+    fused = run_group(tmp_path / "fused", name, dtype, tp, T, 2, 24, env_extra=dict(rep, TP_WORKER_SAMPLED=str(n_s), FL_TP_FUSED_AR="2", TP_WORKER_TUNE=tune))
+    plain = run_group(tmp_path / "plain", name, dtype, tp, T, 2, 24, env_extra=dict(rep, TP_WORKER_SAMPLED=str(n_s), FL_TP_FUSED_AR="0", TP_WORKER_TUNE=tune))
     for r in range(tp):
         for k in ("tokens", "sampled", "decode"):
             np.testing.assert_array_equal(fused[r][k], fused[0][k], err_msg="fused rank %d vs 0: %s" % (r, k))
@@ -173,6 +185,8 @@ def test_all_reduce_fused_into_gemv_epilogue(tmp_path, name, tp, dtype, tune, mo
     try:
         for k, v in tuned.items():
             fa.tune(k, v)
+        if rep:
+            monkeypatch.setenv("FL_ATTN_REP", "0")
         gE = fa.Model(cfg, w, dtype=dtype, tp_mode=binding.TP_EMULATED, tp_size=tp)
         cE = gE.new_cache(T + n_s + 8)
         f = gE.forward_sample(cE, ids[:T], 0, 0.9, seed=5)
@@ -197,12 +211,15 @@ def test_all_reduce_fused_into_gemv_epilogue(tmp_path, name, tp, dtype, tune, mo
     gE.close()
 
 
-@pytest.mark.parametrize("fused", ["2", "0"])
-def test_stalled_peer_is_an_error_not_a_hang(tmp_path, fused):
-    """A rank that never shows up for a decode step: the waiting rank's polls (in the GEMV epilogue, or in the one-shot
+@pytest.mark.parametrize("name,tp,fused", [("llama_a", 2, "2"), ("llama_a", 2, "0"), ("llama_tp8", 8, "2"), ("llama_tp8", 8, "0")])
+def test_stalled_peer_is_an_error_not_a_hang(tmp_path, name, tp, fused):
+    """A rank that never shows up for a decode step: the waiting ranks' polls (in the GEMV epilogue, or in the one-shot
     kernel) give up after FL_AR_TIMEOUT_MS, the step returns FL_ERR_RCCL, and every kernel of the step still drains."""
-    res = run_group(tmp_path, "llama_a", "bf16", 2, env_extra={"TP_WORKER_STALLED_RANK": "1", "FL_AR_TIMEOUT_MS": "300", "FL_TP_FUSED_AR": fused})
-    msg = str(res[0]["error"])
-    assert "gave up waiting for a peer" in msg, msg
-    assert ("0xa11e" in msg) == (fused == "2"), msg                   # which waiter reported: fused epilogue / one-shot kernel
-    assert float(res[0]["waited_s"]) < 30.0
+    tune = "gemv_blocks=16,gemv_waves=4" if tp > 2 else ""
+    res = run_group(tmp_path, name, "bf16", tp, env_extra={"TP_WORKER_STALLED_RANK": str(tp - 1), "FL_AR_TIMEOUT_MS": "300", "FL_TP_FUSED_AR": fused,
+                                                           "TP_WORKER_TUNE": tune, "FL_ATTN_REP": "0" if tp > 4 else "1"})
+    for r in range(tp - 1):
+        msg = str(res[r]["error"])
+        assert "gave up waiting for a peer" in msg, msg
+        assert ("0xa11e" in msg) == (fused == "2"), msg                   # which waiter reported: fused epilogue / one-shot kernel
+        assert float(res[r]["waited_s"]) < 30.0

@@ -1,4 +1,7 @@
-"""One rank of a multi-process tensor-parallel group (tests/test_gpu_tp_ipc.py starts tp of these).
+"""One rank -- or several, "0,1", each on its own thread -- of a multi-process tensor-parallel group
+(tests/test_gpu_tp_ipc.py starts these).  Several ranks per process is how an 8-rank group runs on a one-GPU box that admits
+at most six GPU processes: 4 processes x 2 ranks; the peers of another process are reached through real hipIpc mappings, the
+one in the same process through its plain pointer (comm.hip, comm_exported_here).
 
 No RCCL: the ranks may share one GPU (the GPU boxes have one), so the group is wired with
 fl_comm_ipc_export / fl_comm_ipc_connect and every collective takes the one-shot path over
@@ -33,8 +36,30 @@ def exchange(outdir, rank, world, blob, tag, timeout=120.0):
 
 
 def main():
-    rank, world, name, dtype, outdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+    ranks, world, name, dtype, outdir = [int(r) for r in sys.argv[1].split(",")], int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
     T, n_tf, n_greedy = int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8])
+    if len(ranks) == 1:
+        return run_rank(ranks[0], world, name, dtype, outdir, T, n_tf, n_greedy)
+    import threading
+    import traceback
+    failed = []
+
+    def guarded(r):
+        try:
+            run_rank(r, world, name, dtype, outdir, T, n_tf, n_greedy)
+        except BaseException:                                # noqa: reported below, the process exits non-zero
+            traceback.print_exc()
+            failed.append(r)
+    ts = [threading.Thread(target=guarded, args=(r,)) for r in ranks]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if failed:
+        raise SystemExit("ranks %s failed" % failed)
+
+
+def run_rank(rank, world, name, dtype, outdir, T, n_tf, n_greedy):
     import fastllm_amd as fa
     from fastllm_amd import binding
     import synth
