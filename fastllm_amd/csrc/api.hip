@@ -302,18 +302,25 @@ int fl_profile_end(fl_model *m, fl_kernel_stat *stats, size_t cap, size_t *n_sta
 int fl_tune(const char *key, int value) {
     return guarded([&]() -> int {
         if (!key || value < -1) FL_FAIL(FL_ERR_BAD_ARGUMENT, "bad tuning key/value");       // (-1: "automatic", for the switches that have it)
-        if (!strcmp(key, "gemv_r")) gemv_set_tuning(value, 0, -1, -1);
-        else if (!strcmp(key, "gemv_u")) gemv_set_tuning(0, value, -1, -1);
-        else if (!strcmp(key, "gemv_blocks")) gemv_set_tuning(0, 0, value, -1);        // 0 = automatic
-        else if (!strcmp(key, "gemv_waves")) gemv_set_tuning(0, 0, -1, value);          // 0 = automatic
-        else if (!strcmp(key, "engine_grid")) engine_set_grid(value);                   // 0 = one workgroup per CU (tests: a grid that cannot be resident)
+        if (!strcmp(key, "gemv_blocks")) gemv_set_tuning(value, -1);                    // 0 = automatic
+        else if (!strcmp(key, "gemv_waves")) gemv_set_tuning(-1, value);                // 0 = automatic
+        else if (!strcmp(key, "engine_grid")) {                                         // 0 = one workgroup per CU (tests: a grid that cannot be resident)
+#ifndef FL_EXPERIMENTAL
+            FL_FAIL(FL_ERR_UNSUPPORTED, "default build: engine_grid belongs to the experimental decode engine");
+#endif
+            engine_set_grid(value);
+        }
         else if (!strcmp(key, "experimental")) {                                        // is this the EXPERIMENTAL build? (tests skip otherwise)
 #ifndef FL_EXPERIMENTAL
             FL_FAIL(FL_ERR_UNSUPPORTED, "default build: the experimental kernels (decode engine, fused attention + o_proj, attention prefetch, loader waves) are not compiled in");
 #endif
         }
         else if (!strcmp(key, "reload_env")) tune_reload_env();                        // re-read every FL_<NAME> switch of the table (common.h)
-        else if (tune_set(key, value) != FL_OK) FL_FAIL(FL_ERR_BAD_ARGUMENT, "unknown tuning key %s", key);
+        else {
+            const int rc = tune_set(key, value);
+            if (rc == FL_ERR_UNSUPPORTED) FL_FAIL(FL_ERR_UNSUPPORTED, "default build: %s is a switch of a kernel compiled into the EXPERIMENTAL build only", key);
+            if (rc != FL_OK) FL_FAIL(FL_ERR_BAD_ARGUMENT, "unknown tuning key %s", key);
+        }
         return FL_OK;
     });
 }

@@ -113,6 +113,7 @@ enum TuneKey {
     TK_H4_TAIL,   // a peeled GEMM's tail columns on the 128 x 256 kernel instead of stream-K + fix-up: 0 never, 1 with 2-4 in-launch slices, 2 (default) also unsliced when the tail alone fills the chip
     TK_RS_LAZY,   // 1/rms behind a residual epilogue: taken from the partial sums by the consuming projection (0: rms_finalize launch)
     TK_BATCH_UNFUSED_MIN,   // first batch size on the prefill-shaped step (-1: 3 with the ring kernel, else 7)
+    TK_DEBUG_RS_PARTS,   // tests: gemm_takes_rs_parts() answers yes for every bf16 prompt shape, so that kernels which cannot take partial sums meet them (rs_parts_to_vector)
     TK_COUNT
 };
 int tune(TuneKey k);

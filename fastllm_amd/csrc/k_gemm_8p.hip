@@ -578,7 +578,7 @@ int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias,
     const ResidEpi re = resid ? *resid : ResidEpi{};
     if (ksplit > 1 && ldc != N) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: K slices write whole slabs (ldc == N)");
     if (streamk && ksplit != 1) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: stream-K takes the whole K");
-    if (streamk && L.rsp.part) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: a stream-K launch's fix-up takes its row scales as a vector (run rms_finalize)");
+    if (streamk) FL_TRY(rs_parts_to_vector(L, row_scale, T));       // (a stream-K launch's fix-up takes its row scales as a vector)
     const int tiles_m = (int)((T + P_BM - 1) / P_BM), tiles_n = (int)((N + P_BN - 1) / P_BN);
     if (K % P_BK || K / P_BK / ksplit < 2) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_8p: K must give at least two 64-wide tiles per slice");
     if (ksplit > 1 && (bias || epi != EPI_F32)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "split-K GEMM: fp32 epilogue without bias only");

@@ -6,16 +6,20 @@
 // 256 x 256 on 256 CUs.  Round 2/3 cut K eight ways into fp32 slabs that the NEXT launch (rmsnorm_add, rope_kv) summed: 67 MB
 // written and re-read per projection at T = 512, 13 us of every rmsnorm_add and ~12 us inside the GEMM's own epilogue.  Here the
 // tile is half the size (twice the tiles, so at most FOUR K slices fill the chip: half the partial bytes) and the partials meet
-// inside the launch:
-//   * every workgroup draws a ticket per tile when its K loop ends (arrival order, one agent-scope atomic);
-//   * all but the last arriver publish their fp32 accumulators (write-through sc1 stores, lane-major 16-byte layout), wait for
-//     their stores, and count themselves on the tile's `done` word;
-//   * the last arriver keeps its accumulators in registers, waits until done == slices - 1 -- a wait on workgroups that are
-//     RESIDENT and past their K loops, so it ends whatever else shares the GPU (nobody waits for a workgroup that may not have
-//     started) -- adds the slices in K ORDER (its own from registers at its place in the order: the sum does not depend on who
-//     came last) and runs the epilogue: plain fp32 / bias / row scale, SiLU-gate, or the residual epilogue of kernels.h
-//     (h += y, xn = (h + y) * w_next, partial sums of squares) that replaces the rmsnorm_add launch.
-// Both words are reset by the last arriver: a launch leaves the workspace as it found it.
+// inside the launch, by STATIC OWNERSHIP (the protocol is written out where it runs, "the slices of a tile meet" below):
+//   * a tile is eight blocks (an eighth of the tile each); slice kz of S owns blocks kz, kz + S, ...;
+//   * when its K loop ends a workgroup publishes the blocks it does NOT own (write-through sc1 stores, lane-major 16-byte
+//     layout), waits for its stores and counts itself on the tile's `published` word (one agent-scope atomic add);
+//   * once all S slices are counted it loads the peers' copies of its OWN blocks, adds them to the accumulators it kept in
+//     registers in K ORDER (its own at its place in the order: the sum does not depend on timing) and runs the epilogue of those
+//     blocks: plain fp32 / bias / row scale, SiLU-gate, the residual epilogue of kernels.h (h += y, xn = (h + y) * w_next,
+//     partial sums of squares: no rmsnorm_add launch) or RoPE + KV append (gemm_w4.h);
+//   * nobody waits without bound for a workgroup that may not have started (processes may share the GPU): an early slice
+//     waits `wait_ticks`, then ABANDONS its blocks -- publishes them too, sets their bits in the tile's flag word -- and leaves;
+//     the slice counted last CLOSES the flag word after its own blocks and finishes whatever bits it finds, from memory alone; a
+//     slice whose abandoning fetch_or finds the word closed finishes its blocks itself.  Every block is finished exactly once.
+// The two words of a tile live in two sets used by alternate launches on a workspace; a launch zeroes the OTHER set, so nothing is
+// reset inside a launch and a late waiter never sees a recycled word.
 //
 // Tile and K loop: four waves as 2 (M) x 2 (N), 64 x 128 outputs per wave (32 accumulator tiles = a[0:127], owned by inline asm
 // as in gemm_4w_kernel).  A K tile (BK = 64) is three 16-KiB half tiles -- A (128 rows of X), B0 / B1 (the first / second 64 of
@@ -93,7 +97,11 @@ __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__
         for (int h = 0; h < 2; h++)
             offB[h][s] = (unsigned)(((size_t)min(n0 + a_row(h, r), N - 1) * K + c * 8) * 2) + (W4_BIAS - 1024 * s);
     }
-    const bool blocked = (pf_mode >> 16) & 1;     // TIMING EXPERIMENT (wrong results): W read as if stored K-tile-major, [N/256][K/64][256 rows][64]
+#ifdef FL_EXPERIMENTAL
+    const bool blocked = (pf_mode >> 16) & 1;     // timing probe of the EXPERIMENTAL build only (WRONG RESULTS): W read as if stored K-tile-major, [N/256][K/64][256 rows][64]
+#else
+    constexpr bool blocked = false;
+#endif
     if (blocked) {
 #pragma unroll
         for (int s = 0; s < 4; s++) {
@@ -119,8 +127,11 @@ __global__ __launch_bounds__(256) void gemm_h4_kernel(const bf16_t *__restrict__
 
     const int4w rsX = w4_rsrc(Xs), rsW = w4_rsrc(Ws);
 #define H4_WP(S_, OFF_, KO_) w4_piece<S_, WNT>(rsW, OFF_, KO_)      /* a W piece: non-temporal where few row tiles share the panel */
-    auto koff = [&](int tile) { return (unsigned)(min(tile, nk - 1) * (P_BK * 2)); };   // byte offset of a K tile (clamped past the end)
-    auto koffW = [&](int tile) { return blocked ? (unsigned)((kt0 + min(tile, nk - 1)) * 32768 - kt0 * (P_BK * 2)) : koff(tile); };
+    // byte offset of a K tile, clamped at both ends: past the last tile the requests go on into slots nobody reads, and a prefetch
+    // distance below 3 asks for tiles before the first (an unclamped negative index became a ~4 GiB soffset, outside the buffer's
+    // range check: ADVICE r4)
+    auto koff = [&](int tile) { return (unsigned)(max(0, min(tile, nk - 1)) * (P_BK * 2)); };
+    auto koffW = [&](int tile) { return blocked ? (unsigned)((kt0 + max(0, min(tile, nk - 1))) * 32768 - kt0 * (P_BK * 2)) : koff(tile); };
     const unsigned lds0 = (unsigned)(size_t)lds + wave * 4096;          // this wave's piece 0 of half 0 of slot 0 (LDS byte address)
     // which: 0 A, 1 B0, 2 B1
     auto m0of = [&](int slot, int which) { return lds0 + slot * H4_SLOT + which * P_HALF; };

@@ -426,6 +426,7 @@ int launch_gemm_qkv_rope_long(Launcher &L, const void *W, const void *x, const f
 // Mirrors launch_linear / launch_gemm_mfma: the 128 x 256 kernel, or a plain (no stream-K, no peeled tail) launch of the 256 x 256 ones.
 bool gemm_takes_rs_parts(int dtype, int64_t T, int64_t N, int64_t K, int epi, int max_split) {
     if (dtype != FL_DTYPE_BF16 || T <= 1 || tune(TK_FORCE_GENERIC_GEMM)) return false;
+    if (tune(TK_DEBUG_RS_PARTS)) return true;                        // (tests: a plan that is wrong on purpose)
     if (gemm_h4_plan(T, N, K, epi) > 0 || gemm_w14_plan(T, N, K, epi)) return true;
     if (tune(TK_GEMM_SKINNY) && gemm_skinny_supported(T, N, K)) return false;
     if (!gemm_mfma_supported(dtype, T, N, K)) return false;
@@ -483,7 +484,7 @@ static int launch_gemm_mfma_impl(Launcher &L, const void *W, const void *x, cons
     if (!use8p && kern == GK_8P) kern = cost_256(T, N, K, ksplit) < cost_128(T, N, K, ksplit) ? GK_256 : GK_128;
     if (use8p >= 2 && K % 64 == 0 && (K / 64) / ksplit >= 2 && splittable) kern = GK_8P;
     if (kern == GK_8P) return launch_gemm_8p(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit, ldc);
-    if (L.rsp.part) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_mfma: the 128-column kernels take their row scales as a vector");
+    FL_TRY(rs_parts_to_vector(L, row_scale, T));                    // (the 128-column kernels take their row scales as a vector)
     if (kern == GK_256) {
         const int tm2 = (int)((T + BM2 - 1) / BM2), tn2 = (int)((N + BN - 1) / BN);
         const size_t lds2 = 3 * (size_t)STAGE2;                     // 144 KiB

@@ -56,8 +56,9 @@ constexpr bool kGemvDot2 = FL_GEMV_DOT2 != 0;
 #endif
 constexpr bool kGemvPipe = FL_GEMV_PIPE != 0 && kGemvDot2;
 
-#ifndef FL_GEMV_PLAIN_LOADS
-#define FL_GEMV_PLAIN_LOADS 0              // (timing experiment: the weight stream through plain instead of non-temporal loads)
+#if !defined(FL_GEMV_PLAIN_LOADS) || !defined(FL_EXPERIMENTAL)
+#undef FL_GEMV_PLAIN_LOADS
+#define FL_GEMV_PLAIN_LOADS 0              // (-DFL_GEMV_PLAIN_LOADS=1, EXPERIMENTAL build only: the weight stream through plain instead of non-temporal loads)
 #endif
 __device__ inline void load_raw_nt(const bf16_t *p, RawChunk<bf16_t> &r) {
     if constexpr (FL_GEMV_PLAIN_LOADS != 0) r.v[0] = *reinterpret_cast<const uint4v *>(p);
@@ -492,11 +493,11 @@ __global__ __launch_bounds__(MAXT) void gemv_kernel(const GemvArgs a) {
     leave_candidate();
 }
 
-static std::atomic<int> g_gemv_r{0}, g_gemv_u{0}, g_force_blocks{0}, g_force_waves{0};
+// forced grid / waves per workgroup (fl_tune "gemv_blocks" / "gemv_waves"; 0 = automatic).  Rows per wave pass and chunks per block
+// are rows of the switch table (TK_GEMV_R, TK_GEMV_U): read per launch, so "reload_env" reaches them like every other switch.
+static std::atomic<int> g_force_blocks{0}, g_force_waves{0};
 
-void gemv_set_tuning(int R, int U, int blocks, int waves) {
-    if (R > 0) g_gemv_r = R;
-    if (U > 0) g_gemv_u = U;
+void gemv_set_tuning(int blocks, int waves) {
     if (blocks >= 0) g_force_blocks = blocks;
     if (waves >= 0) g_force_waves = waves;
 }
@@ -592,9 +593,7 @@ static int launch_gemv_t(Launcher &L, const GemvArgs &a) {
 
 template <typename WT, typename XT, int PRO>
 static int launch_gemv_ru(Launcher &L, const GemvArgs &a) {
-    int R = g_gemv_r.load(), U = g_gemv_u.load();
-    if (!R) { R = tune(TK_GEMV_R); g_gemv_r = R; }
-    if (!U) { U = tune(TK_GEMV_U); g_gemv_u = U ? U : -1; }
+    int R = tune(TK_GEMV_R), U = tune(TK_GEMV_U);
     // default (no FL_GEMV_U / fl_tune): four 1-KiB chunks in flight per row, two for the plain and RoPE epilogues at
     // K <= 4096 (Mistral-7B: o_proj 7.96 -> 7.48 us, lm_head 43.8 -> 42.0, QKV 11.95 -> 11.82; down_proj at K = 14336
     // 19.9 vs 20.9 and gate/up 38.2 vs 38.1 stay on four)
@@ -620,8 +619,7 @@ static int launch_gemv_ru(Launcher &L, const GemvArgs &a) {
 // Would this launch's grid fit the ArgMax candidate buffer (GemvArgs::amax)?  A tuned grid (fl_tune "gemv_blocks") or a
 // device with >= 512 CUs may not: the caller then leaves amax null and token selection scans the logits instead.
 bool gemv_leaves_candidates(int dtype, const GemvArgs &a) {
-    int R = g_gemv_r.load();
-    if (!R) R = tune(TK_GEMV_R);
+    int R = tune(TK_GEMV_R);
     if (R != 4) R = 2;                                       // (the instantiations launch_gemv_ru picks from)
     const size_t es = dtype == FL_DTYPE_BF16 ? 2 : 4;
     int blocks = 1, waves = 4;
@@ -630,8 +628,7 @@ bool gemv_leaves_candidates(int dtype, const GemvArgs &a) {
 }
 
 int64_t gemv_owner_chunk(int dtype, int64_t N, int64_t K) {
-    int R = g_gemv_r.load();
-    if (!R) R = tune(TK_GEMV_R);
+    int R = tune(TK_GEMV_R);
     if (R != 4) R = 2;
     const size_t es = dtype == FL_DTYPE_BF16 ? 2 : 4;
     int blocks = 1, waves = 4;

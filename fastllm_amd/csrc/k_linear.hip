@@ -107,8 +107,8 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
     if (epi == EPI_GATEUP && N % 32) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gate/up matrix rows must be a multiple of 32");
     const int force_generic = tune(TK_FORCE_GENERIC_GEMM);
     // Launcher::rsp (row scales as partial sums): only the kernels gemm_takes_rs_parts() names read it -- any other path would
-    // silently use a stale vector, so it refuses
-    auto no_parts = [&]() -> int { if (L.rsp.part) FL_FAIL(FL_ERR_BAD_ARGUMENT, "launch_linear: this kernel takes its row scales as a vector"); return FL_OK; };
+    // silently use a stale vector, so the sums are finished into the vector first (kernels.h, rs_parts_to_vector)
+    auto no_parts = [&]() -> int { return rs_parts_to_vector(L, row_scale, T); };
     if (dtype == FL_DTYPE_BF16) {
         if (T == 1 && gemv_supported(dtype, N, K)) { FL_TRY(no_parts()); return launch_gemv(L, dtype, plain_args(W, x, bias, y, N, K, epi, row_scale)); }
         // mid-size prompts: 128 x 256 tiles, K slices summed inside the launch (k_gemm_h4.hip) -- one complete output, no slabs

@@ -103,6 +103,14 @@ __global__ __launch_bounds__(256) void rms_finalize_kernel(const float *__restri
     ss = wave_sum(ss);
     if (lane == 0) inv_rms[t] = 1.0f / sqrtf(ss / (float)h + eps);
 }
+int rs_parts_to_vector(Launcher &L, const float *row_scale, int64_t T) {
+    if (!L.rsp.part) return FL_OK;
+    if (!row_scale || !(L.rsp.inv_h > 0.f)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "row scales left as partial sums, and no vector to finish them into");
+    const RsParts p = L.rsp;
+    L.rsp = RsParts{};
+    return launch_rms_finalize(L, p.part, p.np, p.eps, const_cast<float *>(row_scale), T, (int64_t)(1.0f / p.inv_h + 0.5f));
+}
+
 int launch_rms_finalize(Launcher &L, const float *part, int np, float eps, float *inv_rms, int64_t T, int64_t h) {
     Launcher LL = L; LL.tag = "finalize";
     return LL.launch(KC_RMSNORM, (double)T * np * 4.0, 0, rms_finalize_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, part, np, eps, inv_rms,

@@ -98,7 +98,7 @@ int launch_gemv(Launcher &L, int dtype, const GemvArgs &a);
 int64_t gemv_owner_chunk(int dtype, int64_t N, int64_t K);
 bool gemv_leaves_candidates(int dtype, const GemvArgs &a);   // the grid launch_gemv would pick fits the candidate buffer
 bool gemv_norm_supported(int dtype, int64_t N, int64_t K);
-void gemv_set_tuning(int R, int U, int maxblocks, int maxblocks_norm);
+void gemv_set_tuning(int blocks, int waves);   // fl_tune "gemv_blocks" / "gemv_waves": force the grid / waves per workgroup (0 automatic, -1 keep)
 
 // ---- the persistent decode engine (k_engine.hip): a chain of projections in one launch ---------------------------
 constexpr int ENG_GATHER_WAVES = 4, ENG_STREAM_WAVES = 8, ENG_MAX_OPS = 4;
@@ -212,6 +212,10 @@ bool gemm_resid_supported(int dtype, int64_t T, int64_t N, int64_t K, int max_sp
 int gemm_resid_partials(int64_t N);                                                       // partial sums per row (np)
 int launch_gemm_resid(Launcher &L, const void *W, const void *x, int64_t T, int64_t N, int64_t K, const ResidEpi &re);
 int launch_rms_finalize(Launcher &L, const float *part, int np, float eps, float *inv_rms, int64_t T, int64_t h);
+// A kernel that reads its row scales as a VECTOR was picked although the caller left them as a residual epilogue's partial sums
+// (Launcher::rsp): the plan (gemm_takes_rs_parts) and the launch disagree -- a switch changed in between, or the two rules drifted.
+// Finish the sums into the vector the caller passed as row_scale and go on, instead of failing a forward half way through its layers.
+int rs_parts_to_vector(Launcher &L, const float *row_scale, int64_t T);
 int64_t gemm_8p_workspace_bytes(hipStream_t stream);   // stream-K workspace held for a stream on the current device
 void gemm_8p_release_stream(hipStream_t stream);   // frees the stream-K workspace of a stream that is about to be destroyed
 int launch_gemm_8p(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
@@ -231,7 +235,7 @@ struct RopeEpi {
 constexpr int H4_MAXS = 4;             // K slices at most
 struct H4Space {
     float *part;                       // [tile][slice][128 x 256] fp32 partial accumulators, lane-major
-    unsigned *ctr;                     // [2 sets][tile]{published, claimed blocks}: alternate launches use alternate sets and zero the other
+    unsigned *ctr;                     // [2 sets][tile]{slices published, flag word: abandoned blocks' bits | CLOSED}: alternate launches use alternate sets and zero the other
 };
 bool gemm_h4_supported(int64_t T, int64_t N, int64_t K, int ksplit);
 int gemm_h4_plan(int64_t T, int64_t N, int64_t K, int epi);

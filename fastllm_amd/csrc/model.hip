@@ -42,7 +42,7 @@ const char *env_str(const char *name) { const char *s = getenv(name); return s &
 int env_int(const char *name, int dflt) { const char *s = env_str(name); return s ? atoi(s) : dflt; }
 
 // ------------------------------------------------------------------------------- switches (common.h: TuneKey)
-struct TuneEntry { const char *name; int dflt; };
+struct TuneEntry { const char *name; int dflt; bool exp_only = false; };   // exp_only: acts in the EXPERIMENTAL build only (Makefile); fl_tune refuses it elsewhere
 static const TuneEntry g_tune_table[TK_COUNT] = {
     {"gemm_h4", 1},
     {"gemm_w14", 1},
@@ -61,10 +61,10 @@ static const TuneEntry g_tune_table[TK_COUNT] = {
     {"verbose", 0},
     {"tp_fused_ar", 1},
     {"attn_nw", 4},
-    {"attn_prefetch", 0},
-    {"attn_prefetch_lines", 8},
-    {"attn_prefetch_pct", 100},
-    {"attn_prefetch_delay", 0},
+    {"attn_prefetch", 0, true},
+    {"attn_prefetch_lines", 8, true},
+    {"attn_prefetch_pct", 100, true},
+    {"attn_prefetch_delay", 0, true},
     {"attn_batch_wgs", 256},
     {"attn_pf32_min_t", 0},
     {"attn_pf32_ks2", -1},
@@ -72,11 +72,11 @@ static const TuneEntry g_tune_table[TK_COUNT] = {
     {"attn_pf_waves", 0},
     {"attn_pf_stages", 2},
     {"attn_pf_ksplit", 2},
-    {"ao_delay", 6},
-    {"ao_waves", 0},
-    {"engine_delay", 12},
-    {"engine_pf", 1},
-    {"engine_timeout_ms", 2000},
+    {"ao_delay", 6, true},
+    {"ao_waves", 0, true},
+    {"engine_delay", 12, true},
+    {"engine_pf", 1, true},
+    {"engine_timeout_ms", 2000, true},
     {"sk_minsteps", 8},
     {"gemm_4w", 1},
     {"gemm_groupm", 0},
@@ -91,7 +91,7 @@ static const TuneEntry g_tune_table[TK_COUNT] = {
     {"skinny_stages", 4},
     {"skinny_nt", 1},
     {"skinny_wm", 1},
-    {"skinny_loaders", -1},
+    {"skinny_loaders", -1, true},
     {"gemm_skinny_maxt2", 256},
     {"gemv_small", 1},
     {"gemv_r", 2},
@@ -109,8 +109,8 @@ static const TuneEntry g_tune_table[TK_COUNT] = {
     {"graph", -1},
     {"fused", 1},
     {"allow_any_arch", 0},
-    {"engine", 0},
-    {"fuse_oproj", 0},
+    {"engine", 0, true},
+    {"fuse_oproj", 0, true},
     {"oneshot", 1},
     {"debug_rccl_self", 0},
     {"attn_mfma", 1},
@@ -127,7 +127,9 @@ static const TuneEntry g_tune_table[TK_COUNT] = {
     {"h4_tail", 2},
     {"rs_lazy", 1},
     {"batch_unfused_min", -1},
+    {"debug_rs_parts", 0},
 };
+static_assert(sizeof(g_tune_table) / sizeof(g_tune_table[0]) == TK_COUNT, "one row per TuneKey, in the enum's order");
 static std::atomic<int> g_tune[TK_COUNT];
 static std::once_flag g_tune_once;
 static void tune_read_env() {
@@ -136,7 +138,12 @@ static void tune_read_env() {
         size_t n = 3;
         for (const char *c = g_tune_table[k].name; *c && n + 1 < sizeof env; c++) env[n++] = (char)toupper((unsigned char)*c);
         env[n] = 0;
-        g_tune[k].store(env_int(env, g_tune_table[k].dflt), std::memory_order_relaxed);
+        int v = env_int(env, g_tune_table[k].dflt);
+#ifndef FL_EXPERIMENTAL
+        if (g_tune_table[k].exp_only) v = g_tune_table[k].dflt;       // the environment cannot reach a kernel that is not compiled in
+        if (k == TK_H4_PF) v &= 0xFFFF;
+#endif
+        g_tune[k].store(v, std::memory_order_relaxed);
     }
 }
 int tune(TuneKey k) {
@@ -146,7 +153,14 @@ int tune(TuneKey k) {
 int tune_set(const char *name, int value) {
     std::call_once(g_tune_once, tune_read_env);
     for (int k = 0; k < TK_COUNT; k++)
-        if (!strcmp(name, g_tune_table[k].name)) { g_tune[k].store(value, std::memory_order_relaxed); return FL_OK; }
+        if (!strcmp(name, g_tune_table[k].name)) {
+#ifndef FL_EXPERIMENTAL
+            if (g_tune_table[k].exp_only) return FL_ERR_UNSUPPORTED;
+            if (k == TK_H4_PF) value &= 0xFFFF;      // (bit 16 is a wrong-results timing probe of the experimental build)
+#endif
+            g_tune[k].store(value, std::memory_order_relaxed);
+            return FL_OK;
+        }
     return FL_ERR_BAD_ARGUMENT;
 }
 void tune_reload_env() {

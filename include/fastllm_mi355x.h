@@ -266,9 +266,17 @@ int fl_profile_end(fl_model *m, fl_kernel_stat *stats, size_t cap, size_t *n_sta
  * (the decode all-reduce after o_proj / down_proj; bench.py --gpus N reports the three side by side.) */
 int fl_comm_probe(fl_model *m, int32_t form, int64_t n, int32_t iters, double *us_per_call);
 
-/* Tuning knobs of the decode weight-streaming kernel (sweeps in tools/; not needed in normal use):
- * "gemv_r" rows per wave pass (2|4), "gemv_u" 512-element chunks per pipeline block (2|4|8),
- * "gemv_blocks" / "gemv_waves": force the grid and the waves per workgroup (0 = automatic). */
+/* Process-wide switches (sweeps and tests; not needed in normal use).  Every switch is an integer row of ONE table
+ * (fastllm_amd/csrc/common.h, enum TuneKey, documents each; DESIGN.md's appendix lists them): key "gemm_h4" is the row read from
+ * the environment variable FL_GEMM_H4.  The environment is read ONCE, on first use; afterwards only this call changes a switch.
+ *   value        >= 0, or -1 = "automatic" for the switches that have such a setting
+ *   "reload_env" re-reads every FL_<NAME> from the environment (value ignored)
+ *   "gemv_blocks" / "gemv_waves"  force the decode GEMV's grid / waves per workgroup (0 = automatic); "gemv_r" rows per wave pass
+ *                (2|4) and "gemv_u" 512-element chunks per pipeline block (0 automatic, 2|4|7|8) are table rows like the rest
+ *   "experimental"  FL_OK in the EXPERIMENTAL build (make EXPERIMENTAL=1), FL_ERR_UNSUPPORTED in the default one
+ * FL_ERR_BAD_ARGUMENT: unknown key.  FL_ERR_UNSUPPORTED: the key belongs to a kernel that is compiled into the EXPERIMENTAL build
+ * only (decode engine, fused attention + o_proj, attention prefetch workgroups, loader waves, "engine_grid"); the default build's
+ * environment cannot reach those either. */
 int fl_tune(const char *key, int value);
 
 /* y[T,N] = x[T,K] . W[N,K]^T (+bias): the projection kernel family on host buffers, for unit

@@ -339,8 +339,12 @@ def test_mid_prompt_in_launch_slices_equal_the_slab_path(env, name, T):
     ids = synth.prompt_ids(cfg, T, seed=19)
     out = {}
     try:
-        for mode in (1, 0, 2):                          # 2: the in-launch path with the rms_finalize launches kept (rs_lazy = 0)
+        for mode in (1, 0, 2, 3):                       # 2: the in-launch path with the rms_finalize launches kept (rs_lazy = 0)
             fa.tune("gemm_h4", min(mode, 1)); fa.tune("rs_lazy", 0 if mode == 2 else 1)
+            # 3: a plan that is wrong on purpose -- every projection is CLAIMED to take its row scales as partial sums, so those whose
+            # kernel reads a vector only (Qwen2-7B's peeled gate/up with its stream-K tail) meet Launcher::rsp and must finish the sums
+            # into the vector themselves (rs_parts_to_vector) instead of failing the forward: the launches and bits of mode 1
+            fa.tune("debug_rs_parts", 1 if mode == 3 else 0)
             c = gm.new_cache(T + 8)
             gm.profile_begin()
             lg = gm.forward(c, ids, 0)
@@ -350,6 +354,9 @@ def test_mid_prompt_in_launch_slices_equal_the_slab_path(env, name, T):
     finally:
         fa.tune("reload_env", 0)
     nres = sum(v for n, v in out[1][2].items() if "h4," in n and "resid" in n)
+    for k in (0, 1):
+        np.testing.assert_array_equal(out[3][k], out[1][k])
+    assert out[3][2] == out[1][2], (out[3][2], out[1][2])
     # 1/rms taken from the partial sums by the consuming projection (Launcher::rsp) against the rms_finalize launch: the same numbers
     # up to the order a row's partial sums are added in -- a kernel that ignored the request would read a stale vector
     # (what stays: the last layer's -- the final norm wants the vector -- and those in front of a projection whose kernel takes a

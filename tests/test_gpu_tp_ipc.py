@@ -223,3 +223,38 @@ def test_stalled_peer_is_an_error_not_a_hang(tmp_path, name, tp, fused):
         assert "gave up waiting for a peer" in msg, msg
         assert ("0xa11e" in msg) == (fused == "2"), msg                   # which waiter reported: fused epilogue / one-shot kernel
         assert float(res[r]["waited_s"]) < 30.0
+
+
+@pytest.mark.parametrize("tp", [2, 4])
+def test_multiprocess_mid_prompt_kernels_at_7b_width(tmp_path, tp):
+    """Round 4's prompt kernels (128 x 256 tiles with in-launch K slices and the RoPE epilogue, 224-column gate/up tiles, row scales
+    as partial sums) had met the multi-process path only on toy widths.  Mistral-7B's layer shape, 512 tokens (BASELINE C3 / C4's
+    prompt), ranks as separate processes: (a) the side-stream schedule (all-reduces of one row chunk under the other's GEMMs) -- all
+    ranks the same bits, within bf16 tolerance of the fp32 oracle; (b) the same prompt with the all-reduces on the compute stream
+    -- the emulated group's bits exactly; and the kernels that ran are the mid-prompt ones."""
+    import fastllm_amd as fa
+    from fastllm_amd import binding
+    name, dtype, T = "mistral_wide", "bf16", 512
+    cfg = synth.CONFIGS[name]
+    res = run_group(tmp_path, name, dtype, tp, T=T, n_tf=2, n_greedy=4, env_extra={"TP_WORKER_PROFILE": "1", "FL_TP_OVERLAP": "1"})
+    for r in range(1, tp):
+        for k in ("prefill", "prefill_profiled", "decode", "tokens"):
+            np.testing.assert_array_equal(res[r][k], res[0][k], err_msg="rank %d vs 0: %s" % (r, k))
+    kernels = [str(k) for k in res[0]["prefill_kernels"]]
+    assert any("h4," in k for k in kernels), kernels                    # 128 x 256 tiles (k_gemm_h4.hip)
+    if tp == 2:
+        assert any("w14" in k for k in kernels), kernels                # a rank's gate/up is 14336 rows = 64 tiles of 224
+    w = synth.synth_weights(cfg)
+    ids = synth.prompt_ids(cfg, T + 2, seed=11)
+    gE = fa.Model(cfg, w, dtype=dtype, tp_mode=binding.TP_EMULATED, tp_size=tp)
+    cE = gE.new_cache(T + 16)
+    e = gE.forward(cE, ids[:T], 0)
+    np.testing.assert_array_equal(res[0]["prefill_profiled"], e)
+    om = oracle.OracleModel(cfg, synth.as_f32(w), round_bf16=True)
+    oc = om.new_cache(T + 16)
+    o = om.forward(oc, ids[:T], 0)
+    check_logits(res[0]["prefill"], o, dtype, "multi-process overlapped prefill vs oracle")
+    check_logits(e, o, dtype, "emulated prefill vs oracle")
+    o1 = om.forward(oc, ids[T:T + 1], T)
+    check_logits(res[0]["decode"][0], o1, dtype, "multi-process decode on the cache the prefill left vs oracle")
+    gE.close()

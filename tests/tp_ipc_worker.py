@@ -73,6 +73,14 @@ def run_rank(rank, world, name, dtype, outdir, T, n_tf, n_greedy):
     ids = synth.prompt_ids(cfg, T + n_tf, seed=11)
     c = m.new_cache(T + n_tf + n_greedy + 8)
     res = {"prefill": m.forward(c, ids[:T], 0)}
+    if os.environ.get("TP_WORKER_PROFILE", "") == "1":
+        # the same prompt again under the profiler: launches bracketed by events, which also keeps the all-reduces on the compute
+        # stream -- the schedule FL_TP_EMULATED runs, so these logits are the emulated group's bits
+        c2 = m.new_cache(T + 8)
+        m.profile_begin()
+        res["prefill_profiled"] = m.forward(c2, ids[:T], 0)
+        res["prefill_kernels"] = np.array(sorted(set(s["name"] for s in m.profile_end())))
+        c2.close()
     stalled = os.environ.get("TP_WORKER_STALLED_RANK", "")
     if stalled:
         # rank `stalled` never issues the decode step (but stays mapped: nobody may push into freed memory); the others
