@@ -522,7 +522,7 @@ def main():
     barrier()
 
     # ---- batched decode (scope row N4: concurrent streams share one weight read); NOT the headline metric ----
-    batch8 = None
+    batch8, batch32 = None, None
     if world == 1 and os.environ.get("FL_BENCH_BATCH", "1") == "1":
         try:
             nb, kb = 8, min(K, 64)
@@ -543,6 +543,33 @@ def main():
                       "aggregate_tokens_per_sec": round(nb * kb / tb, 1), "per_stream_tokens_per_sec": round(kb / tb, 1),
                       "note": "fl_batch_decode: 8 independent %d-token-prompt streams advanced together (k_gemv_batch.hip)" % T}
             log("batched decode x8: %.1f tokens/s aggregate" % batch8["aggregate_tokens_per_sec"])
+            bt.close()
+            # 32 streams (round 5: fl_batch takes up to 64): 24 more caches behind the same prompts' length
+            nb2 = 32
+            for i in range(nb, nb2):
+                pi = rs.randint(0, cfg["vocab_size"], size=T).astype(np.uint32)
+                ci = model.new_cache(T + kb + 24)
+                bfirst.append(model.forward_argmax(ci, pi, 0))
+                bc.append(ci)
+            for ci in bc[:nb]:                                               # the first eight decoded on: back to the prompt
+                ci.reset()
+            for i in range(nb):
+                pi = rs.randint(0, cfg["vocab_size"], size=T).astype(np.uint32)
+                bfirst[i] = model.forward_argmax(bc[i], pi, 0)
+            bt = fa.Batch(model, bc)
+            g = bt.decode(bfirst, [T] * nb2, 8)
+            model.synchronize()
+            t0 = time.perf_counter()
+            g = bt.decode([int(x[-1]) for x in g], [T + 8] * nb2, kb)
+            model.synchronize()
+            tb = time.perf_counter() - t0
+            bb = decode_bytes_per_token(cfg, 0) + nb2 * (decode_bytes_per_token(cfg, T + 8 + kb // 2) - decode_bytes_per_token(cfg, 0))
+            batch32 = {"streams": nb2, "steps": kb, "ms_per_step": round(tb / kb * 1e3, 4),
+                       "aggregate_tokens_per_sec": round(nb2 * kb / tb, 1), "per_stream_tokens_per_sec": round(kb / tb, 1),
+                       "hbm_frac_of_8TBps": round(bb / (tb / kb) / 8e12, 4),
+                       "note": "fl_batch_decode: 32 independent %d-token-prompt streams advanced together: the prefill-shaped step at T = 32 "
+                               "(short-prompt GEMM, batch attention); hbm_frac = (weights once + 32 streams' K / V) per step / 8 TB/s" % T}
+            log("batched decode x32: %.1f tokens/s aggregate" % batch32["aggregate_tokens_per_sec"])
             bt.close()
             for ci in bc:
                 ci.close()
@@ -645,6 +672,7 @@ def main():
             "parity_check": parity,
             "tokens_crc32": my_crc, "ranks_agree": ranks_agree,
             "batched_decode": batch8,
+            "batched_decode_32": batch32,
             "secondary": secondary,
             "fp32_mode_tokens_per_sec": fp32_mode["tokens_per_sec"] if fp32_mode and "tokens_per_sec" in fp32_mode else None,
             "fp32_mode": fp32_mode,

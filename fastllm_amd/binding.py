@@ -301,7 +301,7 @@ class Model:
 
 
 class Batch:
-    """fl_batch: up to 8 caches of one model decoded together."""
+    """fl_batch: up to 64 caches of one model decoded together."""
 
     def __init__(self, model, caches):
         self._model, self._caches = model, list(caches)

@@ -149,9 +149,12 @@ struct Cache {
     ~Cache();
 };
 
-// A fixed set of B <= 8 caches of one model decoded together (k_gemv_batch.hip): one read of the weights
-// per step serves every sequence.  Single GPU, bf16, MFMA-attention shapes.
-constexpr int kMaxBatch = 8;
+// A fixed set of B <= 64 caches of one model decoded together: one read of the weights per step serves every sequence.
+// Up to 8 rows the projections are the streaming GEMVs of k_gemv_batch.hip / k_gemv_dma.hip; beyond, the step is the
+// prefill-shaped one (rmsnorm_add, short-prompt GEMM, RoPE, attention as launches of their own) at T = B.
+// Single GPU, bf16, MFMA-attention shapes.
+constexpr int kMaxBatch = 64;
+constexpr int kMaxBatchGemv = 8;                 // rows the streaming GEMV kernels hold
 struct Batch {
     Model *m = nullptr;
     std::vector<Cache *> caches;

@@ -1550,9 +1550,12 @@ int batch_create(Model *m, Cache *const *caches, size_t B, Batch **out) {
     // B >= 3: the prefill-shaped step (separate norm / RoPE launches) with the wide projections on the LDS-DMA ring kernel
     b->dma = B >= (size_t)tune(TK_BATCH_DMA_MIN) && gemv_dma_supported((int)B, 2 * sh.Ip, D.h, EPI_GATEUP, 0) &&
              gemv_dma_supported((int)B, D.V, D.h, EPI_F32, 0) && gemv_dma_ksplit(D.h, 0, EPI_GATEUP) == 1;
-    b->nks_o = gemv_batch_ksplit((int)B, sh.Hs * D.d, D.h, EPI_F32);
-    b->nks_down = gemv_batch_ksplit((int)B, sh.Ip, D.h, EPI_F32);
-    if (gemv_batch_ksplit((int)B, D.h, 2 * sh.Ip, EPI_GATEUP) != 1) FL_FAIL(FL_ERR_UNSUPPORTED, "hidden size %lld too large for the batched norm prologue", (long long)D.h);
+    const bool gemv_rows = B <= (size_t)kMaxBatchGemv;         // the streaming GEMV forms hold at most eight rows
+    if (gemv_rows) {
+        b->nks_o = gemv_batch_ksplit((int)B, sh.Hs * D.d, D.h, EPI_F32);
+        b->nks_down = gemv_batch_ksplit((int)B, sh.Ip, D.h, EPI_F32);
+        if (gemv_batch_ksplit((int)B, D.h, 2 * sh.Ip, EPI_GATEUP) != 1) FL_FAIL(FL_ERR_UNSUPPORTED, "hidden size %lld too large for the batched norm prologue", (long long)D.h);
+    }
     FL_HIP(hipSetDevice(sh.device));
     std::vector<SeqRef> refs(B);
     for (size_t i = 0; i < B; i++) {
@@ -1576,6 +1579,8 @@ int batch_create(Model *m, Cache *const *caches, size_t B, Batch **out) {
     // ms per step, unfused vs fused): B = 3 4.16 / 3.87, 4 4.21 / 3.99, 6 4.24 / 4.18, 8 4.26 / 4.38
     b->unfused = B >= (size_t)(tune(TK_BATCH_UNFUSED_MIN) >= 0 ? tune(TK_BATCH_UNFUSED_MIN) : (b->dma ? 3 : 7)) && gemm_skinny_supported((int64_t)B, D.h, D.h) &&
                  gemm_skinny_supported((int64_t)B, D.h, sh.Ip);
+    // more than eight streams: always the prefill-shaped step (launch_linear finds a kernel for every shape)
+    if (!gemv_rows) b->unfused = true;
     if (b->unfused) {
         FL_TRY(alloc_scratch(m, sh, b->sc, (int64_t)B, &b->allocs));
     }

@@ -220,7 +220,7 @@ int fl_forward_sample(fl_model *m, fl_cache *c, const uint32_t *ids, size_t T, s
 int fl_decode_sample(fl_model *m, fl_cache *c, uint32_t first_token, size_t pos, size_t n_steps, int64_t eos,
                      const fl_sampling *sampling, uint32_t *tokens_out, size_t *n_out);
 
-/* Batched decode: B <= 8 caches of one model advanced together, one read of the weights per step for all
+/* Batched decode: B <= 64 caches of one model advanced together, one read of the weights per step for all
  * of them.  New capability: the reference runs concurrent streams as independent single-sequence loops
  * (mod.rs:137-238), each paying for the whole weight stream.  Every sequence keeps its own cache, RoPE
  * position and sampler state; per sequence the results are those of the single-sequence entry points

@@ -251,7 +251,7 @@ impl Cache {
     }
 }
 
-/// `fl_batch*`: up to 8 caches of one model decoded together (one read of the weights per step for all of them).
+/// `fl_batch*`: up to 64 caches of one model decoded together (one read of the weights per step for all of them).
 pub struct Batch<'a> {
     raw: *mut ffi::fl_batch,
     n: usize,

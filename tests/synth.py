@@ -78,7 +78,7 @@ CONFIGS = {
     # Mistral-7B's layer shape (h 4096, i 14336, 32/8 heads of 128), two layers, small vocabulary: full-size GEMV grids
     "mistral_wide": dict(family="mistral", hidden_size=4096, intermediate_size=14336, vocab_size=1024,
                          num_hidden_layers=2, num_attention_heads=32, num_key_value_heads=8,
-                         rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=512, sliding_window=4096),
+                         rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=1024, sliding_window=4096),
 }
 
 

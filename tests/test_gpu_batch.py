@@ -42,13 +42,13 @@ def tight(a, b, what, B=1):
 
 
 @pytest.mark.parametrize("name", ["llama_a", "mistral_a", "qwen2_a", "llama_mha", "llama_tp4"])
-@pytest.mark.parametrize("B", [1, 3, 8])
+@pytest.mark.parametrize("B", [1, 3, 8, 9, 16, 32])
 def test_batch_forward_matches_single_and_oracle(fa, name, B):
     cfg = synth.CONFIGS[name]
     w = synth.synth_weights(cfg)
     gm = fa.Model(cfg, w, dtype="bf16")
     om = oracle.OracleModel(cfg, synth.as_f32(w), round_bf16=True)
-    lens = [5 + 3 * i for i in range(B)]                       # ragged: every sequence at its own position
+    lens = [5 + (3 * i) % 41 for i in range(B)]                # ragged: every sequence at its own position
     caches, firsts, prompts = prefilled(gm, cfg, lens)
     singles, _, _ = prefilled(gm, cfg, lens)
     ocs = []
@@ -71,12 +71,12 @@ def test_batch_forward_matches_single_and_oracle(fa, name, B):
     batch.close()
 
 
-@pytest.mark.parametrize("B", [2, 5, 8])
+@pytest.mark.parametrize("B", [2, 5, 8, 16, 32, 64])
 def test_batch_decode_loop_matches_single_loops(fa, B):
     cfg = synth.CONFIGS["mistral_a"]
     w = synth.synth_weights(cfg)
     gm = fa.Model(cfg, w, dtype="bf16")
-    lens = [4 + 2 * i for i in range(B)]
+    lens = [4 + (2 * i) % 37 for i in range(B)]
     caches, firsts, _ = prefilled(gm, cfg, lens)
     singles, firsts2, _ = prefilled(gm, cfg, lens)
     assert firsts == firsts2
@@ -163,7 +163,7 @@ def test_batch_errors(fa):
     with pytest.raises(fa.FastLLMError):
         fa.Batch(gm, [c, c])                                     # the same cache twice
     with pytest.raises(fa.FastLLMError):
-        fa.Batch(gm, [gm.new_cache(8) for _ in range(9)])        # more than 8
+        fa.Batch(gm, [gm.new_cache(8) for _ in range(65)])       # more than 64
     g32 = fa.Model(cfg, w, dtype="f32")
     with pytest.raises(fa.FastLLMError) as e:
         fa.Batch(g32, [g32.new_cache(8)])

@@ -241,9 +241,7 @@ def test_multiprocess_mid_prompt_kernels_at_7b_width(tmp_path, tp):
         for k in ("prefill", "prefill_profiled", "decode", "tokens"):
             np.testing.assert_array_equal(res[r][k], res[0][k], err_msg="rank %d vs 0: %s" % (r, k))
     kernels = [str(k) for k in res[0]["prefill_kernels"]]
-    assert any("h4," in k for k in kernels), kernels                    # 128 x 256 tiles (k_gemm_h4.hip)
-    if tp == 2:
-        assert any("w14" in k for k in kernels), kernels                # a rank's gate/up is 14336 rows = 64 tiles of 224
+    assert any("h4," in k for k in kernels), kernels                    # 128 x 256 tiles, K slices met in the launch (k_gemm_h4.hip)
     w = synth.synth_weights(cfg)
     ids = synth.prompt_ids(cfg, T + 2, seed=11)
     gE = fa.Model(cfg, w, dtype=dtype, tp_mode=binding.TP_EMULATED, tp_size=tp)
