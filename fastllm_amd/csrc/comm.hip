@@ -36,6 +36,33 @@ void comm_forget(void *local) {
     g_exported.erase(std::remove_if(g_exported.begin(), g_exported.end(), [&](auto &e) { return e.second == local; }), g_exported.end());
 }
 
+// hipDeviceMallocUncached buffers are NEVER handed back to the runtime.  Found in round 5 (tools/seq_probe.py): after a model with an
+// uncached inbox had been destroyed -- hipFree of the inbox -- later models of the same process, single-GPU ones included, computed
+// garbage (10 of 12 models wrong, deterministically; with the inbox from plain hipMalloc, or never freed, 0 of 12): on this stack
+// (ROCm 7.2, dmabuf IPC) memory that was once mapped uncached and freed comes back to later allocations in a state that corrupts them.
+// A destroyed shard's inbox (1-3 MB) goes to a free list instead and serves the next shard that asks for that device and size.
+struct InboxBuf { int device; size_t bytes; void *p; };
+static std::mutex g_inbox_mu;
+static std::vector<InboxBuf> g_inbox_free;
+static int inbox_acquire(int device, size_t bytes, void **out) {
+    {
+        std::lock_guard<std::mutex> lock(g_inbox_mu);
+        for (size_t i = 0; i < g_inbox_free.size(); i++)
+            if (g_inbox_free[i].device == device && g_inbox_free[i].bytes == bytes) {
+                *out = g_inbox_free[i].p;
+                g_inbox_free.erase(g_inbox_free.begin() + (long)i);
+                return FL_OK;
+            }
+    }
+    FL_HIP(hipExtMallocWithFlags(out, bytes, hipDeviceMallocUncached));
+    return FL_OK;
+}
+void comm_inbox_release(int device, size_t bytes, void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(g_inbox_mu);
+    g_inbox_free.push_back(InboxBuf{device, bytes, p});
+}
+
 int comm_alloc(Model *m, Shard &sh) {
     PeerComm &pc = sh.pc;
     FL_HIP(hipSetDevice(sh.device));
@@ -43,7 +70,7 @@ int comm_alloc(Model *m, Shard &sh) {
     pc.nmax = (std::max<int64_t>(std::max<int64_t>(tune(TK_AR_INBOX_FLOATS), sh.Vs), 4) + 3) / 4 * 4;
     pc.ll_off = (kCommFlagBytes + (size_t)2 * m->tp * pc.nmax * 4 + 255) & ~(size_t)255;
     pc.bytes = pc.ll_off + (size_t)2 * m->tp * m->D.h * 8;
-    FL_HIP(hipExtMallocWithFlags(&pc.local, pc.bytes, hipDeviceMallocUncached));
+    FL_TRY(inbox_acquire(sh.device, pc.bytes, &pc.local));
     FL_HIP(hipMemset(pc.local, 0, pc.bytes));
     FL_HIP(hipMalloc((void **)&pc.epoch, 64));
     FL_HIP(hipMemset(pc.epoch, 0, 64));
@@ -67,7 +94,7 @@ int comm_ll_publish(Model *m, Shard &sh) {
     PeerComm &pc = sh.pc;
     FL_HIP(hipSetDevice(sh.device));
     pc.ll.epoch_ctr = pc.epoch; pc.ll.err = pc.err; pc.ll.abort_flag = pc.epoch + 8; pc.ll.timeout_ticks = pc.timeout_ticks;
-    pc.ll.rank = sh.rank; pc.ll.tp = m->tp; pc.ll.n = (int)m->D.h; pc.ll.slots = (int)(2 * m->D.L);
+    pc.ll.rank = sh.rank; pc.ll.tp = m->tp; pc.ll.n = (int)m->D.h; pc.ll.slots = (int)(2 * m->D.L); pc.ll.loop = pc.loopback ? 1 : 0;
     FL_HIP(hipMemcpy(pc.ll_dev, &pc.ll, sizeof(LLTable), hipMemcpyHostToDevice));
     pc.ll_ok = true;
     return FL_OK;
@@ -137,6 +164,19 @@ static int comm_connect_impl(Model *m, const void *handles) {
         if (hipPointerGetAttributes(&at, p) == hipSuccess) pc.shares_device = pc.shares_device || at.device == sh.device;
         else (void)hipGetLastError();
     }
+    pc.connected = true;
+    return comm_ll_publish(m, sh);
+}
+
+// TK_DEBUG_TP_LOOPBACK: one rank of a tp-way group alone on its GPU, every inbox entry its own: the kernels push what the tp ranks
+// would push (CommTable::loop, LLTable::loop) and find it at once, so the rank's step runs with its exchange code in place and
+// no peer to wait for.  What it measures: the rank's own time per step.  What it computes: nothing meaningful (sums of tp copies).
+int comm_connect_loopback(Model *m) {
+    Shard &sh = m->shards[0];
+    PeerComm &pc = sh.pc;
+    for (int r = 0; r < m->tp; r++) comm_set_entry(pc, r, pc.local);
+    pc.tab.loop = 1;
+    pc.loopback = true;
     pc.connected = true;
     return comm_ll_publish(m, sh);
 }

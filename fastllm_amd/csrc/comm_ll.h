@@ -26,7 +26,7 @@ __device__ inline void ll_allreduce_rows(const LLTable *__restrict__ t, int slot
 #pragma unroll
     for (int r = 0; r < R; r++) got[r] = 0.f;
     if (lane < tp) {
-        uint64_t *dst = t->peer[lane] + half + (size_t)rank * n + row0;
+        uint64_t *dst = t->peer[lane] + half + (size_t)(t->loop ? lane : rank) * n + row0;      // (loopback: the own region's slot [lane])
 #pragma unroll
         for (int r = 0; r < R; r++)
             if (row0 + r < N)

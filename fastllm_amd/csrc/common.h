@@ -114,6 +114,8 @@ enum TuneKey {
     TK_RS_LAZY,   // 1/rms behind a residual epilogue: taken from the partial sums by the consuming projection (0: rms_finalize launch)
     TK_BATCH_UNFUSED_MIN,   // first batch size on the prefill-shaped step (-1: 3 with the ring kernel, else 7)
     TK_DEBUG_RS_PARTS,   // tests: gemm_takes_rs_parts() answers yes for every bf16 prompt shape, so that kernels which cannot take partial sums meet them (rs_parts_to_vector)
+    TK_DEBUG_TP_LOOPBACK,   // tools: an FL_TP_MULTI_PROCESS model without unique_id connects every inbox entry to ITSELF and plays all ranks' pushes (one rank's step, timed with its exchange in place; results meaningless)
+    TK_DEBUG_POISON,   // tests: every device allocation of the model / cache / batch objects is filled with this byte before use (255: bf16 / fp32 NaN patterns; 63: finite 0.75s), so that a read of bytes nobody wrote shows at once instead of depending on what the allocator handed back
     TK_COUNT
 };
 int tune(TuneKey k);

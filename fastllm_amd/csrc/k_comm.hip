@@ -29,23 +29,25 @@ __global__ __launch_bounds__(1024) void oneshot_kernel(const float *__restrict__
     const size_t half = (size_t)(e & 1) * tp * nmax;
     if (tid == 0) s_bad = 0;
 
-    // push: my vector into slot [rank] of every rank's inbox (own inbox included: one code path)
+    // push: my vector into slot [rank] of every rank's inbox (own inbox included: one code path).  Loopback (CommTable::loop): every
+    // entry is the own inbox, and the store that would go to rank p's slot [rank] goes to the own slot [p]
     const size_t my_slot = half + (size_t)rank * nmax;
+    const size_t slot_step = tab.loop ? (size_t)nmax : 0, slot0 = tab.loop ? half : my_slot;
     if ((n & 3) == 0) {
         for (int i = tid * 4; i < n; i += 4096) {
             const float4v v = *reinterpret_cast<const float4v *>(in + i);
-            for (int p = 0; p < tp; p++) *reinterpret_cast<float4v *>(tab.inbox[p] + my_slot + i) = v;
+            for (int p = 0; p < tp; p++) *reinterpret_cast<float4v *>(tab.inbox[p] + slot0 + p * slot_step + i) = v;
         }
     } else {
         for (int i = tid; i < n; i += 1024) {
             const float v = in[i];
-            for (int p = 0; p < tp; p++) tab.inbox[p][my_slot + i] = v;
+            for (int p = 0; p < tp; p++) tab.inbox[p][slot0 + p * slot_step + i] = v;
         }
     }
     __threadfence_system();                       // every store has been acknowledged by its peer before a flag is raised
     __syncthreads();
     if (tid < tp) {
-        __hip_atomic_store(tab.flags[tid] + rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(tab.flags[tid] + (tab.loop ? tid : rank), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         // wait for rank `tid`'s flag in my own inbox; bounded so a dead peer cannot hang the GPU
         const uint32_t *f = tab.flags[rank] + tid;
         const long long t0 = wall_clock64();

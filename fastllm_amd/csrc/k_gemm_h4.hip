@@ -576,6 +576,27 @@ int gemm_h4_plan(int64_t T, int64_t N, int64_t K, int epi) {
     return 0;
 }
 
+// A projection whose caller needs ONE complete output and cannot hand K slabs to the next launch: a tensor-parallel rank's row-parallel
+// projections (the all-reduce wants the sum) and its shard of gate/up.  Their grids are a fraction of the single-GPU ones -- Mistral-7B
+// at tp = 2, 512 tokens: o_proj 4096 x 2048 and down_proj 4096 x 7168 are 128 tiles of 128 x 128 with 32 / 112 K steps, which that
+// kernel ran unsliced at 220-280 TFLOP/s (profiles/r05/tp_prefill_before.txt: a rank's 512-token prefill took LONGER at tp = 2 than the
+// whole model on one GPU) -- so K slices that meet inside the launch are what fills the chip.  0: not here.
+int gemm_h4_plan_whole(int64_t T, int64_t N, int64_t K, int epi) {
+    if (tune(TK_GEMM_H4) <= 0 || T <= 128 || T > 1024 || (epi != EPI_F32 && epi != EPI_GATEUP && epi != EPI_QKV_ROPE)) return 0;
+    const int64_t tiles = ((T + H4_BM - 1) / H4_BM) * ((N + H4_BN - 1) / H4_BN), nk = K / P_BK;
+    const int64_t t8 = ((T + 255) / 256) * ((N + 255) / 256);
+    if (t8 >= 128 || tiles > 256) return 0;                          // (half a round of 256 x 256 tiles and more: the large kernels' shapes)
+    int ks = 1;
+    while (ks < H4_MAXS && tiles * (ks + 1) <= 256 && nk / (ks + 1) >= 8) ks++;
+    if (epi == EPI_QKV_ROPE) {                                       // a rank's q | k | v rows: RoPE, bias and the KV append in the epilogue (1, 2 or 4 slices)
+        if (ks == 3) ks = 2;
+        // (tp = 4: 1536 rows = 24 tiles x 4 slices; against 128 x 128 tiles in K slabs + the rope_kv launch that sums them)
+        return gemm_h4_supported(T, N, K, ks) && tiles * ks >= 96 ? ks : 0;       // (tp = 8: 12 tiles x 4 = a tie, stays)
+    }
+    if (!gemm_h4_supported(T, N, K, ks) || tiles * ks < 96) return 0;
+    return ks;
+}
+
 // The tail columns of a column-peeled GEMM (k_gemm_mfma.hip: whole rounds of 256 x 256 tiles + at most half a round more): instead of the
 // stream-K launch and its fix-up launch, ONE launch of this kernel when the tail's 128 x 256 tiles times 2-4 K slices fill most of the
 // chip -- any epilogue, the slices summed inside.  (Qwen2-7B: the 5120 gate/up columns past 32768 at 512 tokens 31.3 + 13.2 us as

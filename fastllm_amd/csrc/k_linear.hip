@@ -115,6 +115,11 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
         if (!force_generic && T > 1) {
             const int ks = gemm_h4_plan(T, N, K, epi);
             if (ks > 0) return launch_gemm_h4(L, W, x, bias, y, T, N, K, epi, row_scale, ks);
+            // a tensor-parallel rank's projections (no slabs: the all-reduce wants the sum): K slices that meet inside the launch
+            if (L.tp > 1 && max_split <= 1) {
+                const int kw = gemm_h4_plan_whole(T, N, K, epi);
+                if (kw > 0) return launch_gemm_h4(L, W, x, bias, y, T, N, K, epi, row_scale, kw);
+            }
             // 224-column tiles where they fill the chip and 256-column ones do not (k_gemm_w14.hip)
             if (gemm_w14_plan(T, N, K, epi)) return launch_gemm_w14(L, W, x, bias, y, T, N, K, epi, row_scale);
         }

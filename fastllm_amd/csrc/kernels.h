@@ -26,6 +26,7 @@ struct Launcher {
     RsParts rsp;                               // non-null part: the next projection's row scales come from these partial sums
     std::vector<ProfRecord> *prof = nullptr;   // non-null: bracket every launch with HIP events
     const char *tag = "";                      // optional sub-class label for the profile (shape, variant)
+    int tp = 1;                                // tensor-parallel degree of the model this launch belongs to (> 1: a rank's shard shapes -- launch_linear plans for those)
 
     template <typename... KArgs, typename... Args>
     int launch(int kc, double bytes, double flops, void (*kernel)(KArgs...), dim3 grid, dim3 block,
@@ -239,6 +240,7 @@ struct H4Space {
 };
 bool gemm_h4_supported(int64_t T, int64_t N, int64_t K, int ksplit);
 int gemm_h4_plan(int64_t T, int64_t N, int64_t K, int epi);
+int gemm_h4_plan_whole(int64_t T, int64_t N, int64_t K, int epi);   // ... for a caller that needs one complete output (no slabs): a tensor-parallel rank's projections
 // 256 x 224 four-wave tile (k_gemm_w14.hip): fp32 / gate-up epilogues, N whole 224-column tiles
 // fp32 operands on the matrix cores (k_gemm_f32.hip): the fp32 mode's prompt GEMM, bit-identical to gemm_generic_kernel's fmaf chains
 bool gemm_f32_mfma_supported(int64_t T, int64_t N, int64_t K);
@@ -301,7 +303,11 @@ int launch_reduce_shards(Launcher &L, float *const *bufs_dev, int nshards, int64
 constexpr int FL_MAX_TP = 8;
 // Per-rank view of the tp inboxes: entry r is rank r's inbox / flag array as mapped in THIS process
 // (own allocation for r == rank, hipIpcOpenMemHandle / peer pointer otherwise).
-struct CommTable { float *inbox[FL_MAX_TP]; uint32_t *flags[FL_MAX_TP]; };
+struct CommTable {
+    float *inbox[FL_MAX_TP]; uint32_t *flags[FL_MAX_TP];
+    int loop = 0;        // 1: LOOPBACK (tools/tp_rank_loopback.py, TK_DEBUG_TP_LOOPBACK): every entry is this rank's own inbox and the kernel plays all
+                         // tp ranks' pushes itself -- one rank's step timed with its exchange in place, results meaningless
+};
 int launch_oneshot(Launcher &L, bool gather, const float *in, float *out, const CommTable &tab, int rank, int tp,
                    int64_t n, int64_t nmax, int64_t out_stride, uint32_t *epoch_ctr, uint32_t *err, long long timeout_ticks,
                    uint32_t *abort_flag = nullptr);
@@ -319,6 +325,7 @@ struct LLTable {
     uint32_t *abort_flag;           // device word, set with err: later waits of a broken step give up after ~1 ms
     long long timeout_ticks;
     int rank, tp, n, slots;
+    int loop;                       // 1: loopback (see CommTable::loop): lane p pushes into slot [p] of its own region
 };
 // stand-alone exerciser of ll_allreduce_rows (bootstrap self-test, tests): out[i] = sum_r in_r[i], i < n
 int launch_ll_allreduce(Launcher &L, const LLTable *ll_dev, int slot, const float *in, float *out, int64_t n);

@@ -64,6 +64,7 @@ struct PeerComm {
     LLTable ll{};                // host copy; `ll_dev` is what the kernels read
     LLTable *ll_dev = nullptr;
     bool ll_ok = false;          // region connected (and, with RCCL, proven against ncclAllReduce by all ranks)
+    bool loopback = false;       // TK_DEBUG_TP_LOOPBACK: all entries are this rank's own inbox, the kernels play every rank's push
     bool shares_device = false;  // a peer lives on this same GPU (rehearsals): full-chip grids that wait for each other cannot co-reside
 };
 
@@ -202,9 +203,11 @@ void debug_inject(const char *site);     // FL_DEBUG_THROW fault injection (test
 Launcher make_launcher(Model *m, Shard &sh);
 // comm.hip: inbox / LL region of one shard, its table entries, and the group-level steps
 int comm_alloc(Model *m, Shard &sh);
+void comm_inbox_release(int device, size_t bytes, void *p);   // a destroyed shard's uncached inbox goes to a free list, never back to the runtime (comm.hip)
 void comm_forget(void *local);                         // a destroyed shard's inbox leaves the table of handles exported by this process
 void comm_set_entry(PeerComm &pc, int r, void *base);
 int comm_ll_publish(Model *m, Shard &sh);              // every entry is set: hand the fused all-reduce's table to the device
+int comm_connect_loopback(Model *m);                   // TK_DEBUG_TP_LOOPBACK: every entry is this rank's own inbox (timing tool)
 int comm_bootstrap_over_rccl(Model *m);                // all-gather the handles through RCCL, connect, self-test, vote
 int comm_probe(Model *m, int form, int64_t n, int iters, double *us_per_call);   // fl_comm_probe
 int comm_check(Model *m);                              // a kernel gave up waiting for a peer -> FL_ERR_RCCL

@@ -128,6 +128,8 @@ static const TuneEntry g_tune_table[TK_COUNT] = {
     {"rs_lazy", 1},
     {"batch_unfused_min", -1},
     {"debug_rs_parts", 0},
+    {"debug_tp_loopback", 0},
+    {"debug_poison", 0},
 };
 static_assert(sizeof(g_tune_table) / sizeof(g_tune_table[0]) == TK_COUNT, "one row per TuneKey, in the enum's order");
 static std::atomic<int> g_tune[TK_COUNT];
@@ -150,6 +152,7 @@ int tune(TuneKey k) {
     std::call_once(g_tune_once, tune_read_env);
     return g_tune[k].load(std::memory_order_relaxed);
 }
+void tune_poison_restart();
 int tune_set(const char *name, int value) {
     std::call_once(g_tune_once, tune_read_env);
     for (int k = 0; k < TK_COUNT; k++)
@@ -158,6 +161,7 @@ int tune_set(const char *name, int value) {
             if (g_tune_table[k].exp_only) return FL_ERR_UNSUPPORTED;
             if (k == TK_H4_PF) value &= 0xFFFF;      // (bit 16 is a wrong-results timing probe of the experimental build)
 #endif
+            if (k == TK_DEBUG_POISON) tune_poison_restart();
             g_tune[k].store(value, std::memory_order_relaxed);
             return FL_OK;
         }
@@ -261,6 +265,8 @@ int tp_slice(const Dims &D, const char *name_c, int rank, int tp, int64_t out[4]
 }
 
 // ------------------------------------------------------------------------------- allocation
+static std::atomic<int> g_poison_count{0};
+void tune_poison_restart() { g_poison_count.store(0); }
 static int dev_alloc(std::vector<void *> &owner, void **p, size_t bytes, int64_t *acct) {
     if (bytes == 0) bytes = 16;
     const hipError_t e = hipMalloc(p, bytes);
@@ -268,6 +274,11 @@ static int dev_alloc(std::vector<void *> &owner, void **p, size_t bytes, int64_t
     FL_HIP(e);
     owner.push_back(*p);
     if (acct) *acct += (int64_t)bytes;
+    if (const int fill = tune(TK_DEBUG_POISON)) {
+        // bits 0-7: the byte; bits 8+: 0 = every allocation, n = only the n-th since the switch was last set (tools/poison_probe.py scans)
+        const int nth = g_poison_count.fetch_add(1) + 1, want = fill >> 8;
+        if (want == 0 || want == nth) { FL_HIP(hipMemset(*p, fill & 0xFF, bytes)); FL_HIP(hipDeviceSynchronize()); }
+    }
     return FL_OK;
 }
 
@@ -280,7 +291,7 @@ Model::~Model() {
         if (s.comm_stream) { (void)hipStreamSynchronize(s.comm_stream); (void)hipStreamDestroy(s.comm_stream); }
         for (auto &e : s.ev) if (e) (void)hipEventDestroy(e);
         for (void *mp : s.pc.mapped) if (mp) (void)hipIpcCloseMemHandle(mp);
-        if (s.pc.local) { comm_forget(s.pc.local); (void)hipFree(s.pc.local); }
+        if (s.pc.local) { comm_forget(s.pc.local); comm_inbox_release(s.device, s.pc.bytes, s.pc.local); }
         if (s.pc.epoch) (void)hipFree(s.pc.epoch);
         if (s.pc.ll_dev) (void)hipFree(s.pc.ll_dev);
         if (s.pc.err) (void)hipHostFree(s.pc.err);
@@ -718,6 +729,8 @@ int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int c
             FL_HIP(hipSetDevice(m->shards[0].device));
             FL_NCCL(ncclCommInitRank(&m->shards[0].comm, tp, id, P.tp_rank));
             if (tune(TK_ONESHOT)) FL_TRY(comm_bootstrap_over_rccl(m.get()));
+        } else if (tune(TK_DEBUG_TP_LOOPBACK)) {
+            FL_TRY(comm_connect_loopback(m.get()));
         }
     } else if (tp > 1 && P.mode == FL_TP_EMULATED) {
         FL_HIP(hipMalloc((void **)&m->emu_ptrs, sizeof(float *) * tp * 2));
@@ -856,7 +869,7 @@ SampleState make_sampler(const fl_sampling *sp) {
 }
 
 Launcher make_launcher(Model *m, Shard &sh) {
-    Launcher L; L.stream = sh.stream; L.prof = m->profiling ? &m->prof : nullptr; return L;
+    Launcher L; L.stream = sh.stream; L.prof = m->profiling ? &m->prof : nullptr; L.tp = m->tp; return L;
 }
 
 // all-reduce(sum) of each local shard's `delta` [count] fp32 (after o_proj / down_proj rows)
@@ -1247,7 +1260,8 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             // (Qwen2's q/k/v bias moves into the RoPE launch, which sums the slabs anyway: with the bias in the GEMM epilogue the
             // projection could not run in K slices and a mid-size prompt's QKV sat on 128x128 tiles -- T = 512: 63 us at 0.27 PFLOP/s)
             const int64_t sa = (int64_t)c->seq_alloc;
-            const int h4_qkv = dt == FL_DTYPE_BF16 ? gemm_h4_plan(T, nq, D.h, EPI_QKV_ROPE) : 0;
+            int h4_qkv = dt == FL_DTYPE_BF16 ? gemm_h4_plan(T, nq, D.h, EPI_QKV_ROPE) : 0;
+            if (!h4_qkv && dt == FL_DTYPE_BF16 && m->tp > 1 && D.d * sh.Hkvs % 128 == 0 && nq % 128 == 0) h4_qkv = gemm_h4_plan_whole(T, nq, D.h, EPI_QKV_ROPE);   // (a rank's narrower q | k | v)
             with_parts(L, sc);                                       // (the previous layer's down_proj may have left 1/rms as partial sums)
             if (h4_qkv) {
                 // mid-size prompts: RoPE, bias and the KV append ride in the projection's epilogue (k_gemm_h4.hip): no fp32 QKV matrix

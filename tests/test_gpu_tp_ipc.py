@@ -73,6 +73,8 @@ def test_multiprocess_oneshot_matches_emulated_and_oracle(tmp_path, name, tp, dt
     f = gN.forward_argmax(cN, ids[:1], T + n_tf)
     rest = gN.decode_greedy(cN, f, T + n_tf + 1, n_greedy)
     np.testing.assert_array_equal(res[0]["tokens"], np.concatenate([[f], rest]).astype(np.uint32))
+    cN.close()
+    gN.close()
 
 
 def test_small_inbox_chunks_collectives(tmp_path):
@@ -95,7 +97,11 @@ def test_unconnected_group_fails_loudly():
     c = m.new_cache(16)
     with pytest.raises(fa.FastLLMError) as e:
         m.forward(c, [1, 2, 3], 0)
-    assert "not connected" in str(e.value)
+    msg = str(e.value)
+    del e                                    # (the exception info holds the frame, i.e. the model: it would live until some later gc pass)
+    assert "not connected" in msg
+    c.close()
+    m.close()
 
 
 @pytest.mark.parametrize("name,tp,dtype", [("llama_a", 2, "bf16"), ("qwen2_a", 2, "f32"), ("mistral_a", 2, "bf16")])
@@ -105,8 +111,13 @@ def test_single_process_group_on_one_device(name, tp, dtype):
     Same partition and summation order as FL_TP_EMULATED, so the results must be the same bits.  (Two shards only:
     on ONE device the shards' streams share the process's few hardware queues, and a shard whose launches queue
     behind another shard's waiting collective can never signal it; with one device per shard that cannot happen.)"""
+    import gc
     import fastllm_amd as fa
     from fastllm_amd import binding
+    # models that earlier tests left to the garbage collector still own streams: on ONE device this process's streams share a few
+    # hardware queues, and the two shards' streams must not land on one (tools/sp_probe.py: a third model alive -> a shard waits
+    # for a peer whose launches sit behind it in the same queue)
+    gc.collect()
     cfg = synth.CONFIGS[name]
     w = synth.synth_weights(cfg)
     gS = fa.Model(cfg, w, dtype=dtype, tp_mode=binding.TP_SINGLE_PROCESS, tp_size=tp, device_ids=[0] * tp)
