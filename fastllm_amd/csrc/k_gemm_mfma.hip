@@ -427,6 +427,7 @@ int launch_gemm_qkv_rope_long(Launcher &L, const void *W, const void *x, const f
 bool gemm_takes_rs_parts(int dtype, int64_t T, int64_t N, int64_t K, int epi, int max_split) {
     if (dtype != FL_DTYPE_BF16 || T <= 1 || tune(TK_FORCE_GENERIC_GEMM)) return false;
     if (tune(TK_DEBUG_RS_PARTS)) return true;                        // (tests: a plan that is wrong on purpose)
+    if (tune(TK_GEMM_SKF) >= 2 && gemm_skf_plan(T, N, K, epi) > 0 && (epi == EPI_GATEUP || tune(TK_GEMM_SKF) >= 3)) return true;   // short prompts: k_gemm_skf.hip sums the partials itself
     if (gemm_h4_plan(T, N, K, epi) > 0 || gemm_w14_plan(T, N, K, epi)) return true;
     if (tune(TK_GEMM_SKINNY) && gemm_skinny_supported(T, N, K)) return false;
     if (!gemm_mfma_supported(dtype, T, N, K)) return false;
@@ -442,6 +443,7 @@ bool gemm_takes_rs_parts(int dtype, int64_t T, int64_t N, int64_t K, int epi, in
 int gemm_resid_partials(int64_t N) { return (int)((N + 255) / 256) * 4; }
 bool gemm_resid_supported(int dtype, int64_t T, int64_t N, int64_t K, int max_split) {
     if (tune(TK_GEMM_RESID) == 0) return false;
+    if (dtype == FL_DTYPE_BF16 && tune(TK_GEMM_SKF) >= 2 && gemm_skf_plan(T, N, K, EPI_RESID) > 0) return true;   // short prompts: k_gemm_skf.hip (opt-in)
     if (dtype == FL_DTYPE_BF16 && N % 16 == 0 && gemm_h4_plan(T, N, K, EPI_RESID) > 0) return true;   // mid-size prompts: k_gemm_h4.hip
     if (dtype != FL_DTYPE_BF16 || tune(TK_GEMM_8P) != 1 || T < 256 || K % 64 || K / 64 < 2 || N % 16) return false;
     if (gemm_streamk_whole(T, N, K, EPI_F32)) return false;
@@ -462,6 +464,7 @@ bool gemm_resid_supported(int dtype, int64_t T, int64_t N, int64_t K, int max_sp
 }
 int launch_gemm_resid(Launcher &L, const void *W, const void *x, int64_t T, int64_t N, int64_t K, const ResidEpi &re) {
     if (re.np != gemm_resid_partials(N)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_resid: partial-sum layout");
+    if (const int ks = tune(TK_GEMM_SKF) >= 2 ? gemm_skf_plan(T, N, K, EPI_RESID) : 0) return launch_gemm_skf(L, W, x, nullptr, nullptr, T, N, K, EPI_RESID, nullptr, ks, &re);
     if (const int ks = gemm_h4_plan(T, N, K, EPI_RESID)) return launch_gemm_h4(L, W, x, nullptr, nullptr, T, N, K, EPI_RESID, nullptr, ks, N, &re);
     int64_t n_main = 0;
     if (peel_plan(T, N, K, &n_main)) {

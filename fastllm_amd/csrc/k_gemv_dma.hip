@@ -1,4 +1,4 @@
-// k_gemv_dma.hip -- the WIDE projections of a batched decode step (3 <= B <= 8 sequences; gate/up and lm_head: thousands
+// k_gemv_dma.hip -- the WIDE projections of a batched decode step or a very short prompt (3 <= B <= 16 rows; gate/up and lm_head: thousands
 // of 16-row tiles): Y[b] = W[N,K] . x[b] on the matrix cores with the weights streamed by LDS-DMA into wave-private
 // rings.  Row N4 of the scope table (mod.rs:137-238: the reference runs every stream as its own loop and pays for the
 // whole weight read per stream; here one read serves the batch).
@@ -39,7 +39,7 @@ typedef __bf16 bf16x8d __attribute__((ext_vector_type(8)));
 
 constexpr int D_WAVES = 8, D_THREADS = D_WAVES * 64, D_STAGES = 8, D_STAGE_BYTES = 2048;
 constexpr int D_RING_BYTES = D_WAVES * D_STAGES * D_STAGE_BYTES;      // 128 KB
-constexpr int D_RED_FLOATS = 2 * D_WAVES * 32 * 4;                    // two buffers of 8 partial half-tiles
+constexpr int D_RED_FLOATS = 2 * D_WAVES * 64 * 4;                    // two buffers of 8 partial tiles (16 rows x 16 slots: round 5, was half a tile for <= 8 rows)
 
 __device__ inline void glds16d(const void *g, unsigned char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(D_THREADS) void gemv_dma_kernel(const GemvBatchArgs
     constexpr int RPI = 16 / DPS, LPR = 64 / RPI;               // rows per instruction, lanes (16-byte chunks) per row
     constexpr int SUB = KT / 32;                                // MFMA k steps per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // [8 waves][8 stages][2 KB] | red | inv
-    float *red = reinterpret_cast<float *>(lds + D_RING_BYTES);              // [2][8 waves][32 lanes][4]
-    float *inv_lds = red + D_RED_FLOATS;                                      // [8]
+    float *red = reinterpret_cast<float *>(lds + D_RING_BYTES);              // [2][8 waves][64 lanes][4]
+    float *inv_lds = red + D_RED_FLOATS;                                      // [16]
     const bf16_t *__restrict__ W = reinterpret_cast<const bf16_t *>(a.W);
     const int N = a.N, K = a.K, B = a.B;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -132,17 +132,17 @@ __global__ __launch_bounds__(D_THREADS) void gemv_dma_kernel(const GemvBatchArgs
                 xf[t][s2] = *reinterpret_cast<const uint4v *>(x + (size_t)m16 * K + (size_t)(t0s + t * D_WAVES + wave) * KT + s2 * 32 + kg * 8);
         }
     }
-    if (tid < 8) inv_lds[tid] = (a.x_scale && tid < B) ? a.x_scale[tid] : 1.0f;
+    if (tid < 16) inv_lds[tid] = (a.x_scale && tid < B) ? a.x_scale[tid] : 1.0f;
     __syncthreads();
 
-    // ---- epilogue of one unit: the summed tile lives in lanes 0..31 (tokens 4 * kg + reg, slot m16) ----
+    // ---- epilogue of one unit: the summed tile (tokens 4 * kg + reg, slot m16); lanes whose four tokens are all past B have nothing to do ----
     auto epilogue = [&](int u, float4v sum) {
-        if (kg >= 2) return;
+        if (kg * 4 >= B) return;
         const int i = m16;
         float other[4];
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
-            sum[rg] *= inv_lds[(kg * 4 + rg) & 7];
+            sum[rg] *= inv_lds[kg * 4 + rg];
             other[rg] = __shfl_xor(sum[rg], 8, 64);                   // the partner slot's value (gate <-> up)
         }
         if constexpr (EPI == EPI_F32) {
@@ -193,15 +193,16 @@ __global__ __launch_bounds__(D_THREADS) void gemv_dma_kernel(const GemvBatchArgs
             f++;
         }
         // the 8 partial tiles meet in LDS; wave (ui % 8) sums them in wave order and runs the epilogue
-        float *buf = red + (ui & 1) * (D_WAVES * 32 * 4);
-        if (kg < 2) *reinterpret_cast<float4v *>(buf + (wave * 32 + lane) * 4) = acc;
+        float *buf = red + (ui & 1) * (D_WAVES * 64 * 4);
+        const bool rows_live = kg * 4 < B;                              // (wave-uniform per 16 lanes: B <= 8 leaves half the tile out, as before)
+        if (rows_live) *reinterpret_cast<float4v *>(buf + (wave * 64 + lane) * 4) = acc;
         __syncthreads();
         if (wave == (ui & 7)) {
             float4v sum = {0.f, 0.f, 0.f, 0.f};
-            if (kg < 2) {
+            if (rows_live) {
 #pragma unroll
                 for (int w = 0; w < D_WAVES; w++) {
-                    const float4v p = *reinterpret_cast<const float4v *>(buf + (w * 32 + lane) * 4);
+                    const float4v p = *reinterpret_cast<const float4v *>(buf + (w * 64 + lane) * 4);
                     sum[0] += p[0]; sum[1] += p[1]; sum[2] += p[2]; sum[3] += p[3];
                 }
             }
@@ -234,7 +235,7 @@ static int dma_tiles_per_wave(int64_t K, int nks) {
 
 bool gemv_dma_supported(int B, int64_t N, int64_t K, int epi, int d) {
     (void)d;
-    if (B < 1 || B > 8 || K % 64 || N < 1) return false;
+    if (B < 1 || B > 16 || K % 64 || N < 1) return false;
     if (epi == EPI_GATEUP) return N % 32 == 0;
     return epi == EPI_F32;                                            // (its epilogue clamps a ragged last unit)
 }
@@ -254,7 +255,7 @@ int gemv_dma_ksplit(int64_t K, int64_t N, int epi) {
 template <int NKT, int EPI, int KT>
 static int launch_dma_e(Launcher &L, const GemvBatchArgs &a) {
     auto kern = gemv_dma_kernel<NKT, EPI, KT>;
-    const size_t lds = (size_t)D_RING_BYTES + (size_t)(D_RED_FLOATS + 8) * 4;
+    const size_t lds = (size_t)D_RING_BYTES + (size_t)(D_RED_FLOATS + 16) * 4;
     FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
     const int64_t nunits = EPI == EPI_F32 ? (a.N + 15) / 16 : a.N / 16;
     const int cus = cu_count_d();

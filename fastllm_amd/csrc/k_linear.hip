@@ -123,6 +123,24 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
             // 224-column tiles where they fill the chip and 256-column ones do not (k_gemm_w14.hip)
             if (gemm_w14_plan(T, N, K, epi)) return launch_gemm_w14(L, W, x, bias, y, T, N, K, epi, row_scale);
         }
+        // short prompts / decode batches on the kernel whose K slices meet inside the launch (k_gemm_skf.hip): a tensor-parallel rank's
+        // complete outputs (no slabs for its all-reduce) up to 64 rows -- tp = 4, 32 rows: down_proj 22.6 -> 11.6 us, 128 rows: o_proj
+        // 11.1 -> 18.1 (the last arriver's tail grows with the tile) --; gate/up of the opt-in five-launch layer; every shape when forced
+        if (!force_generic && T > 1 && T <= 128) {
+            const int skf = tune(TK_GEMM_SKF);
+            const bool whole = epi == EPI_F32 && ((skf >= 1 && L.tp > 1 && max_split <= 1 && T <= 64) || skf >= 3);
+            if ((epi == EPI_GATEUP && skf >= 2) || whole) {
+                const int ks = gemm_skf_plan(T, N, K, epi);
+                if (ks > 0 && (ks > 1 || epi == EPI_GATEUP || skf >= 3)) return launch_gemm_skf(L, W, x, bias, y, T, N, K, epi, row_scale, ks);
+            }
+        }
+        // prompts of 2-16 tokens: the wide gate/up stream on the LDS-DMA ring kernel of the decode batches (5.8 TB/s against 4.9)
+        if (!force_generic && T > 1 && T <= 16 && epi == EPI_GATEUP && N >= 8192 && !L.rsp.part && tune(TK_PREFILL_DMA) &&
+            gemv_dma_supported((int)T, N, K, epi, 0) && gemv_dma_ksplit(K, 0, epi) == 1) {
+            GemvBatchArgs ga;
+            ga.W = W; ga.x = x; ga.x_scale = row_scale; ga.out = y; ga.N = (int)N; ga.K = (int)K; ga.epi = epi; ga.pro = PRO_X; ga.B = (int)T; ga.nks = 1;
+            return launch_gemv_dma(L, ga);
+        }
         const int use_skinny = tune(TK_GEMM_SKINNY);
         if (!force_generic && use_skinny && gemm_skinny_supported(T, N, K)) {     // short prompts: a weight stream
             FL_TRY(no_parts());

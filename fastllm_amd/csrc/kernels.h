@@ -231,6 +231,10 @@ struct RopeEpi {
     void *q_out = nullptr, *k_cache = nullptr, *v_cache = nullptr;     // bf16: q [T][H*d]; K [Hkv][max_seq][d]; V [Hkv][d][max_seq] (transposed) or as K
     int H = 0, Hkv = 0, d = 0, max_seq = 0, v_transposed = 0;
     int col_base = 0;                  // first column of this launch in the whole QKV matrix (a column-peeled projection's tail launch)
+    // decode batch (k_gemm_skf.hip only): row t is sequence t's single new token -- its RoPE position, KV slot and caches come from
+    // seqs[t] (st->pos, st->len, k / v + kv_layer_off * seq_alloc; V transposed), not from st / k_cache / v_cache
+    const struct SeqRef *seqs = nullptr;
+    size_t kv_layer_off = 0;
 };
 // 128 x 256 tile, K slices summed inside the launch (k_gemm_h4.hip): mid-size prompts
 constexpr int H4_MAXS = 4;             // K slices at most
@@ -263,6 +267,12 @@ int gemm_h4_tail_slices(int64_t T, int64_t N, int64_t K);     // a peeled GEMM's
 int launch_gemm_h4(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
                    int epi, const float *row_scale, int ksplit, int64_t ldc = 0, const ResidEpi *resid = nullptr, const RopeEpi *rope = nullptr);
 int64_t gemm_h4_workspace_bytes(hipStream_t stream);
+// short prompts and decode batches (2-128 rows, k_gemm_skf.hip): the weight-streaming GEMM with its K slices met inside the launch and the
+// fp32 / gate-up / residual + norm / RoPE + KV-append epilogues; d: head_dim of the RoPE epilogue (0 otherwise)
+int gemm_skf_plan(int64_t T, int64_t N, int64_t K, int epi, int d = 0);
+int launch_gemm_skf(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K, int epi,
+                    const float *row_scale, int ksplit, const ResidEpi *resid = nullptr, const RopeEpi *rope = nullptr);
+void gemm_skf_release_stream(hipStream_t stream);
 void gemm_h4_release_stream(hipStream_t stream);   // before the owner destroys the stream
 bool gemm_skinny_supported(int64_t T, int64_t N, int64_t K);
 int gemm_skinny_ksplit(int64_t T, int64_t N, int64_t K, int epi, int max_split);

@@ -130,6 +130,9 @@ static const TuneEntry g_tune_table[TK_COUNT] = {
     {"debug_rs_parts", 0},
     {"debug_tp_loopback", 0},
     {"debug_poison", 0},
+    {"gemm_skf", 1},
+    {"skf_split", 0},
+    {"prefill_dma", 1},
 };
 static_assert(sizeof(g_tune_table) / sizeof(g_tune_table[0]) == TK_COUNT, "one row per TuneKey, in the enum's order");
 static std::atomic<int> g_tune[TK_COUNT];
@@ -301,6 +304,7 @@ Model::~Model() {
             closed.push_back(s.stream);
             gemm_8p_release_stream(s.stream);
             gemm_h4_release_stream(s.stream);
+            gemm_skf_release_stream(s.stream);
             (void)hipStreamDestroy(s.stream);
         }
     }
@@ -541,7 +545,7 @@ static int alloc_scratch(Model *m, Shard &sh, Scratch &sc, int64_t T, std::vecto
     FL_TRY(dev_alloc(own, (void **)&sc.delta, (size_t)std::max<int64_t>(slab_rows(T, ksplit_cap_max), T == 1 ? sh.Hkvs : 0) * D.h * 4, acct));
     FL_TRY(dev_alloc(own, &sc.xn, (size_t)T * D.h * es, acct));
     FL_TRY(dev_alloc(own, (void **)&sc.inv_rms, (size_t)T * 4, acct));
-    if (T > 128) FL_TRY(dev_alloc(own, (void **)&sc.rs_part, (size_t)T * gemm_resid_partials(D.h) * 4, acct));
+    if (T > 1) FL_TRY(dev_alloc(own, (void **)&sc.rs_part, (size_t)T * gemm_resid_partials(D.h) * 4, acct));
     FL_TRY(dev_alloc(own, (void **)&sc.qkv, (size_t)slab_rows(T, qkv_split_cap_max) * nq * 4, acct));    // split-K slabs of any prompt <= T
     FL_TRY(dev_alloc(own, &sc.q, (size_t)T * sh.Hs * D.d * es, acct));
     FL_TRY(dev_alloc(own, &sc.ao, (size_t)T * sh.Hs * D.d * es, acct));
@@ -1226,7 +1230,7 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
     int nslab = 1;                        // slabs the current delta consists of (same on every shard)
     // Long prompts on one GPU: where the 256x256 kernel takes o_proj / down_proj in one piece, its epilogue adds the residual,
     // writes the next norm's x * w and leaves partial sums of squares (EPI_RESID) -- no delta round trip, no rmsnorm_add launch.
-    const bool resid_ok = ns == 1 && m->tp == 1 && !m->shards[0].comm && dt == FL_DTYPE_BF16 && T > 128 && SC(m->shards[0]).rs_part != nullptr;
+    const bool resid_ok = ns == 1 && m->tp == 1 && !m->shards[0].comm && dt == FL_DTYPE_BF16 && T > 1 && SC(m->shards[0]).rs_part != nullptr;
     bool norm_done = false;               // xn / inv_rms for the upcoming norm were produced by the previous projection
     // consumer_takes_parts: the projection that follows takes its row scales (1/rms) straight from the partial sums (Launcher::rsp,
     // kernels.h) -- then there is no rms_finalize launch either; rs_lazy says so until that projection is launched
@@ -1263,7 +1267,14 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             int h4_qkv = dt == FL_DTYPE_BF16 ? gemm_h4_plan(T, nq, D.h, EPI_QKV_ROPE) : 0;
             if (!h4_qkv && dt == FL_DTYPE_BF16 && m->tp > 1 && D.d * sh.Hkvs % 128 == 0 && nq % 128 == 0) h4_qkv = gemm_h4_plan_whole(T, nq, D.h, EPI_QKV_ROPE);   // (a rank's narrower q | k | v)
             with_parts(L, sc);                                       // (the previous layer's down_proj may have left 1/rms as partial sums)
-            if (h4_qkv) {
+            const int skf_qkv = dt == FL_DTYPE_BF16 && !h4_qkv && m->tp == 1 && tune(TK_GEMM_SKF) >= 2 ? gemm_skf_plan(T, nq, D.h, EPI_QKV_ROPE, (int)D.d) : 0;
+            if (skf_qkv) {
+                // short prompts: the same epilogue on the weight-streaming kernel (k_gemm_skf.hip), its K slices met inside the launch
+                RopeEpi ro;
+                ro.st = cs.st; ro.cos_tab = sh.cos_tab; ro.sin_tab = sh.sin_tab; ro.max_pos = (int)D.max_pos; ro.q_out = sc.q; ro.k_cache = kc; ro.v_cache = vc;
+                ro.H = (int)sh.Hs; ro.Hkv = (int)sh.Hkvs; ro.d = (int)D.d; ro.max_seq = (int)sa; ro.v_transposed = c->v_transposed ? 1 : 0;
+                FL_TRY(launch_gemm_skf(L, ly.wqkv, sc.xn, ly.bqkv, nullptr, T, nq, D.h, EPI_QKV_ROPE, sc.inv_rms, skf_qkv, nullptr, &ro));
+            } else if (h4_qkv) {
                 // mid-size prompts: RoPE, bias and the KV append ride in the projection's epilogue (k_gemm_h4.hip): no fp32 QKV matrix
                 RopeEpi ro;
                 ro.st = cs.st; ro.cos_tab = sh.cos_tab; ro.sin_tab = sh.sin_tab; ro.max_pos = (int)D.max_pos; ro.q_out = sc.q; ro.k_cache = kc; ro.v_cache = vc;
@@ -1310,7 +1321,7 @@ static int enqueue_forward(Model *m, Cache *c, bool pre, int64_t T, bool ids_in_
             if (resid_ok && gemm_resid_supported(dt, T, D.h, sh.Ip, max_split)) {
                 // (the next layer's QKV projection takes the partial sums if its kernel can; the last layer's final norm wants the vector)
                 const int64_t nq = (sh.Hs + 2 * sh.Hkvs) * D.d;
-                const bool next_takes = l + 1 < D.L && (gemm_h4_plan(T, nq, D.h, EPI_QKV_ROPE) > 0 ||
+                const bool next_takes = l + 1 < D.L && (gemm_h4_plan(T, nq, D.h, EPI_QKV_ROPE) > 0 || (tune(TK_GEMM_SKF) >= 2 && gemm_skf_plan(T, nq, D.h, EPI_QKV_ROPE, (int)D.d) > 0) ||
                                                         gemm_takes_rs_parts(dt, T, nq, D.h, EPI_F32, std::min(tune(TK_QKV_SPLIT), qkv_split_cap(T))));
                 FL_TRY(linear_resid(L, sh, sc, ly.wd, sc.act, sh.Ip, l + 1 < D.L ? sh.layers[l + 1].ln1 : sh.norm, next_takes));
                 norm_done = true;
@@ -1669,9 +1680,49 @@ static int enqueue_batch_step_unfused(Batch *b) {
         return launch_gemv_dma(L, ga);
     };
     FL_TRY(launch_embed_batch(L, sh.embed, b->seqs_dev, sc.x_res, B, D.h));
+    const int64_t nq = (sh.Hs + 2 * sh.Hkvs) * D.d;
+    // Round 5, FL_GEMM_SKF=2 (off by default: it measured 8-13 % SLOWER, profiles/r05/README.md): the layer as FIVE launches (k_gemm_skf.hip) -- QKV with each row's RoPE / KV append in its epilogue, attention, o_proj and
+    // down_proj with the residual + next norm in theirs (K slices met inside the launch: no slabs, no rmsnorm_add), gate/up with its
+    // row scales from the partial sums -- where every projection of the model has a plan there; otherwise the eight-launch layer below
+    const int ks_q = dt == FL_DTYPE_BF16 && sc.rs_part && tune(TK_GEMM_SKF) >= 2 ? gemm_skf_plan(T, nq, D.h, EPI_QKV_ROPE, (int)D.d) : 0;
+    const int ks_o = ks_q ? gemm_skf_plan(T, D.h, sh.Hs * D.d, EPI_RESID) : 0, ks_d = ks_o ? gemm_skf_plan(T, D.h, sh.Ip, EPI_RESID) : 0;
+    if (ks_q && ks_o && ks_d && gemm_skf_plan(T, 2 * sh.Ip, D.h, EPI_GATEUP) > 0 && tune(TK_GEMM_RESID)) {
+        const int np = gemm_resid_partials(D.h);
+        auto resid = [&](const void *W, const void *x, int64_t K, const float *next_w, int ks) -> int {
+            ResidEpi re;
+            re.h = sc.x_res; re.w = next_w; re.xn = sc.xn; re.part = sc.rs_part; re.np = np;
+            return launch_gemm_skf(L, W, x, nullptr, nullptr, T, D.h, K, EPI_RESID, nullptr, ks, &re);
+        };
+        const RsParts parts{sc.rs_part, np, D.eps, 1.0f / (float)D.h};
+        FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, nullptr, sh.layers[0].ln1, D.eps, sc.xn, sc.inv_rms, T, D.h, 1, slab));
+        for (int64_t l = 0; l < D.L; l++) {
+            LayerW &ly = sh.layers[l];
+            RopeEpi ro;
+            ro.cos_tab = sh.cos_tab; ro.sin_tab = sh.sin_tab; ro.max_pos = (int)D.max_pos; ro.q_out = sc.q;
+            ro.H = (int)sh.Hs; ro.Hkv = (int)sh.Hkvs; ro.d = (int)D.d; ro.v_transposed = 1;
+            ro.seqs = b->seqs_dev; ro.kv_layer_off = (size_t)l * sh.Hkvs * D.d;
+            if (l > 0) L.rsp = parts;                                    // (the previous layer's down_proj left 1/rms as partial sums)
+            FL_TRY(launch_gemm_skf(L, ly.wqkv, sc.xn, ly.bqkv, nullptr, T, nq, D.h, EPI_QKV_ROPE, sc.inv_rms, ks_q, nullptr, &ro));
+            L.rsp = RsParts{};
+            FL_TRY(launch_attn_decode_mfma_batch(L, sc.q, b->seqs_dev, B, b->max_nsplit, (size_t)l * sh.Hkvs * D.d, sc.ao, sh.Hs, sh.Hkvs,
+                                                 D.d, D.scale, 0.0));
+            FL_TRY(resid(ly.wo, sc.ao, sh.Hs * D.d, ly.ln2, ks_o));
+            if (b->dma) {                                                // (eight rows at most: the LDS-DMA ring kernel streams gate/up fastest, and takes a vector)
+                FL_TRY(launch_rms_finalize(L, sc.rs_part, np, D.eps, sc.inv_rms, T, D.h));
+                FL_TRY(wide(ly.wgu, sc.act, 2 * sh.Ip, EPI_GATEUP));
+            } else {
+                L.rsp = parts;
+                FL_TRY(launch_linear(L, dt, ly.wgu, sc.xn, nullptr, sc.act, T, 2 * sh.Ip, D.h, EPI_GATEUP, sc.inv_rms));
+                L.rsp = RsParts{};
+            }
+            FL_TRY(resid(ly.wd, sc.act, sh.Ip, l + 1 < D.L ? sh.layers[l + 1].ln1 : sh.norm, ks_d));
+        }
+        FL_TRY(launch_rms_finalize(L, sc.rs_part, np, D.eps, sc.inv_rms, T, D.h));
+        FL_TRY(wide(sh.lm_head, b->logits, D.V, EPI_F32));
+        return launch_select_advance_batch(L, b->logits, D.V, b->seqs_dev, B, 1);
+    }
     for (int64_t l = 0; l < D.L; l++) {
         LayerW &ly = sh.layers[l];
-        const int64_t nq = (sh.Hs + 2 * sh.Hkvs) * D.d;
         FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, l == 0 ? nullptr : sc.delta, ly.ln1, D.eps, sc.xn, sc.inv_rms, T, D.h, nslab, slab));
         // K slices for the QKV stream too (96 strips of 64 rows otherwise: a third of the chip); the bias, if any, moves
         // into the RoPE launch, which sums the slabs anyway

@@ -192,3 +192,31 @@ def test_batch_fullsize_tinyllama(fa):
     got = batch.decode([int(t) for t in am], [n + 1 for n in lens], 24)
     assert all(len(g) == 24 for g in got)
     batch.close()
+
+
+@pytest.mark.parametrize("B", [3, 8, 16, 40])
+def test_batch_five_launch_layer_matches_the_default_step(fa, B):
+    """FL_GEMM_SKF=2: the decode batch's layer as five launches (k_gemm_skf.hip: every row's RoPE / KV append in the QKV epilogue,
+    residual + norm in o_proj's and down_proj's, K slices met inside the launch) against the default eight-launch step on the same
+    caches' contents; and 9-16 rows on the LDS-DMA ring kernel (k_gemv_dma.hip took eight at most before round 5)."""
+    cfg = synth.CONFIGS["mistral_a"]
+    w = synth.synth_weights(cfg)
+    gm = fa.Model(cfg, w, dtype="bf16")
+    lens = [4 + (3 * i) % 29 for i in range(B)]
+    out = {}
+    try:
+        for mode in (2, 1):
+            fa.tune("gemm_skf", mode)
+            caches, firsts, _ = prefilled(gm, cfg, lens)
+            batch = fa.Batch(gm, caches)
+            lg, am = batch.forward(firsts, lens)
+            lg2, am2 = batch.forward([int(t) for t in am], [n + 1 for n in lens])
+            out[mode] = (lg, lg2, batch.decode([int(t) for t in am2], [n + 2 for n in lens], 12))     # (the graph-replayed loop)
+            batch.close()
+    finally:
+        fa.tune("reload_env", 0)
+    for i in range(B):
+        tight(out[2][0][i], out[1][0][i], "five-launch layer, seq %d" % i, B)
+        tight(out[2][1][i], out[1][1][i], "five-launch layer, second step, seq %d" % i, B)
+        assert len(out[2][2][i]) == 12
+    gm.close()

@@ -354,9 +354,9 @@ def test_mid_prompt_in_launch_slices_equal_the_slab_path(env, name, T):
     finally:
         fa.tune("reload_env", 0)
     nres = sum(v for n, v in out[1][2].items() if "h4," in n and "resid" in n)
-    for k in (0, 1):
-        np.testing.assert_array_equal(out[3][k], out[1][k])
-    assert out[3][2] == out[1][2], (out[3][2], out[1][2])
+    for k in (0, 1):        # (not the same bits: a kernel that CAN sum the partials but was not planned to now does; a stale vector would be O(1))
+        assert np.linalg.norm(out[3][k] - out[1][k]) <= 1e-2 * np.linalg.norm(out[1][k]), "wrong plan: rel L2 %.2e" % (
+            np.linalg.norm(out[3][k] - out[1][k]) / np.linalg.norm(out[1][k]))
     # 1/rms taken from the partial sums by the consuming projection (Launcher::rsp) against the rms_finalize launch: the same numbers
     # up to the order a row's partial sums are added in -- a kernel that ignored the request would read a stale vector
     # (what stays: the last layer's -- the final norm wants the vector -- and those in front of a projection whose kernel takes a
@@ -516,5 +516,48 @@ def test_mid_prompt_small_hidden_size_on_the_in_launch_kernel(env, T):
     for k in (0, 1):
         a, b = out[1][k], out[0][k]
         assert np.linalg.norm(a - b) <= 1e-2 * np.linalg.norm(b), "rel L2 %.2e" % (np.linalg.norm(a - b) / np.linalg.norm(b))
+        assert oracle.argmax(a) == oracle.argmax(b)
+    gm.close()
+
+
+@pytest.mark.parametrize("name,T", [("mistral-7b", 2), ("mistral-7b", 16), ("mistral-7b", 33), ("mistral-7b", 100), ("mistral-7b", 128),
+                                    ("qwen2-7b", 24), ("qwen2-7b", 128), ("tinyllama-1.1b", 7), ("tinyllama-1.1b", 128)])
+def test_short_prompt_fused_layer_equals_the_slab_path(env, name, T):
+    """2-128 tokens: QKV with RoPE / bias / KV append in its epilogue, o_proj and down_proj with the residual + norm epilogue, gate/up
+    with its row scales from the partial sums -- all on the weight-streaming kernel whose K slices meet inside the launch
+    (k_gemm_skf.hip, FL_GEMM_SKF=2): five launches per layer.  Against the default path (FL_GEMM_SKF=0 / 1: fp32 slabs summed by rope_kv / rmsnorm_add,
+    eight launches): full width, 3 layers, the prefill's logits and two decode steps on the cache the epilogue wrote.  Same math up to
+    the order of fp32 sums (1/rms) and of `acc * rs` against the slabs' sum."""
+    torch, fa, bench = env
+    from fastllm_amd.configs import MODEL_CONFIGS
+    cfg = dict(MODEL_CONFIGS[name], num_hidden_layers=3)
+    wts = bench.synth_device_weights(torch, cfg, torch.device("cuda", 0), seed=17)
+    gm = fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16")
+    del wts
+    torch.cuda.empty_cache()
+    ids = synth.prompt_ids(cfg, T + 2, seed=23)
+    out = {}
+    try:
+        for mode in (1, 0):
+            fa.tune("gemm_skf", 2 if mode else 0)            # (2: the opt-in five-launch layer; it measured slower than the slab path, profiles/r05)
+            c = gm.new_cache(T + 8)
+            gm.profile_begin()
+            lg = gm.forward(c, ids[:T], 0)
+            names = {s["name"]: s["launches"] for s in gm.profile_end()}
+            out[mode] = (lg, gm.forward(c, ids[T:T + 1], T), gm.forward(c, ids[T + 1:T + 2], T + 1), names)
+            c.close()
+    finally:
+        fa.tune("reload_env", 0)
+    n1, n0 = out[1][3], out[0][3]
+    assert sum(v for n, v in n1.items() if "skf," in n and "rope" in n) == 3, n1
+    assert sum(v for n, v in n1.items() if "skf," in n and "resid" in n) == 6, n1
+    assert sum(v for n, v in n1.items() if "skf," in n and "glu" in n) == 3, n1
+    import json
+    assert not any("rope_kv" in n for n in n1) and n1.get("rmsnorm_add", 0) == 1, json.dumps(n1)     # (the first layer's)
+    assert sum(n1.values()) <= 5 * 3 + 6, json.dumps(n1)     # five launches per layer + embed, first norm, final 1/rms, lm_head, token selection
+    assert not any("skf," in n for n in n0), n0
+    for k in (0, 1, 2):
+        a, b = out[1][k], out[0][k]
+        assert np.linalg.norm(a - b) <= 1e-2 * np.linalg.norm(b), "call %d: rel L2 %.2e" % (k, np.linalg.norm(a - b) / np.linalg.norm(b))
         assert oracle.argmax(a) == oracle.argmax(b)
     gm.close()

@@ -364,3 +364,42 @@ def test_linear_h4_epilogues(fa, T, N, K, epi, bias, slices):
         np.testing.assert_allclose(y, ref, atol=2e-3, rtol=2 ** -7)
     else:
         np.testing.assert_allclose(y, ref, atol=2e-5 * np.sqrt(K) + 1e-5, rtol=1e-5)
+
+
+# Short-prompt GEMM whose K slices meet inside the launch (k_gemm_skf.hip; forced for every plain shape with gemm_skf = 3): integer
+# operands, so the sum of the slices is exact in any order -- a missed slice, a stale partial tile or a ticket word that was not reset
+# shows as a wrong integer.  All three token tiles (32 / 64 / 128 rows), ragged T and N, a bias, repeated launches on one workspace.
+@pytest.mark.parametrize("T,N,K", [(2, 64, 256), (16, 4096, 4096), (33, 1000, 1024), (64, 6144, 4096), (100, 520, 6400), (128, 4096, 14336), (17, 384, 512)])
+@pytest.mark.parametrize("slices", [1, 2, 3, 4])
+def test_linear_skf_slices_meet_in_the_launch(fa, T, N, K, slices):
+    if K // 64 < slices:
+        pytest.skip("no such case")
+    rs = np.random.RandomState(T + N + K)
+    x = rs.randint(-3, 4, size=(T, K)).astype(np.float32)
+    w = rs.randint(-3, 4, size=(N, K)).astype(np.float32)
+    b = rs.randint(-8, 9, size=(N,)).astype(np.float32) if N % 3 == 0 else None
+    ref = (x.astype(np.float64) @ w.astype(np.float64).T + (b if b is not None else 0.0)).astype(np.float32)
+    xb, wb = synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w)
+    try:
+        fa.tune("gemm_skf", 3); fa.tune("skf_split", slices)
+        for _ in range(5):
+            np.testing.assert_array_equal(fa.op_linear(xb, wb, b), ref)
+    finally:
+        fa.tune("reload_env", 0)
+
+
+@pytest.mark.parametrize("T,I,K", [(5, 352, 256), (32, 14336, 4096), (96, 1024, 2048), (128, 5632, 2048)])
+def test_linear_skf_gate_up(fa, T, I, K):
+    """its silu(gate) * up epilogue against fp64 (gate rows [0, I), up rows [I, 2 I) in HF order: the library interleaves them)"""
+    x, w = _rand((T, K), 7), _rand((2 * I, K), 8, 0.05)
+    xb, wb = synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w)
+    ref = _ref(synth.bf16_bits_to_f32(xb), synth.bf16_bits_to_f32(wb), None, 1)
+    try:
+        fa.tune("gemm_skf", 3); fa.tune("prefill_dma", 0)
+        y = fa.op_linear(xb, wb, None, epilogue=1)
+        fa.tune("gemm_skf", 0)
+        y0 = fa.op_linear(xb, wb, None, epilogue=1)
+    finally:
+        fa.tune("reload_env", 0)
+    np.testing.assert_allclose(y, ref, atol=2e-3, rtol=2 ** -7)
+    np.testing.assert_array_equal(y, y0)                 # the same K order and epilogue arithmetic as the kernel it stands in for
