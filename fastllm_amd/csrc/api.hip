@@ -400,7 +400,7 @@ int fl_op_linear(const void *x, const void *w, const float *bias, int64_t T, int
         // FL_OP_LINEAR_DMA=1: T <= 8 rows go through the batched-decode projection kernel (k_gemv_dma.hip) instead, so that
         // its weight-streaming rate can be measured (and its arithmetic tested) without a model around it
         const bool use_dma = tune(TK_OP_LINEAR_DMA) == 1;
-        const bool dma = use_dma && dtype == FL_DTYPE_BF16 && T <= 16 && !B.b && gemv_dma_supported((int)T, Nw, K, epilogue, 0) &&
+        const bool dma = use_dma && dtype == FL_DTYPE_BF16 && T <= 32 && !B.b && gemv_dma_supported((int)T, Nw, K, epilogue, 0) &&
                          gemv_dma_ksplit(K, Nw, epilogue) <= max_split;
         auto run = [&](const void *wp) -> int {
             if (!dma) return launch_linear(L, dtype, wp, B.x, B.b, B.y, T, Nw, K, epilogue, nullptr, max_split, &nsplit);

@@ -69,15 +69,16 @@ __device__ inline int unit_row(const GemvBatchArgs &a, int u, int i) {
 // NKT: K tiles per wave (compile-time: the activation fragments live in registers).
 // KT: k per tile, 64 or 128 -- a stage is 16 rows x KT k (2 or 4 KB), so one 1-KB LDS-DMA instruction carries 8 rows x 128 B or
 // 4 rows x 256 B: the longer the contiguous run per row, the better the HBM serves it (round 3; FL_DMA_KT).
-template <int NKT, int EPI, int KT>
+// RB: blocks of 16 activation rows (1: up to 16 rows; 2: up to 32 -- two accumulator tiles per weight fragment, the partial tiles of a
+// unit then meet in a single LDS buffer behind one more barrier per unit: the ring keeps its 128 KB)
+template <int NKT, int EPI, int KT, int RB>
 __global__ __launch_bounds__(D_THREADS) void gemv_dma_kernel(const GemvBatchArgs a) {
     constexpr int STAGE_BYTES = 16 * KT * 2, STAGES = (D_STAGES * D_STAGE_BYTES) / STAGE_BYTES;   // 16 KB of ring per wave either way
     constexpr int DPS = STAGE_BYTES / 1024;                     // LDS-DMA instructions per stage
     constexpr int RPI = 16 / DPS, LPR = 64 / RPI;               // rows per instruction, lanes (16-byte chunks) per row
     constexpr int SUB = KT / 32;                                // MFMA k steps per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // [8 waves][8 stages][2 KB] | red | inv
-    float *red = reinterpret_cast<float *>(lds + D_RING_BYTES);              // [2][8 waves][64 lanes][4]
-    float *inv_lds = red + D_RED_FLOATS;                                      // [16]
+    float *red = reinterpret_cast<float *>(lds + D_RING_BYTES);              // [2 units in flight][RB][8 waves][64 lanes][4]: 16 KB per row block -- with two, the CU's 160 KB to the byte
     const bf16_t *__restrict__ W = reinterpret_cast<const bf16_t *>(a.W);
     const int N = a.N, K = a.K, B = a.B;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -121,28 +122,37 @@ __global__ __launch_bounds__(D_THREADS) void gemv_dma_kernel(const GemvBatchArgs
     for (; issued < STAGES - 1 && issued < total; issued++) issue(issued);
 
     // ---- activation fragments of this wave's K tiles: lane (token m16, k group kg) ----
-    uint4v xf[NKT][SUB];
+    uint4v xf[RB][NKT][SUB];
     const bf16_t *__restrict__ x = reinterpret_cast<const bf16_t *>(a.x);
 #pragma unroll
-    for (int t = 0; t < NKT; t++) {
+    for (int rb = 0; rb < RB; rb++)
 #pragma unroll
-        for (int s2 = 0; s2 < SUB; s2++) {
-            xf[t][s2] = uint4v{0, 0, 0, 0};
-            if (tile_ok(t) && m16 < B)
-                xf[t][s2] = *reinterpret_cast<const uint4v *>(x + (size_t)m16 * K + (size_t)(t0s + t * D_WAVES + wave) * KT + s2 * 32 + kg * 8);
+        for (int t = 0; t < NKT; t++) {
+#pragma unroll
+            for (int s2 = 0; s2 < SUB; s2++) {
+                xf[rb][t][s2] = uint4v{0, 0, 0, 0};
+                if (tile_ok(t) && rb * 16 + m16 < B)
+                    xf[rb][t][s2] = *reinterpret_cast<const uint4v *>(x + (size_t)(rb * 16 + m16) * K + (size_t)(t0s + t * D_WAVES + wave) * KT + s2 * 32 + kg * 8);
+            }
         }
-    }
-    if (tid < 16) inv_lds[tid] = (a.x_scale && tid < B) ? a.x_scale[tid] : 1.0f;
-    __syncthreads();
+    // 1/rms of this lane's rows (tokens 16 rb + 4 kg + rg): registers, the LDS is all ring and partial tiles
+    float inv[RB][4];
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int b = rb * 16 + kg * 4 + rg;
+            inv[rb][rg] = (a.x_scale && b < B) ? a.x_scale[b] : 1.0f;
+        }
 
     // ---- epilogue of one unit: the summed tile (tokens 4 * kg + reg, slot m16); lanes whose four tokens are all past B have nothing to do ----
-    auto epilogue = [&](int u, float4v sum) {
-        if (kg * 4 >= B) return;
+    auto epilogue = [&](int u, float4v sum, int rb) {                 // rb: the row block (tokens 16 rb ..)
+        if (rb * 16 + kg * 4 >= B) return;
         const int i = m16;
         float other[4];
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
-            sum[rg] *= inv_lds[kg * 4 + rg];
+            sum[rg] *= inv[rb][rg];
             other[rg] = __shfl_xor(sum[rg], 8, 64);                   // the partner slot's value (gate <-> up)
         }
         if constexpr (EPI == EPI_F32) {
@@ -152,14 +162,14 @@ __global__ __launch_bounds__(D_THREADS) void gemv_dma_kernel(const GemvBatchArgs
             const float bv = (a.bias && ks_slice == 0) ? a.bias[row] : 0.f;
 #pragma unroll
             for (int rg = 0; rg < 4; rg++) {
-                const int b = kg * 4 + rg;
+                const int b = rb * 16 + kg * 4 + rg;
                 if (b < B) out[(size_t)b * N + row] = sum[rg] + bv;
             }
         } else {
             if (i >= 8) return;
 #pragma unroll
             for (int rg = 0; rg < 4; rg++) {
-                const int b = kg * 4 + rg;
+                const int b = rb * 16 + kg * 4 + rg;
                 if (b >= B) continue;
                 const float gt = sum[rg], up = other[rg];
                 const float act = gt / (1.0f + expf(-gt)) * up;        // candle silu(g) * u
@@ -171,7 +181,9 @@ __global__ __launch_bounds__(D_THREADS) void gemv_dma_kernel(const GemvBatchArgs
     // ---- main loop: units outer, this wave's K tiles inner (unrolled: xf[t] is a register name) ----
     int f = 0;                                                          // next task to consume
     for (int ui = 0; ui < my_units; ui++) {
-        float4v acc = {0.f, 0.f, 0.f, 0.f};
+        float4v acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++) acc[rb] = float4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < NKT; t++) {
             if (!tile_ok(t)) continue;
@@ -188,26 +200,31 @@ __global__ __launch_bounds__(D_THREADS) void gemv_dma_kernel(const GemvBatchArgs
             __builtin_amdgcn_sched_barrier(0);
             if (issued < total) { issue(issued); issued++; }           // into the stage task f - 1 used: its reads are done
 #pragma unroll
-            for (int s2 = 0; s2 < SUB; s2++)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8d, xf[t][s2]), wf[s2], acc, 0, 0, 0);
+            for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+                for (int s2 = 0; s2 < SUB; s2++)
+                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8d, xf[rb][t][s2]), wf[s2], acc[rb], 0, 0, 0);
             f++;
         }
         // the 8 partial tiles meet in LDS; wave (ui % 8) sums them in wave order and runs the epilogue
-        float *buf = red + (ui & 1) * (D_WAVES * 64 * 4);
-        const bool rows_live = kg * 4 < B;                              // (wave-uniform per 16 lanes: B <= 8 leaves half the tile out, as before)
-        if (rows_live) *reinterpret_cast<float4v *>(buf + (wave * 64 + lane) * 4) = acc;
-        __syncthreads();
-        if (wave == (ui & 7)) {
-            float4v sum = {0.f, 0.f, 0.f, 0.f};
-            if (rows_live) {
+        float *buf = red + (ui & 1) * (RB * D_WAVES * 64 * 4);          // (rewritten two units later: one barrier per unit orders it)
 #pragma unroll
-                for (int w = 0; w < D_WAVES; w++) {
-                    const float4v p = *reinterpret_cast<const float4v *>(buf + (w * 64 + lane) * 4);
-                    sum[0] += p[0]; sum[1] += p[1]; sum[2] += p[2]; sum[3] += p[3];
+        for (int rb = 0; rb < RB; rb++)
+            if (rb * 16 + kg * 4 < B) *reinterpret_cast<float4v *>(buf + ((rb * D_WAVES + wave) * 64 + lane) * 4) = acc[rb];
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++)
+            if (wave == ((RB * ui + rb) & 7)) {                         // (two row blocks: two waves, side by side)
+                float4v sum = {0.f, 0.f, 0.f, 0.f};
+                if (rb * 16 + kg * 4 < B) {
+#pragma unroll
+                    for (int w = 0; w < D_WAVES; w++) {
+                        const float4v p = *reinterpret_cast<const float4v *>(buf + ((rb * D_WAVES + w) * 64 + lane) * 4);
+                        sum[0] += p[0]; sum[1] += p[1]; sum[2] += p[2]; sum[3] += p[3];
+                    }
                 }
+                epilogue((int)blockIdx.x + ui * (int)gridDim.x, sum, rb);
             }
-            epilogue((int)blockIdx.x + ui * (int)gridDim.x, sum);
-        }
     }
 }
 
@@ -235,7 +252,9 @@ static int dma_tiles_per_wave(int64_t K, int nks) {
 
 bool gemv_dma_supported(int B, int64_t N, int64_t K, int epi, int d) {
     (void)d;
-    if (B < 1 || B > 16 || K % 64 || N < 1) return false;
+    if (B < 1 || B > 32 || K % 64 || N < 1) return false;
+    // 17-32 rows: two sets of activation fragments per wave -- half as many K tiles fit its registers (the whole K, unsliced)
+    if (B > 16 && (dma_tiles_per_wave(K, 1) == 0 || dma_tiles_per_wave(K, 1) * (dma_kt(K) / 64) > 8)) return false;
     if (epi == EPI_GATEUP) return N % 32 == 0;
     return epi == EPI_F32;                                            // (its epilogue clamps a ragged last unit)
 }
@@ -252,10 +271,10 @@ int gemv_dma_ksplit(int64_t K, int64_t N, int epi) {
     return nks;
 }
 
-template <int NKT, int EPI, int KT>
+template <int NKT, int EPI, int KT, int RB = 1>
 static int launch_dma_e(Launcher &L, const GemvBatchArgs &a) {
-    auto kern = gemv_dma_kernel<NKT, EPI, KT>;
-    const size_t lds = (size_t)D_RING_BYTES + (size_t)(D_RED_FLOATS + 16) * 4;
+    auto kern = gemv_dma_kernel<NKT, EPI, KT, RB>;
+    const size_t lds = (size_t)D_RING_BYTES + (size_t)D_RED_FLOATS * 4 * RB;
     FL_TRY(raise_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
     const int64_t nunits = EPI == EPI_F32 ? (a.N + 15) / 16 : a.N / 16;
     const int cus = cu_count_d();
@@ -271,6 +290,10 @@ template <int NKT, int KT>
 static int launch_dma_n(Launcher &L, const GemvBatchArgs &a) {
     return a.epi == EPI_GATEUP ? launch_dma_e<NKT, EPI_GATEUP, KT>(L, a) : launch_dma_e<NKT, EPI_F32, KT>(L, a);
 }
+template <int NKT, int KT>
+static int launch_dma_n2(Launcher &L, const GemvBatchArgs &a) {        // 17-32 rows
+    return a.epi == EPI_GATEUP ? launch_dma_e<NKT, EPI_GATEUP, KT, 2>(L, a) : launch_dma_e<NKT, EPI_F32, KT, 2>(L, a);
+}
 
 int launch_gemv_dma(Launcher &L, const GemvBatchArgs &a) {
     if (!gemv_dma_supported(a.B, a.N, a.K, a.epi, a.d)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "launch_gemv_dma: unsupported shape");
@@ -278,6 +301,11 @@ int launch_gemv_dma(Launcher &L, const GemvBatchArgs &a) {
     if (a.nks < 1 || (a.nks > 1 && a.epi != EPI_F32)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "launch_gemv_dma: K slices only for the plain fp32 projection");
     const int pw = dma_tiles_per_wave(a.K, a.nks);
     if (pw == 0) FL_FAIL(FL_ERR_BAD_ARGUMENT, "launch_gemv_dma: too few K slices (a wave holds at most 16 K tiles of activations)");
+    if (a.B > 16) {
+        if (a.nks != 1) FL_FAIL(FL_ERR_BAD_ARGUMENT, "launch_gemv_dma: 17-32 rows take the whole K");
+        if (dma_kt(a.K) == 128) return pw <= 2 ? launch_dma_n2<2, 128>(L, a) : launch_dma_n2<4, 128>(L, a);
+        return pw <= 4 ? launch_dma_n2<4, 64>(L, a) : launch_dma_n2<8, 64>(L, a);
+    }
     if (dma_kt(a.K) == 128) {
         if (pw <= 2) return launch_dma_n<2, 128>(L, a);
         if (pw <= 4) return launch_dma_n<4, 128>(L, a);

@@ -170,7 +170,11 @@ def test_linear_skinny_kernel(fa, monkeypatch, T, N, K, epi, bias, loaders):
 # a wave-private ring ordered only by counted waits: same bits on every launch
 @pytest.mark.parametrize("T,N,K,epi", [(8, 4096, 4096, 0), (3, 1000, 256, 0), (5, 2000, 1536, 0), (8, 512, 7168, 0),
                                        (1, 320, 512, 0), (8, 4096, 14336, 0), (7, 33, 64, 0),
-                                       (8, 14336, 4096, 1), (4, 352, 256, 1), (6, 5632, 2048, 1), (2, 16, 128, 1)])
+                                       (8, 14336, 4096, 1), (4, 352, 256, 1), (6, 5632, 2048, 1), (2, 16, 128, 1),
+                                       # round 5: 9-16 rows (the whole MFMA tile) and 17-32 (two row blocks per weight fragment)
+                                       (16, 4096, 4096, 0), (11, 1000, 1536, 0), (16, 14336, 4096, 1), (9, 352, 256, 1), (13, 512, 7168, 0),
+                                       (32, 4096, 4096, 0), (17, 1000, 1024, 0), (32, 14336, 4096, 1), (24, 5632, 2048, 1), (29, 9472, 3584, 1),
+                                       (32, 300, 512, 0)])
 def test_linear_dma_ring_kernel(fa, T, N, K, epi, monkeypatch):
     monkeypatch.setenv("FL_OP_LINEAR_DMA", "1")
     x, w = _rand((T, K), 41), _rand((N if not epi else 2 * N, K), 42, 0.05)
