@@ -30,6 +30,7 @@ for spec in "qwen2_4k qwen2-7b 4096" "mistral_t512 mistral-7b 512"; do
 done
 else
 cd $R
+if [ "$1" != "traffic" ]; then
 timeout -k 10 600 python3 bench.py > $O/bench_mistral7b_decode.json 2> $O/bench_mistral7b.err || exit 1
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 $R/bench.py --steps 64 --no-cpu-baseline --no-secondary --no-traffic > $O/prof_stats_bench.json 2> $O/prof_stats.err || exit 1
@@ -38,6 +39,11 @@ cp "$f" $O/rocprofv3_kernel_stats_mistral7b.csv
 python3 $R/tools/check_profile_kernels.py $O/rocprofv3_kernel_stats_mistral7b.csv $O/prof_stats_bench.json --stamp || exit 1
 python3 $R/tools/check_profile_kernels.py $O/rocprofv3_kernel_stats_mistral7b.csv $O/bench_mistral7b_decode.json || exit 1
 python3 $R/tools/rocprof_gemv.py "$f" $O/rocprof_gemv.json > /dev/null || exit 1
+fi
+cd /tmp
+# (counter passes without the batched-decode legs, as bench.py's own in-run passes: the 8- and 32-stream legs add ~40k dispatches and the
+# profiler's counter collection segfaulted behind them; the counters are read for gemv_kernel only)
+export FL_BENCH_BATCH=0
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 16 --no-cpu-baseline --no-secondary --no-traffic > /dev/null 2> $O/pmc_fetch.err || exit 1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 16 --no-cpu-baseline --no-secondary --no-traffic > /dev/null 2> $O/pmc_write.err || exit 1
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/traffic_gemv.json > /dev/null || exit 1
