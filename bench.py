@@ -576,6 +576,50 @@ def main():
         except Exception as e:                                               # the headline line must not depend on it
             log("batched decode leg failed:", repr(e))
 
+    # ---- the same 32 streams on the tensor-parallel group (round 5: fl_batch_* on the ranks of a multi-process group).  Every rank builds
+    #      the same batch; the headline's numbers are complete at this point and a failure here only drops this entry ----
+    if world > 1 and os.environ.get("FL_BENCH_BATCH", "1") == "1":
+        ok_b, bt, bc = 1, None, []
+        try:
+            nb2, kb = 32, min(K, 32)
+            rsb = np.random.RandomState(4321)
+            bfirst = []
+            for i in range(nb2):
+                pi = rsb.randint(0, cfg["vocab_size"], size=T).astype(np.uint32)
+                ci = model.new_cache(T + kb + 24)
+                bfirst.append(model.forward_argmax(ci, pi, 0))
+                bc.append(ci)
+            bt = fa.Batch(model, bc)
+            g = bt.decode(bfirst, [T] * nb2, 8)
+            barrier(); model.synchronize()
+            t0 = time.perf_counter()
+            g = bt.decode([int(x[-1]) for x in g], [T + 8] * nb2, kb)
+            model.synchronize(); barrier()
+            tb = time.perf_counter() - t0
+        except Exception as e:                                               # noqa: the headline line must not depend on it
+            ok_b = 0
+            log("rank %d: tensor-parallel batched decode leg failed: %r" % (rank, e))
+        okt = torch.tensor([ok_b], dtype=torch.int32)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt[0]) == 1:
+            tt = torch.tensor([tb], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tb = float(tt[0])
+            crcs = [None] * world
+            dist.all_gather_object(crcs, zlib.crc32(np.stack(g).astype(np.uint32).tobytes()))
+            batch32 = {"streams": nb2, "steps": kb, "ms_per_step": round(tb / kb * 1e3, 4), "aggregate_tokens_per_sec": round(nb2 * kb / tb, 1),
+                       "per_stream_tokens_per_sec": round(kb / tb, 1), "ranks_agree": all(c == crcs[0] for c in crcs),
+                       "note": "fl_batch_decode on the %d ranks of the group: 32 independent %d-token-prompt streams, one-shot all-reduces of [32, h] behind "
+                               "o_proj / down_proj, one gather of the ranks' logits blocks per step" % (world, T)}
+            log("batched decode x32 on the group: %.1f tokens/s aggregate" % batch32["aggregate_tokens_per_sec"])
+        try:
+            if bt is not None:
+                bt.close()
+            for ci in bc:
+                ci.close()
+        except Exception as e:                                               # noqa
+            log("rank %d: closing the batch: %r" % (rank, e))
+
     # ---- the other single-GPU BASELINE configs and the fp32 parity mode, each behind its own parity gate (N = 1, default model only):
     #      configs[1] TinyLlama-1.1B 128 / 128; configs[4]'s single-GPU half, Qwen2-7B 4096-token prefill + decode at S = 4097..;
     #      and the headline workload in fp32 mode, the mode that meets north_star's literal 1e-3 / bit-exact-ids bar.

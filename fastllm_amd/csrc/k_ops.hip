@@ -767,6 +767,20 @@ int launch_select_advance_batch(Launcher &L, const float *logits, int64_t V, con
                     seqs_dev, advance);
 }
 
+// a tensor-parallel batch's gathered logits [tp][B][Vs] (rank-major: what one all-gather of every rank's [B][Vs] block leaves) ->
+// [B][V] (V = tp * Vs), the layout token selection and fl_batch_forward's caller read
+__global__ __launch_bounds__(256) void unshard_logits_kernel(const float *__restrict__ in, float *__restrict__ out, int tp, int B, int Vs) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4, n = (long long)tp * B * Vs;
+    if (i >= n) return;
+    const int r = (int)(i / ((long long)B * Vs)), rem = (int)(i % ((long long)B * Vs)), b = rem / Vs, j = rem % Vs;     // (Vs % 4 == 0: a float4 stays in its row)
+    *reinterpret_cast<float4v *>(out + ((size_t)b * tp + r) * Vs + j) = *reinterpret_cast<const float4v *>(in + i);
+}
+int launch_unshard_logits(Launcher &L, const float *in, float *out, int tp, int B, int64_t Vs) {
+    if (Vs % 4) FL_FAIL(FL_ERR_UNSUPPORTED, "a tensor-parallel batch needs a vocabulary shard that is a multiple of 4");
+    const long long n = (long long)tp * B * Vs;
+    return L.launch(KC_ARGMAX, (double)n * 8, 0, unshard_logits_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, in, out, tp, B, (int)Vs);
+}
+
 // scratch: V floats (probabilities / cumulative weights of the sampling path)
 int launch_select_advance(Launcher &L, const float *logits, int64_t V, StepState *st, SampleState *ss, float *scratch,
                           uint32_t *out_tokens, int advance, const ArgmaxCand *cand, uint32_t *epoch_bump) {

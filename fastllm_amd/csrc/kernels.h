@@ -191,6 +191,7 @@ int launch_rope_kv_batch(Launcher &L, const float *qkv, const SeqRef *seqs_dev, 
                          int64_t max_pos, void *q_out, size_t kv_layer_off, int B, int64_t H, int64_t Hkv, int64_t d, int n_slab = 1,
                          const float *bias = nullptr);
 // logits fp32 [B][V] -> every sequence's token / step state
+int launch_unshard_logits(Launcher &L, const float *in, float *out, int tp, int B, int64_t Vs);   // [tp][B][Vs] -> [B][tp * Vs]
 int launch_select_advance_batch(Launcher &L, const float *logits, int64_t V, const SeqRef *seqs_dev, int B, int advance);
 
 // dst row of gate/up pair q in the 16-interleaved fused layout: 16 gate rows then 16 up rows

@@ -169,6 +169,7 @@ struct Batch {
     void *q = nullptr, *ao = nullptr;            // [B][H*d]
     void *act = nullptr;                         // [B][Ip]
     float *logits = nullptr;                     // [B][V]
+    float *logits_local = nullptr, *logits_ranks = nullptr;   // tensor-parallel rank: its [B][Vs] block, and the gathered [tp][B][Vs]
     uint32_t *host_tokens = nullptr;             // pinned [B][kBatchChunk]
     StepState *host_states = nullptr;            // pinned [B]
     hipGraphExec_t graph = nullptr;

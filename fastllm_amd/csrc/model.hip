@@ -1559,7 +1559,12 @@ Batch::~Batch() {
 int batch_create(Model *m, Cache *const *caches, size_t B, Batch **out) {
     if (!m || !caches || !out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
     if (B < 1 || B > (size_t)kMaxBatch) FL_FAIL(FL_ERR_BAD_ARGUMENT, "batch size %zu not in 1..%d", B, kMaxBatch);
-    if (m->tp != 1 || m->shards.size() != 1) FL_FAIL(FL_ERR_UNSUPPORTED, "batched decode is single-GPU (tp = 1)");
+    // one GPU, or -- round 5 -- one rank of a multi-process tensor-parallel group (every rank builds the same batch and calls the same
+    // entry points: the step's all-reduces and logits gather are collectives)
+    const bool tp_rank = m->tp > 1 && m->tp_mode == FL_TP_MULTI_PROCESS && m->shards.size() == 1;
+    if (m->shards.size() != 1 || (m->tp != 1 && !tp_rank)) FL_FAIL(FL_ERR_UNSUPPORTED, "batched decode runs on one GPU or on the ranks of an FL_TP_MULTI_PROCESS group");
+    if (tp_rank && (!m->shards[0].pc.connected || !m->vocab_parallel || m->shards[0].Vs % 4))
+        FL_FAIL(FL_ERR_UNSUPPORTED, "batched decode on a tensor-parallel group needs connected peer inboxes and a vocabulary shard that is a multiple of 4");
     if (m->dtype != FL_DTYPE_BF16) FL_FAIL(FL_ERR_UNSUPPORTED, "batched decode is bf16 only");
     const Dims &D = m->D;
     Shard &sh = m->shards[0];
@@ -1574,8 +1579,8 @@ int batch_create(Model *m, Cache *const *caches, size_t B, Batch **out) {
     b->caches.assign(caches, caches + B);
     // B >= 3: the prefill-shaped step (separate norm / RoPE launches) with the wide projections on the LDS-DMA ring kernel
     b->dma = B >= (size_t)tune(TK_BATCH_DMA_MIN) && gemv_dma_supported((int)B, 2 * sh.Ip, D.h, EPI_GATEUP, 0) &&
-             gemv_dma_supported((int)B, D.V, D.h, EPI_F32, 0) && gemv_dma_ksplit(D.h, 0, EPI_GATEUP) == 1;
-    const bool gemv_rows = B <= (size_t)kMaxBatchGemv;         // the streaming GEMV forms hold at most eight rows
+             gemv_dma_supported((int)B, sh.Vs, D.h, EPI_F32, 0) && gemv_dma_ksplit(D.h, 0, EPI_GATEUP) == 1;
+    const bool gemv_rows = B <= (size_t)kMaxBatchGemv && !tp_rank;   // the streaming GEMV forms hold at most eight rows (and know no all-reduce)
     if (gemv_rows) {
         b->nks_o = gemv_batch_ksplit((int)B, sh.Hs * D.d, D.h, EPI_F32);
         b->nks_down = gemv_batch_ksplit((int)B, sh.Ip, D.h, EPI_F32);
@@ -1599,12 +1604,16 @@ int batch_create(Model *m, Cache *const *caches, size_t B, Batch **out) {
     FL_TRY(dev_alloc(b->allocs, &b->ao, B * sh.Hs * D.d * es, nullptr));
     FL_TRY(dev_alloc(b->allocs, &b->act, B * sh.Ip * es, nullptr));
     FL_TRY(dev_alloc(b->allocs, (void **)&b->logits, B * D.V * 4, nullptr));
+    if (tp_rank) {
+        FL_TRY(dev_alloc(b->allocs, (void **)&b->logits_local, B * sh.Vs * 4, nullptr));
+        FL_TRY(dev_alloc(b->allocs, (void **)&b->logits_ranks, B * D.V * 4, nullptr));
+    }
     // B >= 7: every projection through the short-prompt GEMM with the norm and RoPE / KV append as their own small
     // launches, i.e. the prefill pipeline at T = B with per-sequence positions and caches.  Measured (Mistral-7B,
     // ms per step, unfused vs fused): B = 3 4.16 / 3.87, 4 4.21 / 3.99, 6 4.24 / 4.18, 8 4.26 / 4.38
     b->unfused = B >= (size_t)(tune(TK_BATCH_UNFUSED_MIN) >= 0 ? tune(TK_BATCH_UNFUSED_MIN) : (b->dma ? 3 : 7)) && gemm_skinny_supported((int64_t)B, D.h, D.h) &&
                  gemm_skinny_supported((int64_t)B, D.h, sh.Ip);
-    // more than eight streams: always the prefill-shaped step (launch_linear finds a kernel for every shape)
+    // more than eight streams, or a tensor-parallel rank: always the prefill-shaped step (launch_linear finds a kernel for every shape)
     if (!gemv_rows) b->unfused = true;
     if (b->unfused) {
         FL_TRY(alloc_scratch(m, sh, b->sc, (int64_t)B, &b->allocs));
@@ -1684,7 +1693,8 @@ static int enqueue_batch_step_unfused(Batch *b) {
     // Round 5, FL_GEMM_SKF=2 (off by default: it measured 8-13 % SLOWER, profiles/r05/README.md): the layer as FIVE launches (k_gemm_skf.hip) -- QKV with each row's RoPE / KV append in its epilogue, attention, o_proj and
     // down_proj with the residual + next norm in theirs (K slices met inside the launch: no slabs, no rmsnorm_add), gate/up with its
     // row scales from the partial sums -- where every projection of the model has a plan there; otherwise the eight-launch layer below
-    const int ks_q = dt == FL_DTYPE_BF16 && sc.rs_part && tune(TK_GEMM_SKF) >= 2 ? gemm_skf_plan(T, nq, D.h, EPI_QKV_ROPE, (int)D.d) : 0;
+    const bool tpr = m->tp > 1;                                        // a rank of a multi-process group: all-reduce behind o_proj / down_proj, gathered logits
+    const int ks_q = dt == FL_DTYPE_BF16 && sc.rs_part && !tpr && tune(TK_GEMM_SKF) >= 2 ? gemm_skf_plan(T, nq, D.h, EPI_QKV_ROPE, (int)D.d) : 0;
     const int ks_o = ks_q ? gemm_skf_plan(T, D.h, sh.Hs * D.d, EPI_RESID) : 0, ks_d = ks_o ? gemm_skf_plan(T, D.h, sh.Ip, EPI_RESID) : 0;
     if (ks_q && ks_o && ks_d && gemm_skf_plan(T, 2 * sh.Ip, D.h, EPI_GATEUP) > 0 && tune(TK_GEMM_RESID)) {
         const int np = gemm_resid_partials(D.h);
@@ -1732,13 +1742,23 @@ static int enqueue_batch_step_unfused(Batch *b) {
                                     sh.Hkvs, D.d, qkv_slabs, ly.bqkv));
         FL_TRY(launch_attn_decode_mfma_batch(L, sc.q, b->seqs_dev, B, b->max_nsplit, (size_t)l * sh.Hkvs * D.d, sc.ao, sh.Hs, sh.Hkvs,
                                              D.d, D.scale, 0.0));
-        FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, T, D.h, sh.Hs * D.d, EPI_F32, nullptr, kMaxKSplit, &nslab));
+        // (a rank's row-parallel outputs: complete, no slabs -- the all-reduce wants the sum; sums in rank order on every rank)
+        FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, T, D.h, sh.Hs * D.d, EPI_F32, nullptr, tpr ? 1 : kMaxKSplit, &nslab));
+        if (tpr) FL_TRY(oneshot(m, sh, false, sc.delta, sc.delta, T * D.h, 0));
         FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, sc.delta, ly.ln2, D.eps, sc.xn, sc.inv_rms, T, D.h, nslab, slab));
         FL_TRY(wide(ly.wgu, sc.act, 2 * sh.Ip, EPI_GATEUP));
-        FL_TRY(launch_linear(L, dt, ly.wd, sc.act, nullptr, sc.delta, T, D.h, sh.Ip, EPI_F32, nullptr, kMaxKSplit, &nslab));
+        FL_TRY(launch_linear(L, dt, ly.wd, sc.act, nullptr, sc.delta, T, D.h, sh.Ip, EPI_F32, nullptr, tpr ? 1 : kMaxKSplit, &nslab));
+        if (tpr) FL_TRY(oneshot(m, sh, false, sc.delta, sc.delta, T * D.h, 0));
     }
     FL_TRY(launch_rmsnorm_add(L, dt, sc.x_res, sc.delta, sh.norm, D.eps, sc.xn, sc.inv_rms, T, D.h, nslab, slab));
-    FL_TRY(wide(sh.lm_head, b->logits, D.V, EPI_F32));
+    if (tpr) {
+        // every rank's [B][V / tp] block of the logits, gathered in one collective (rank-major) and laid out [B][V] for token selection
+        FL_TRY(wide(sh.lm_head, b->logits_local, sh.Vs, EPI_F32));
+        FL_TRY(oneshot(m, sh, true, b->logits_local, b->logits_ranks, (int64_t)B * sh.Vs, (int64_t)B * sh.Vs));
+        FL_TRY(launch_unshard_logits(L, b->logits_ranks, b->logits, m->tp, B, sh.Vs));
+    } else {
+        FL_TRY(wide(sh.lm_head, b->logits, D.V, EPI_F32));
+    }
     return launch_select_advance_batch(L, b->logits, D.V, b->seqs_dev, B, 1);
 }
 
@@ -1805,6 +1825,7 @@ int batch_decode(Batch *b, const uint32_t *first, const size_t *pos, size_t n_st
             FL_HIP(hipMemcpyAsync(b->host_states + i, b->caches[i]->shards[0].st, sizeof(StepState), hipMemcpyDeviceToHost, sh.stream));
         }
         FL_HIP(hipStreamSynchronize(sh.stream));
+        FL_TRY(comm_check(m));                                    // (a tensor-parallel rank: a collective that gave up waiting for a peer)
         bool all_finished = true;
         for (int i = 0; i < B; i++) {
             if (b->host_states[i].error) FL_FAIL(FL_ERR_HIP, "device-side wait gave up (code 0x%x) in sequence %d", b->host_states[i].error, i);
@@ -1853,6 +1874,7 @@ int batch_forward(Batch *b, const uint32_t *tokens, const size_t *pos, float *lo
         FL_HIP(hipMemcpyAsync(b->host_states + i, b->caches[i]->shards[0].st, sizeof(StepState), hipMemcpyDeviceToHost, sh.stream));
     }
     FL_HIP(hipStreamSynchronize(sh.stream));
+    FL_TRY(comm_check(m));
     for (int i = 0; i < B; i++) {
         if (b->host_states[i].error) FL_FAIL(FL_ERR_HIP, "device-side wait gave up (code 0x%x) in sequence %d", b->host_states[i].error, i);
         b->caches[i]->len += 1;

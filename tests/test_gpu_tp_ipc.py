@@ -267,3 +267,36 @@ def test_multiprocess_mid_prompt_kernels_at_7b_width(tmp_path, tp):
     o1 = om.forward(oc, ids[T:T + 1], T)
     check_logits(res[0]["decode"][0], o1, dtype, "multi-process decode on the cache the prefill left vs oracle")
     gE.close()
+
+
+@pytest.mark.parametrize("name,tp,B", [("llama_tp4", 2, 3), ("llama_tp4", 4, 12), ("mistral_wide", 2, 32), ("llama_tp8", 8, 9)])
+def test_batched_decode_on_a_multiprocess_group(tmp_path, name, tp, B):
+    """Round 5: fl_batch_* on the ranks of an FL_TP_MULTI_PROCESS group -- the prefill-shaped step at T = B with a rank's shard shapes,
+    one-shot all-reduces behind o_proj / down_proj (complete outputs, sums in rank order) and ONE gather of every rank's [B][V / tp]
+    logits block.  Every rank holds the same bits; per sequence the logits are those of one GPU running the whole model in a batch
+    (bf16 bar: the row-parallel sums run in another order), and the greedy loops agree up to near-ties."""
+    import fastllm_amd as fa
+    cfg = synth.CONFIGS[name]
+    res = run_group(tmp_path, name, "bf16", tp, T=6, n_tf=1, n_greedy=2, env_extra={"TP_WORKER_BATCH": str(B), "FL_ATTN_REP": "0" if tp > 4 else "1"})
+    for r in range(1, tp):
+        for k in ("batch_logits", "batch_tokens"):
+            np.testing.assert_array_equal(res[r][k], res[0][k], err_msg="rank %d vs 0: %s" % (r, k))
+    w = synth.synth_weights(cfg)
+    g1 = fa.Model(cfg, w, dtype="bf16")
+    lens = [3 + (2 * i) % 11 for i in range(B)]
+    caches, firsts = [], []
+    for i, n in enumerate(lens):
+        ci = g1.new_cache(48)
+        firsts.append(g1.forward_argmax(ci, synth.prompt_ids(cfg, n, seed=70 + i), 0))
+        caches.append(ci)
+    feed = [int(t) for t in res[0]["batch_first"]]                   # (the group's own first tokens: a near-tie may have parted them)
+    bt = fa.Batch(g1, caches)
+    lg, am = bt.forward(feed, lens)
+    same_first = sum(int(a == b) for a, b in zip(firsts, feed))
+    assert same_first >= B - 1, (firsts, feed)
+    for i in range(B):
+        if firsts[i] == feed[i]:
+            check_logits(res[0]["batch_logits"][i], lg[i], "bf16", "sequence %d: group vs one GPU" % i)
+    assert res[0]["batch_tokens"].shape == (B, 11)
+    bt.close()
+    g1.close()

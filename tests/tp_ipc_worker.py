@@ -112,6 +112,22 @@ def run_rank(rank, world, name, dtype, outdir, T, n_tf, n_greedy):
         f2 = m.forward_sample(c2, ids[:T], 0, 0.9, seed=5)
         res["sampled"] = np.concatenate([[f2], m.decode_sample(c2, f2, T, n_sampled, 0.9, seed=5)]).astype(np.uint32)
         c2.close()
+    n_batch = int(os.environ.get("TP_WORKER_BATCH", "0"))
+    if n_batch:                                          # a batch of streams on the group: every rank builds the same batch
+        lens = [3 + (2 * i) % 11 for i in range(n_batch)]
+        caches, firsts = [], []
+        for i, n in enumerate(lens):
+            ci = m.new_cache(48)
+            firsts.append(m.forward_argmax(ci, synth.prompt_ids(cfg, n, seed=70 + i), 0))
+            caches.append(ci)
+        bt = fa.Batch(m, caches)
+        lg, am = bt.forward(firsts, lens)
+        res["batch_logits"], res["batch_first"] = lg, np.asarray(firsts, dtype=np.uint32)
+        toks = bt.decode([int(t) for t in am], [n + 1 for n in lens], 10)
+        res["batch_tokens"] = np.stack([np.concatenate([[am[i]], toks[i]]).astype(np.uint32) for i in range(n_batch)])
+        bt.close()
+        for ci in caches:
+            ci.close()
     np.savez(os.path.join(outdir, "out_%d.npz" % rank), **res)
     exchange(outdir, rank, world, b"done", "done")      # nobody unmaps an inbox a peer may still push to
     c.close()

@@ -1,4 +1,4 @@
-"""Short prompts and decode batches with / without the fused five-launch layer (FL_GEMM_SKF 1 / 0), one process, alternating, medians.
+"""Short prompts and decode batches with / without the opt-in five-launch layer (FL_GEMM_SKF 2 / 1), one process, alternating, medians.
 usage: short_ab.py model T[,T...] [batch sizes B,B]"""
 import os, sys, time
 import numpy as np
@@ -21,7 +21,7 @@ for T in Ts:
     res = {0: [], 1: []}
     for rep in range(7):
         for mode in (1, 0):
-            fa.tune("gemm_skf", mode)
+            fa.tune("gemm_skf", 2 if mode else 1)
             c.reset(); gm.forward_argmax(c, p, 0); c.reset()
             gm.synchronize(); t0 = time.perf_counter()
             for _ in range(3):
@@ -29,13 +29,13 @@ for T in Ts:
             gm.synchronize()
             res[mode].append((time.perf_counter() - t0) / 3)
     a, b = sorted(res[1])[3] * 1e3, sorted(res[0])[3] * 1e3
-    print("%s prefill T=%4d: fused %.3f ms   slab path %.3f ms   x%.3f" % (name, T, a, b, a / b), flush=True)
+    print("%s prefill T=%4d: five-launch layer %.3f ms   default %.3f ms   x%.3f" % (name, T, a, b, a / b), flush=True)
     c.close()
 for B in Bs:
     T, K = 512, 48
     out = {}
     for mode in (1, 0):
-        fa.tune("gemm_skf", mode)
+        fa.tune("gemm_skf", 2 if mode else 1)
         caches, firsts = [], []
         for i in range(B):
             ci = gm.new_cache(T + 2 * K + 80)
@@ -50,5 +50,5 @@ for B in Bs:
         bt.close()
         for ci in caches:
             ci.close()
-    print("%s batch B=%2d: fused %.3f ms/step (%.0f tok/s)   slab path %.3f ms/step (%.0f tok/s)   x%.3f" % (name, B, out[1], B / out[1] * 1e3, out[0], B / out[0] * 1e3, out[1] / out[0]), flush=True)
+    print("%s batch B=%2d: five-launch layer %.3f ms/step (%.0f tok/s)   default %.3f ms/step (%.0f tok/s)   x%.3f" % (name, B, out[1], B / out[1] * 1e3, out[0], B / out[0] * 1e3, out[1] / out[0]), flush=True)
 fa.tune("reload_env", 0)
