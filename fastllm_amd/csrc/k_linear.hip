@@ -134,8 +134,8 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
                 if (ks > 0 && (ks > 1 || epi == EPI_GATEUP || skf >= 3)) return launch_gemm_skf(L, W, x, bias, y, T, N, K, epi, row_scale, ks);
             }
         }
-        // prompts of 2-16 tokens: the wide gate/up stream on the LDS-DMA ring kernel of the decode batches (5.8 TB/s against 4.9)
-        if (!force_generic && T > 1 && T <= 16 && epi == EPI_GATEUP && N >= 8192 && !L.rsp.part && tune(TK_PREFILL_DMA) &&
+        // prompts of 2-32 tokens: the wide gate/up stream on the LDS-DMA ring kernel of the decode batches (5.8 / 5.3 TB/s at <= 16 / 32 rows against 4.9)
+        if (!force_generic && T > 1 && T <= 32 && epi == EPI_GATEUP && N >= 8192 && !L.rsp.part && tune(TK_PREFILL_DMA) &&
             gemv_dma_supported((int)T, N, K, epi, 0) && gemv_dma_ksplit(K, 0, epi) == 1) {
             GemvBatchArgs ga;
             ga.W = W; ga.x = x; ga.x_scale = row_scale; ga.out = y; ga.N = (int)N; ga.K = (int)K; ga.epi = epi; ga.pro = PRO_X; ga.B = (int)T; ga.nks = 1;
