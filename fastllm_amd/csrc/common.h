@@ -114,9 +114,9 @@ enum TuneKey {
     TK_RS_LAZY,   // 1/rms behind a residual epilogue: taken from the partial sums by the consuming projection (0: rms_finalize launch)
     TK_BATCH_UNFUSED_MIN,   // first batch size on the prefill-shaped step (-1: 3 with the ring kernel, else 7)
     TK_DEBUG_RS_PARTS,   // tests: gemm_takes_rs_parts() answers yes for every bf16 prompt shape, so that kernels which cannot take partial sums meet them (rs_parts_to_vector)
-    TK_DEBUG_TP_LOOPBACK,   // tools: an FL_TP_MULTI_PROCESS model without unique_id connects every inbox entry to ITSELF and plays all ranks' pushes (one rank's step, timed with its exchange in place; results meaningless)
+    TK_DEBUG_TP_LOOPBACK,   // tools (EXPERIMENTAL build only): an FL_TP_MULTI_PROCESS model without unique_id connects every inbox entry to ITSELF and plays all ranks' pushes (one rank's step, timed with its exchange in place; results meaningless)
     TK_DEBUG_POISON,   // tests: every device allocation of the model / cache / batch objects is filled with this byte before use (255: bf16 / fp32 NaN patterns; 63: finite 0.75s), so that a read of bytes nobody wrote shows at once instead of depending on what the allocator handed back
-    TK_GEMM_SKF,   // short prompts / decode batches (2-128 rows) on the kernel whose K slices meet inside the launch (k_gemm_skf.hip): 0 off; 1 (default) a tensor-parallel rank's complete outputs up to 64 rows; 2 also the five-launch layer (residual + norm and RoPE + KV-append epilogues: measured SLOWER than slabs + rmsnorm_add / rope_kv launches, profiles/r05/README.md); 3 also every plain launch_linear shape (tests)
+    TK_GEMM_SKF,   // short prompts / decode batches (2-128 rows) on the kernel whose K slices meet inside the launch (k_gemm_skf.hip): 0 off; 1 (default) a tensor-parallel rank's complete outputs up to 64 rows; 2 (EXPERIMENTAL build only; the default build treats it as 1) also the five-launch layer (residual + norm and RoPE + KV-append epilogues: measured SLOWER than slabs + rmsnorm_add / rope_kv launches, profiles/r05/README.md); 3 also every plain launch_linear shape (tests)
     TK_SKF_SPLIT,   // its K slices: 0 by rule, 1..4 forced (tests)
     TK_PREFILL_DMA,   // prompts of 2-32 tokens: the wide gate/up projection on the LDS-DMA ring kernel of the decode batches (k_gemv_dma.hip); 0: the short-prompt GEMM
     TK_COUNT

@@ -14,7 +14,9 @@
 // arriver, so a launch leaves the workspace as it found it and there is no per-launch host state (graph capture).  At T <= 128 a tile
 // is at most 32 KB: the serial tail of the last arriver is one L2 round trip plus the epilogue it would have run anyway (the 128 x 256
 // kernel's static block ownership, k_gemm_h4.hip, exists because ITS tiles are 128 KB).
-// Epilogues (the last arriver's, or every workgroup's when K is not sliced):
+// Epilogues (the last arriver's, or every workgroup's when K is not sliced).  The DEFAULT library holds EPI_F32 only -- what it runs: a
+// tensor-parallel rank's complete outputs; the other three are the five-launch layer, which measured slower than the launches it
+// replaces (profiles/r05/README.md) and lives in the EXPERIMENTAL build with the other kernels that lost:
 //   EPI_F32       row scale, bias -> fp32 (a complete output: what a tensor-parallel rank's all-reduce wants)
 //   EPI_GATEUP    silu(gate) * up -> bf16; the row scale may come from a residual epilogue's partial sums (RsParts)
 //   EPI_RESID     h += y; xn = bf16((h + y) * w_next); one partial sum of squares per (row, 64-column strip)  (kernels.h, ResidEpi)
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(NW * NWM * 64) void gemm_skf_kernel(const bf16_t *_
 
     const int cn = lane & 15, rm = (lane >> 4) * 4;
     const int mw = wm * MT * 16;                                        // first token (within the tile) of this wave's rows
+#ifdef FL_EXPERIMENTAL                                                  // (the five-launch layer's epilogues: see the header)
     if (epi == EPI_GATEUP) {
         if constexpr (NT == 2) {
             const int n = n0 + wrow[0] + cn;                            // gate row; up = n + 16
@@ -357,6 +360,7 @@ __global__ __launch_bounds__(NW * NWM * 64) void gemm_skf_kernel(const bf16_t *_
         }
         return;
     }
+#endif
     // EPI_F32: row scale and bias -> fp32
 #pragma unroll
     for (int i = 0; i < MT; i++)
@@ -418,6 +422,9 @@ static int skf_bn(int64_t N, int epi, int d) {
 int gemm_skf_plan(int64_t T, int64_t N, int64_t K, int epi, int d) {
     if (tune(TK_GEMM_SKF) <= 0 || T < 2 || T > 128 || K % F_BK || K / F_BK < 4 || N < 64) return 0;
     if (epi != EPI_F32 && epi != EPI_GATEUP && epi != EPI_RESID && epi != EPI_QKV_ROPE) return 0;
+#ifndef FL_EXPERIMENTAL
+    if (epi != EPI_F32) return 0;          // the five-launch layer's epilogues measured slower than the launches they replace: EXPERIMENTAL build only
+#endif
     if (epi == EPI_GATEUP && N % 32) return 0;
     if (epi == EPI_RESID && N % 64) return 0;                       // (one partial-sum slot per 64-column strip, whole strips)
     if (epi == EPI_QKV_ROPE && ((d != 64 && d != 128) || N % 128)) return 0;
@@ -489,6 +496,9 @@ int launch_gemm_skf(Launcher &L, const void *W, const void *x, const float *bias
         FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_skf: the RoPE epilogue takes its operands, the whole q | k | v matrix, head_dim 64 / 128");
     if (epi == EPI_GATEUP && (bias || ksplit != 1 || N % 32)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_skf: gate/up takes no bias and the whole K");
     if (epi != EPI_F32 && epi != EPI_GATEUP && epi != EPI_RESID && epi != EPI_QKV_ROPE) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_skf: epilogue %d", epi);
+#ifndef FL_EXPERIMENTAL
+    if (epi != EPI_F32) FL_FAIL(FL_ERR_UNSUPPORTED, "gemm_skf: the gate/up, residual and RoPE epilogues (the five-launch layer: measured slower) are in the EXPERIMENTAL build only");
+#endif
     SkfArgs a;
     if (resid) a.re = *resid;
     if (rope) { a.ro = *rope; a.ro.on = 1; }
@@ -499,10 +509,14 @@ int launch_gemm_skf(Launcher &L, const void *W, const void *x, const float *bias
         if (strips > kSkfMaxTiles || (size_t)strips * ksplit * bm * bn * 4 > kSkfPartBytes) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemm_skf: partial tiles exceed the workspace");
         FL_TRY(skf_space(L.stream, &a.ws));
     }
+#ifdef FL_EXPERIMENTAL
 #define FL_SKF(BMV)                                                                                                       \
     if (bn == 128) return launch_skf_t<BMV, 2, 4>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit, a);                  \
     if (epi == EPI_QKV_ROPE) return launch_skf_t<BMV, 2, 2>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit, a);        \
     return launch_skf_t<BMV, 1, 4>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit, a);
+#else
+#define FL_SKF(BMV) return launch_skf_t<BMV, 1, 4>(L, W, x, bias, y, T, N, K, epi, row_scale, ksplit, a);
+#endif
     if (T <= 32) { FL_SKF(32) }
     if (T <= 64) { FL_SKF(64) }
     FL_SKF(128)

@@ -128,7 +128,7 @@ static const TuneEntry g_tune_table[TK_COUNT] = {
     {"rs_lazy", 1},
     {"batch_unfused_min", -1},
     {"debug_rs_parts", 0},
-    {"debug_tp_loopback", 0},
+    {"debug_tp_loopback", 0, true},      // (results are meaningless by design: a timing tool of the EXPERIMENTAL build)
     {"debug_poison", 0},
     {"gemm_skf", 1},
     {"skf_split", 0},

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import synth
+from conftest import needs_experimental
 from oracle import oracle
 from test_gpu_parity import check_logits
 
@@ -194,6 +195,7 @@ def test_batch_fullsize_tinyllama(fa):
     batch.close()
 
 
+@needs_experimental
 @pytest.mark.parametrize("B", [3, 8, 16, 40])
 def test_batch_five_launch_layer_matches_the_default_step(fa, B):
     """FL_GEMM_SKF=2: the decode batch's layer as five launches (k_gemm_skf.hip: every row's RoPE / KV append in the QKV epilogue,

@@ -15,6 +15,7 @@ import numpy as np
 import pytest
 
 import synth
+from conftest import needs_experimental
 from oracle import oracle
 from test_gpu_fullsize import close_bf16
 
@@ -520,6 +521,7 @@ def test_mid_prompt_small_hidden_size_on_the_in_launch_kernel(env, T):
     gm.close()
 
 
+@needs_experimental
 @pytest.mark.parametrize("name,T", [("mistral-7b", 2), ("mistral-7b", 16), ("mistral-7b", 33), ("mistral-7b", 100), ("mistral-7b", 128),
                                     ("qwen2-7b", 24), ("qwen2-7b", 128), ("tinyllama-1.1b", 7), ("tinyllama-1.1b", 128)])
 def test_short_prompt_fused_layer_equals_the_slab_path(env, name, T):

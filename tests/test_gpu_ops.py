@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 import synth
+from conftest import needs_experimental
 from conftest import experimental_build
 
 pytestmark = pytest.mark.gpu
@@ -392,6 +393,7 @@ def test_linear_skf_slices_meet_in_the_launch(fa, T, N, K, slices):
         fa.tune("reload_env", 0)
 
 
+@needs_experimental
 @pytest.mark.parametrize("T,I,K", [(5, 352, 256), (32, 14336, 4096), (96, 1024, 2048), (128, 5632, 2048)])
 def test_linear_skf_gate_up(fa, T, I, K):
     """its silu(gate) * up epilogue against fp64 (gate rows [0, I), up rows [I, 2 I) in HF order: the library interleaves them)"""

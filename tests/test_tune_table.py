@@ -29,7 +29,7 @@ def test_default_build_refuses_experimental_switches_and_timing_probes(monkeypat
         pytest.skip("this is the EXPERIMENTAL build (FL_LIB_PATH)")
     except fa.FastLLMError as e:
         assert e.code == -10
-    for key in ("engine", "fuse_oproj", "attn_prefetch", "skinny_loaders", "engine_grid", "ao_waves", "engine_timeout_ms"):
+    for key in ("engine", "fuse_oproj", "attn_prefetch", "skinny_loaders", "engine_grid", "ao_waves", "engine_timeout_ms", "debug_tp_loopback"):
         with pytest.raises(fa.FastLLMError) as e:
             fa.tune(key, 1)
         assert e.value.code == -10 and "EXPERIMENTAL" in str(e.value).upper(), (key, str(e.value))

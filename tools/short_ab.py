@@ -1,5 +1,7 @@
 """Short prompts and decode batches with / without the opt-in five-launch layer (FL_GEMM_SKF 2 / 1), one process, alternating, medians.
-usage: short_ab.py model T[,T...] [batch sizes B,B]"""
+usage: short_ab.py model T[,T...] [batch sizes B,B]
+FL_GEMM_SKF=2 acts in the EXPERIMENTAL build only: run with FL_LIB_PATH=fastllm_amd/lib/libfastllm_mi355x_exp.so
+"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -7,7 +7,8 @@ The rank runs its real shard shapes, its real launches (graph-replayed decode st
 the o_proj / down_proj GEMV epilogues (comm_ll.h) or the one-shot kernels (--fused 0), the logits gather -- but every inbox entry is
 its own, so nothing waits for a peer and no link latency is included: this is what ONE rank's step costs before a byte crosses
 xGMI ("time ONE rank with the exchange looped back to itself").  The sums are sums of tp copies of the rank's own
-partials: tokens are meaningless, only the time is read.
+partials: tokens are meaningless, only the time is read.  The switch exists in the EXPERIMENTAL build only:
+    FL_LIB_PATH=fastllm_amd/lib/libfastllm_mi355x_exp.so python tools/tp_rank_loopback.py ...
 """
 import argparse
 import json
