@@ -17,7 +17,7 @@
 namespace fl {
 
 // ------------------------------------------------------------------------------- one-shot collectives
-constexpr size_t kCommFlagBytes = 4096;
+constexpr size_t kCommFlagBytes = 16384;            // one-workgroup collectives: words [0, tp); many-workgroup ones: [64 + 8 g + rank], g < 256 (k_comm.hip)
 static int comm_connect_impl(Model *m, const void *handles);
 static int comm_export_impl(Shard &sh, void *handle_out);
 
@@ -187,9 +187,16 @@ int oneshot(Model *m, Shard &sh, bool gather, const float *in, float *out, int64
     PeerComm &pc = sh.pc;
     Launcher L = make_launcher(m, sh);
     if (on) L.stream = on;
+    // workgroups of a large message (FL_ONESHOT_WIDE: 0 one, 1 up to 256, N > 1 up to N).  They WAIT for the same slice of every peer, so all
+    // of them, of every rank, must be resident at once.  One rank per GPU: always so.  Ranks that share a card (a test rig): workgroups of
+    // different processes do not share a CU on this hardware -- the fourth process' 80 workgroups found no CU while three times 80 of the others
+    // sat waiting for them (4 x 64 = 256 CUs ran, measured) -- so the ranks of a card split 192 CUs between them and leave the rest to whichever rank is still computing
+    const int64_t wide = tune(TK_ONESHOT_WIDE);
+    const int max_wgs = wide <= 0 ? 0 : pc.shares_device ? std::max(1, 192 / m->tp) : wide > 1 ? (int)std::min<int64_t>(wide, 256) : 256;
     for (int64_t off = 0; off < n; off += pc.nmax) {
         const int64_t c = std::min(pc.nmax, n - off);
-        FL_TRY(launch_oneshot(L, gather, in + off, out + off, pc.tab, sh.rank, m->tp, c, pc.nmax, out_stride, pc.epoch, pc.err, pc.timeout_ticks, pc.epoch + 8));
+        FL_TRY(launch_oneshot(L, gather, in + off, out + off, pc.tab, sh.rank, m->tp, c, pc.nmax, out_stride, pc.epoch, pc.err, pc.timeout_ticks, pc.epoch + 8,
+                              pc.epoch + 12, max_wgs));
     }
     return FL_OK;
 }

@@ -321,7 +321,7 @@ struct CommTable {
 };
 int launch_oneshot(Launcher &L, bool gather, const float *in, float *out, const CommTable &tab, int rank, int tp,
                    int64_t n, int64_t nmax, int64_t out_stride, uint32_t *epoch_ctr, uint32_t *err, long long timeout_ticks,
-                   uint32_t *abort_flag = nullptr);
+                   uint32_t *abort_flag = nullptr, uint32_t *done_ctr = nullptr, int max_wgs = 0);     // done_ctr: a zeroed device word, max_wgs > 1 -> large messages go over up to max_wgs workgroups
 
 // All-reduce fused into the epilogue of a row-parallel decode GEMV ("LL" protocol: a value and the epoch that
 // validates it travel in ONE 8-byte store, so there is no fence, no flag round and no separate kernel).  Every

@@ -56,7 +56,7 @@ static const TuneEntry g_tune_table[TK_COUNT] = {
     {"op_maxsplit", 0},
     {"op_linear_dma", 0},
     {"op_hot", 0},
-    {"ar_inbox_floats", 65536},
+    {"ar_inbox_floats", 131072},
     {"ar_timeout_ms", 20000},
     {"verbose", 0},
     {"tp_fused_ar", 1},
@@ -133,6 +133,7 @@ static const TuneEntry g_tune_table[TK_COUNT] = {
     {"gemm_skf", 1},
     {"skf_split", 0},
     {"prefill_dma", 1},
+    {"oneshot_wide", 1},
 };
 static_assert(sizeof(g_tune_table) / sizeof(g_tune_table[0]) == TK_COUNT, "one row per TuneKey, in the enum's order");
 static std::atomic<int> g_tune[TK_COUNT];

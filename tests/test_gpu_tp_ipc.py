@@ -269,7 +269,8 @@ def test_multiprocess_mid_prompt_kernels_at_7b_width(tmp_path, tp):
     gE.close()
 
 
-@pytest.mark.parametrize("name,tp,B", [("llama_tp4", 2, 3), ("llama_tp4", 4, 12), ("mistral_wide", 2, 32), ("llama_tp8", 8, 9)])
+@pytest.mark.parametrize("name,tp,B", [("llama_tp4", 2, 3), ("llama_tp4", 4, 12), ("mistral_wide", 2, 32), ("llama_tp8", 8, 9),
+                                       ("mistral_wide", 4, 16), ("mistral_wide", 8, 8)])     # (the last three: [B, h] of 16384 floats and more -- the many-workgroup collective)
 def test_batched_decode_on_a_multiprocess_group(tmp_path, name, tp, B):
     """Round 5: fl_batch_* on the ranks of an FL_TP_MULTI_PROCESS group -- the prefill-shaped step at T = B with a rank's shard shapes,
     one-shot all-reduces behind o_proj / down_proj (complete outputs, sums in rank order) and ONE gather of every rank's [B][V / tp]

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--batch", default="", help="also time fl_batch_decode with these many streams on the rank, e.g. 8,32")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     os.environ["FL_TP_FUSED_AR"] = "1" if args.fused else "0"
@@ -71,6 +72,31 @@ def main():
                                        "GBps": round(s["bytes"] / s["total_ms"] / 1e6, 1) if s["total_ms"] else None})
                 print("    %-36s x%-4d %8.2f us/launch %8.1f GB/s" % (s["name"], s["launches"] // 8, s["total_ms"] * 1e3 / s["launches"],
                                                                         s["bytes"] / (s["total_ms"] * 1e-3) / 1e9 if s["total_ms"] else 0), flush=True)
+        for B in [int(x) for x in args.batch.split(",") if x]:
+            if tp == 1 and False:
+                continue
+            caches, firsts = [], []
+            for i in range(B):
+                ci = m.new_cache(T + 120)
+                firsts.append(m.forward_argmax(ci, prompt, 0) % cfg["vocab_size"])
+                caches.append(ci)
+            bt = fa.Batch(m, caches)
+            g = bt.decode(firsts, [T] * B, 8)
+            m.synchronize()
+            t0 = time.perf_counter()
+            g = bt.decode([int(x[-1]) % cfg["vocab_size"] for x in g], [T + 8] * B, 32)
+            m.synchronize()
+            db = (time.perf_counter() - t0) / 32
+            row["batch_%d_ms_per_step_one_rank" % B] = round(db * 1e3, 4)
+            print("%s tp=%d: %d streams %.4f ms per step for one rank -> %.0f tokens/s ceiling before links" % (args.model, tp, B, db * 1e3, B / db), flush=True)
+            if args.profile:
+                m.profile_begin()
+                bt.decode([int(x[-1]) % cfg["vocab_size"] for x in g], [T + 40] * B, 4)
+                for s_ in m.profile_end():
+                    print("    %-36s x%-4d %8.2f us/launch" % (s_["name"], s_["launches"] // 4, s_["total_ms"] * 1e3 / s_["launches"]), flush=True)
+            bt.close()
+            for ci in caches:
+                ci.close()
         rows.append(row)
         c.close(); m.close()
     fa.tune("debug_tp_loopback", 0)
