@@ -192,7 +192,7 @@ int oneshot(Model *m, Shard &sh, bool gather, const float *in, float *out, int64
     // different processes do not share a CU on this hardware -- the fourth process' 80 workgroups found no CU while three times 80 of the others
     // sat waiting for them (4 x 64 = 256 CUs ran, measured) -- so the ranks of a card split 192 CUs between them and leave the rest to whichever rank is still computing
     const int64_t wide = tune(TK_ONESHOT_WIDE);
-    const int max_wgs = wide <= 0 ? 0 : pc.shares_device ? std::max(1, 192 / m->tp) : wide > 1 ? (int)std::min<int64_t>(wide, 256) : 256;
+    const int max_wgs = wide <= 0 || !pc.wide_ok ? 0 : pc.shares_device ? std::max(1, 192 / m->tp) : wide > 1 ? (int)std::min<int64_t>(wide, 256) : 256;
     for (int64_t off = 0; off < n; off += pc.nmax) {
         const int64_t c = std::min(pc.nmax, n - off);
         FL_TRY(launch_oneshot(L, gather, in + off, out + off, pc.tab, sh.rank, m->tp, c, pc.nmax, out_stride, pc.epoch, pc.err, pc.timeout_ticks, pc.epoch + 8,
@@ -278,6 +278,35 @@ int comm_bootstrap_over_rccl(Model *m) {
         ok = *pc.err == 0 && memcmp(ya.data(), yb.data(), test_n * 4) == 0;
         if (!ok && verbose) fprintf(stderr, "[fastllm_mi355x] rank %d: one-shot all-reduce self-test failed (err 0x%x)\n", sh.rank, *pc.err);
         if (agree(ok, &all) != FL_OK) return finish(FL_ERR_RCCL);
+        if (all && tune(TK_ONESHOT_WIDE) > 0 && pc.nmax >= 16384) {
+            // the many-workgroup form of the same collective (messages of 16 384 floats and more: a batch's [B, h], short prompts) is
+            // proved on its own; if it fails anywhere, every rank keeps the one-workgroup form (a wait that gave up still moves the
+            // epoch on every rank: the last workgroup's ticket does not depend on the wait's outcome)
+            const size_t wn = (size_t)std::min<int64_t>(pc.nmax, 98304) / 4 * 4;
+            float *w = nullptr;
+            int wide_good = hipMalloc((void **)&w, wn * 4) == hipSuccess;
+            if (wide_good) {
+                std::vector<float> xw(wn);
+                for (size_t i = 0; i < wn; i++) xw[i] = (float)(i % 251) + 1000.f * sh.rank;
+                FL_HIP(hipMemcpyAsync(w, xw.data(), wn * 4, hipMemcpyHostToDevice, sh.stream));
+                pc.timeout_ticks = 200000000LL;
+                wide_good = oneshot(m, sh, false, w, w, (int64_t)wn, 0) == FL_OK;
+                pc.timeout_ticks = keep;
+                FL_HIP(hipMemcpyAsync(xw.data(), w, wn * 4, hipMemcpyDeviceToHost, sh.stream));
+                FL_HIP(hipStreamSynchronize(sh.stream));
+                wide_good = wide_good && *pc.err == 0;
+                for (size_t i = 0; i < wn && wide_good; i++) wide_good = xw[i] == (float)tp * (float)(i % 251) + 1000.f * (float)(tp * (tp - 1) / 2);
+                (void)hipFree(w);
+            }
+            int wide_all = 0;
+            if (agree(wide_good, &wide_all) != FL_OK) return finish(FL_ERR_RCCL);
+            if (!wide_good && verbose) fprintf(stderr, "[fastllm_mi355x] rank %d: many-workgroup all-reduce self-test failed (err 0x%x)\n", sh.rank, *pc.err);
+            pc.wide_ok = wide_all != 0;
+            *pc.err = 0;
+            FL_HIP(hipMemsetAsync(pc.epoch + 8, 0, 4, sh.stream));
+            FL_HIP(hipMemsetAsync(pc.epoch + 12, 0, 4, sh.stream));
+            FL_HIP(hipStreamSynchronize(sh.stream));
+        }
     }
     if (!all) {                                      // stay on RCCL; the epoch counters may differ now, so the path is closed for good
         pc.connected = false;
@@ -287,7 +316,8 @@ int comm_bootstrap_over_rccl(Model *m) {
         FL_HIP(hipStreamSynchronize(sh.stream));
     }
     if (verbose && sh.rank == 0)
-        fprintf(stderr, "[fastllm_mi355x] small collectives: %s%s\n", all ? "one-shot over peer-mapped HBM" : "RCCL", all && pc.ll_ok ? ", all-reduce fused into the GEMV epilogues" : "");
+        fprintf(stderr, "[fastllm_mi355x] small collectives: %s%s%s\n", all ? "one-shot over peer-mapped HBM" : "RCCL", all && pc.ll_ok ? ", all-reduce fused into the GEMV epilogues" : "",
+                all && !pc.wide_ok ? ", one workgroup per collective" : "");
     return finish(FL_OK);
 }
 

@@ -119,7 +119,8 @@ enum TuneKey {
     TK_GEMM_SKF,   // short prompts / decode batches (2-128 rows) on the kernel whose K slices meet inside the launch (k_gemm_skf.hip): 0 off; 1 (default) a tensor-parallel rank's complete outputs up to 64 rows; 2 (EXPERIMENTAL build only; the default build treats it as 1) also the five-launch layer (residual + norm and RoPE + KV-append epilogues: measured SLOWER than slabs + rmsnorm_add / rope_kv launches, profiles/r05/README.md); 3 also every plain launch_linear shape (tests)
     TK_SKF_SPLIT,   // its K slices: 0 by rule, 1..4 forced (tests)
     TK_PREFILL_DMA,   // prompts of 2-32 tokens: the wide gate/up projection on the LDS-DMA ring kernel of the decode batches (k_gemv_dma.hip); 0: the short-prompt GEMM
-    TK_ONESHOT_WIDE,   // one-shot collectives of 16384 floats and more (a decode batch's deltas and logits, a short prompt's span) over up to 64 workgroups; 0: the one-workgroup kernel
+    TK_ONESHOT_WIDE,   // one-shot collectives of 16384 floats and more (a decode batch's deltas and logits, a short prompt's span) over up to 256 workgroups (N > 1: at most N); 0: the one-workgroup kernel
+    TK_GATEUP_ROWSPLIT,   // gate/up of a prompt 1-96 tokens past an EVEN number of 256-row tiles (513-608, 1025-1120 ...): whole rounds on the 224-column kernel + the last rows as a launch of their own; 0: one launch
     TK_COUNT
 };
 int tune(TuneKey k);

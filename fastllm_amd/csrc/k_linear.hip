@@ -120,6 +120,22 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
                 const int kw = gemm_h4_plan_whole(T, N, K, epi);
                 if (kw > 0) return launch_gemm_h4(L, W, x, bias, y, T, N, K, epi, row_scale, kw);
             }
+            // a few tokens past an even number of 256-row tiles: 3 x 128 tiles are a round and a half of the chip and cost two (Mistral-7B gate/up
+            // 512 / 513 tokens: 92.6 / 170.3 us).  The even part keeps its whole rounds and the last rows go as a launch of their own on
+            // whatever serves that many rows (ring kernel 36-46 us up to 32 rows, short-prompt GEMM 47-56 us up to 128).  Whole Mistral-7B
+            // prefills, split / one launch: 513 tokens 10.25 / 10.87 ms, 545 10.76 / 11.01, 600 11.26 / 11.37, 1025 16.49 / 16.83, 1100
+            // 16.91 / 17.08 -- and 700 12.48 / 12.29, 768 12.68 / 12.50, 1280 18.46 / 18.17: the second weight pass stops paying near 100 rows
+            if (epi == EPI_GATEUP && T > 512 && tune(TK_GATEUP_ROWSPLIT) && !bias) {
+                const int64_t tm = (T + 255) / 256, T0 = (tm - 1) * 256;
+                if ((tm & 1) && T - T0 <= 96 && gemm_w14_plan(T0, N, K, epi)) {
+                    FL_TRY(launch_gemm_w14(L, W, x, bias, y, T0, N, K, epi, row_scale));
+                    Launcher L2 = L;
+                    if (L2.rsp.part) L2.rsp.part += (size_t)T0 * L2.rsp.np;
+                    if (T - T0 <= 32) FL_TRY(rs_parts_to_vector(L2, row_scale ? row_scale + T0 : nullptr, T - T0));     // (the ring kernel reads the vector)
+                    return launch_linear(L2, dtype, W, (const char *)x + (size_t)T0 * K * 2, bias, (char *)y + (size_t)T0 * (N / 2) * 2, T - T0, N, K, epi,
+                                         row_scale ? row_scale + T0 : nullptr, max_split, nullptr);
+                }
+            }
             // 224-column tiles where they fill the chip and 256-column ones do not (k_gemm_w14.hip)
             if (gemm_w14_plan(T, N, K, epi)) return launch_gemm_w14(L, W, x, bias, y, T, N, K, epi, row_scale);
         }

@@ -65,6 +65,7 @@ struct PeerComm {
     LLTable *ll_dev = nullptr;
     bool ll_ok = false;          // region connected (and, with RCCL, proven against ncclAllReduce by all ranks)
     bool loopback = false;       // TK_DEBUG_TP_LOOPBACK: all entries are this rank's own inbox, the kernels play every rank's push
+    bool wide_ok = true;         // messages of 16 384 floats and more over many workgroups (oneshot_wide_kernel): proved at bootstrap, like the rest
     bool shares_device = false;  // a peer lives on this same GPU (rehearsals): full-chip grids that wait for each other cannot co-reside
 };
 

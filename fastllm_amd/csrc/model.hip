@@ -134,6 +134,7 @@ static const TuneEntry g_tune_table[TK_COUNT] = {
     {"skf_split", 0},
     {"prefill_dma", 1},
     {"oneshot_wide", 1},
+    {"gateup_rowsplit", 1},
 };
 static_assert(sizeof(g_tune_table) / sizeof(g_tune_table[0]) == TK_COUNT, "one row per TuneKey, in the enum's order");
 static std::atomic<int> g_tune[TK_COUNT];

@@ -250,7 +250,8 @@ _ORACLE_LONG = {}
 
 
 @pytest.mark.parametrize("name,T,tp", [("mistral-7b", 1100, 1), ("qwen2-7b", 1100, 1), ("mistral-7b", 4100, 1), ("qwen2-7b", 4096, 1),
-                                       ("mistral-7b", 512, 8), ("qwen2-7b", 4096, 4)])      # the last two: BASELINE configs C4 / C5, emulated ranks
+                                       ("mistral-7b", 512, 8), ("qwen2-7b", 4096, 4),       # these two: BASELINE configs C4 / C5, emulated ranks
+                                       ("mistral-7b", 513, 1), ("mistral-7b", 545, 1)])     # one / 33 tokens past two row tiles: gate/up as 512 rows + a launch for the rest (k_linear.hip)
 def test_7b_width_long_prompt_vs_oracle(env, name, T, tp):
     """The long-prompt kernels against the fp32 ORACLE (not against each other): full width, 2 layers (1 at 4096 / 4100 tokens, where
     the CPU side is 10 s per layer; the layer-to-layer hand-off at that length is held by the GPU-vs-GPU tests of this file, whose

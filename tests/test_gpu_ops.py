@@ -352,6 +352,28 @@ def test_linear_w14_epilogues(fa, T, N, K, epi, bias):
         np.testing.assert_array_equal(y, y0)
 
 
+@pytest.mark.parametrize("T", [513, 530, 545, 577, 608, 1030, 1120])
+def test_linear_gate_up_row_split_past_an_even_tile_count(fa, T):
+    """Round 5: gate/up of a prompt 1 ... 96 tokens past an EVEN number of 256-row tiles -- the even part on the 224-column kernel (whole
+    rounds of the chip), the last rows as a launch of their own (gemv / ring kernel / short-prompt GEMM, by row count):
+    against fp64 numpy, and against the one-launch form (another accumulation pattern: one bf16 rounding apart)."""
+    I, K = 4480, 320                                   # 2 I = 40 tiles of 224 columns
+    x, w = _rand((T, K), 191), _rand((2 * I, K), 192, 0.05)
+    xb, wb = synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w)
+    ref = _ref(synth.bf16_bits_to_f32(xb), synth.bf16_bits_to_f32(wb), None, 1)
+    try:
+        fa.tune("gemm_h4", 0); fa.tune("gemm_w14", 2)
+        y = fa.op_linear(xb, wb, None, epilogue=1)
+        fa.tune("gateup_rowsplit", 0)
+        y0 = fa.op_linear(xb, wb, None, epilogue=1)
+    finally:
+        fa.tune("reload_env", 0)
+    np.testing.assert_allclose(y, ref, atol=2e-3, rtol=2 ** -7)
+    np.testing.assert_allclose(y, y0, atol=1e-6, rtol=2 ** -7)
+    T0 = (T + 255) // 256 * 256 - 256
+    np.testing.assert_array_equal(y[:T0], y0[:T0])      # the even part: the same kernel, the same tiles
+
+
 @pytest.mark.parametrize("T,N,K,epi,bias", [(512, 4096, 4096, 0, True), (200, 1408, 1024, 1, False), (384, 704, 512, 1, False), (300, 1000, 1024, 0, True)])
 @pytest.mark.parametrize("slices", [1, 2, 4])
 def test_linear_h4_epilogues(fa, T, N, K, epi, bias, slices):
