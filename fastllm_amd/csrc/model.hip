@@ -1567,22 +1567,26 @@ int batch_create(Model *m, Cache *const *caches, size_t B, Batch **out) {
     if (m->shards.size() != 1 || (m->tp != 1 && !tp_rank)) FL_FAIL(FL_ERR_UNSUPPORTED, "batched decode runs on one GPU or on the ranks of an FL_TP_MULTI_PROCESS group");
     if (tp_rank && (!m->shards[0].pc.connected || !m->vocab_parallel || m->shards[0].Vs % 4))
         FL_FAIL(FL_ERR_UNSUPPORTED, "batched decode on a tensor-parallel group needs connected peer inboxes and a vocabulary shard that is a multiple of 4");
-    if (m->dtype != FL_DTYPE_BF16) FL_FAIL(FL_ERR_UNSUPPORTED, "batched decode is bf16 only");
     const Dims &D = m->D;
     Shard &sh = m->shards[0];
+    // fp32 models (the literal-parity mode) and caches without the MFMA attention layout: the weights are still read once per step for
+    // all B rows; embedding, RoPE / KV append and attention run as the single-sequence kernels on row i of the batch (3 B small launches
+    // per layer, replayed from the step's graph)
+    bool per_seq = m->dtype != FL_DTYPE_BF16;
     for (size_t i = 0; i < B; i++) {
         if (!caches[i] || caches[i]->m != m) FL_FAIL(FL_ERR_BAD_ARGUMENT, "cache %zu is null or belongs to another model", i);
-        if (!caches[i]->v_transposed) FL_FAIL(FL_ERR_UNSUPPORTED, "batched decode needs the MFMA attention layout (head_dim 64/128, group <= 8)");
+        if (!caches[i]->v_transposed) per_seq = true;
         for (size_t j = 0; j < i; j++) if (caches[j] == caches[i]) FL_FAIL(FL_ERR_BAD_ARGUMENT, "cache %zu appears twice in the batch", i);
     }
+    if (per_seq && tp_rank) FL_FAIL(FL_ERR_UNSUPPORTED, "batched decode on a tensor-parallel group is bf16 with the MFMA attention layout (head_dim 64/128, group <= 8)");
     std::unique_ptr<Batch> b(new Batch());
     std::lock_guard<std::mutex> lock(m->mu);
-    b->m = m; b->B = (int)B;
+    b->m = m; b->B = (int)B; b->per_seq = per_seq;
     b->caches.assign(caches, caches + B);
     // B >= 3: the prefill-shaped step (separate norm / RoPE launches) with the wide projections on the LDS-DMA ring kernel
-    b->dma = B >= (size_t)tune(TK_BATCH_DMA_MIN) && gemv_dma_supported((int)B, 2 * sh.Ip, D.h, EPI_GATEUP, 0) &&
+    b->dma = !per_seq && B >= (size_t)tune(TK_BATCH_DMA_MIN) && gemv_dma_supported((int)B, 2 * sh.Ip, D.h, EPI_GATEUP, 0) &&
              gemv_dma_supported((int)B, sh.Vs, D.h, EPI_F32, 0) && gemv_dma_ksplit(D.h, 0, EPI_GATEUP) == 1;
-    const bool gemv_rows = B <= (size_t)kMaxBatchGemv && !tp_rank;   // the streaming GEMV forms hold at most eight rows (and know no all-reduce)
+    const bool gemv_rows = B <= (size_t)kMaxBatchGemv && !tp_rank && !per_seq;   // the streaming GEMV forms hold at most eight rows (and know no all-reduce)
     if (gemv_rows) {
         b->nks_o = gemv_batch_ksplit((int)B, sh.Hs * D.d, D.h, EPI_F32);
         b->nks_down = gemv_batch_ksplit((int)B, sh.Ip, D.h, EPI_F32);
@@ -1690,13 +1694,32 @@ static int enqueue_batch_step_unfused(Batch *b) {
         ga.W = W; ga.x = sc.xn; ga.x_scale = sc.inv_rms; ga.out = out; ga.N = (int)N; ga.K = (int)D.h; ga.epi = epi; ga.pro = PRO_X; ga.B = B; ga.nks = 1;
         return launch_gemv_dma(L, ga);
     };
-    FL_TRY(launch_embed_batch(L, sh.embed, b->seqs_dev, sc.x_res, B, D.h));
+    const bool ps = b->per_seq;
+    const size_t es = m->esize();
+    if (ps) { for (int i = 0; i < B; i++) FL_TRY(launch_embed(L, dt, sh.embed, nullptr, b->caches[i]->shards[0].st, sc.x_res + (size_t)i * D.h, 1, D.h)); }
+    else FL_TRY(launch_embed_batch(L, sh.embed, b->seqs_dev, sc.x_res, B, D.h));
     const int64_t nq = (sh.Hs + 2 * sh.Hkvs) * D.d;
+    // per-sequence mode: row i's RoPE / KV append and attention on the single-sequence kernels (position, length and cache of sequence i)
+    auto rope_attn_per_seq = [&](int64_t l, const float *bias) -> int {
+        for (int i = 0; i < B; i++) {
+            Cache *ci = b->caches[i];
+            CacheShard &cs = ci->shards[0];
+            const int64_t sa = ci->seq_alloc;
+            const size_t kv_layer = (size_t)l * sh.Hkvs * sa * D.d * es;
+            void *kc = (char *)cs.k + kv_layer, *vc = (char *)cs.v + kv_layer;
+            void *qi = (char *)sc.q + (size_t)i * sh.Hs * D.d * es, *aoi = (char *)sc.ao + (size_t)i * sh.Hs * D.d * es;
+            FL_TRY(launch_rope_kv(L, dt, sc.qkv + (size_t)i * nq, cs.st, sh.cos_tab, sh.sin_tab, D.max_pos, qi, kc, vc, 1, sh.Hs, sh.Hkvs, D.d, sa, ci->v_transposed, 1, bias));
+            AttnScratch as{cs.part_m, cs.part_l, cs.part_o, cs.counters, ci->nsplit, 0};
+            if (ci->v_transposed) FL_TRY(launch_attn_decode_mfma(L, qi, kc, vc, cs.st, aoi, as, sh.Hs, sh.Hkvs, D.d, sa, D.scale));
+            else FL_TRY(launch_attn_decode(L, dt, qi, kc, vc, cs.st, aoi, as, sh.Hs, sh.Hkvs, D.d, sa, D.scale));
+        }
+        return FL_OK;
+    };
     // Round 5, FL_GEMM_SKF=2 (off by default: it measured 8-13 % SLOWER, profiles/r05/README.md): the layer as FIVE launches (k_gemm_skf.hip) -- QKV with each row's RoPE / KV append in its epilogue, attention, o_proj and
     // down_proj with the residual + next norm in theirs (K slices met inside the launch: no slabs, no rmsnorm_add), gate/up with its
     // row scales from the partial sums -- where every projection of the model has a plan there; otherwise the eight-launch layer below
     const bool tpr = m->tp > 1;                                        // a rank of a multi-process group: all-reduce behind o_proj / down_proj, gathered logits
-    const int ks_q = dt == FL_DTYPE_BF16 && sc.rs_part && !tpr && tune(TK_GEMM_SKF) >= 2 ? gemm_skf_plan(T, nq, D.h, EPI_QKV_ROPE, (int)D.d) : 0;
+    const int ks_q = dt == FL_DTYPE_BF16 && sc.rs_part && !tpr && !ps && tune(TK_GEMM_SKF) >= 2 ? gemm_skf_plan(T, nq, D.h, EPI_QKV_ROPE, (int)D.d) : 0;
     const int ks_o = ks_q ? gemm_skf_plan(T, D.h, sh.Hs * D.d, EPI_RESID) : 0, ks_d = ks_o ? gemm_skf_plan(T, D.h, sh.Ip, EPI_RESID) : 0;
     if (ks_q && ks_o && ks_d && gemm_skf_plan(T, 2 * sh.Ip, D.h, EPI_GATEUP) > 0 && tune(TK_GEMM_RESID)) {
         const int np = gemm_resid_partials(D.h);
@@ -1739,11 +1762,16 @@ static int enqueue_batch_step_unfused(Batch *b) {
         // K slices for the QKV stream too (96 strips of 64 rows otherwise: a third of the chip); the bias, if any, moves
         // into the RoPE launch, which sums the slabs anyway
         int qkv_slabs = 1;
-        FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, nullptr, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms, kMaxQkvSplitShort, &qkv_slabs));
-        FL_TRY(launch_rope_kv_batch(L, sc.qkv, b->seqs_dev, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, (size_t)l * sh.Hkvs * D.d, B, sh.Hs,
-                                    sh.Hkvs, D.d, qkv_slabs, ly.bqkv));
-        FL_TRY(launch_attn_decode_mfma_batch(L, sc.q, b->seqs_dev, B, b->max_nsplit, (size_t)l * sh.Hkvs * D.d, sc.ao, sh.Hs, sh.Hkvs,
-                                             D.d, D.scale, 0.0));
+        if (ps) {
+            FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, nullptr, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms));
+            FL_TRY(rope_attn_per_seq(l, ly.bqkv));
+        } else {
+            FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, nullptr, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms, kMaxQkvSplitShort, &qkv_slabs));
+            FL_TRY(launch_rope_kv_batch(L, sc.qkv, b->seqs_dev, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, (size_t)l * sh.Hkvs * D.d, B, sh.Hs,
+                                        sh.Hkvs, D.d, qkv_slabs, ly.bqkv));
+            FL_TRY(launch_attn_decode_mfma_batch(L, sc.q, b->seqs_dev, B, b->max_nsplit, (size_t)l * sh.Hkvs * D.d, sc.ao, sh.Hs, sh.Hkvs,
+                                                 D.d, D.scale, 0.0));
+        }
         // (a rank's row-parallel outputs: complete, no slabs -- the all-reduce wants the sum; sums in rank order on every rank)
         FL_TRY(launch_linear(L, dt, ly.wo, sc.ao, nullptr, sc.delta, T, D.h, sh.Hs * D.d, EPI_F32, nullptr, tpr ? 1 : kMaxKSplit, &nslab));
         if (tpr) FL_TRY(oneshot(m, sh, false, sc.delta, sc.delta, T * D.h, 0));

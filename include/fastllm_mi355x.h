@@ -224,7 +224,8 @@ int fl_decode_sample(fl_model *m, fl_cache *c, uint32_t first_token, size_t pos,
  * of them.  New capability: the reference runs concurrent streams as independent single-sequence loops
  * (mod.rs:137-238), each paying for the whole weight stream.  Every sequence keeps its own cache, RoPE
  * position and sampler state; per sequence the results are those of the single-sequence entry points
- * (same kernels' arithmetic, up to fp32 summation order in the norm).  bf16; one GPU, or the ranks of an FL_TP_MULTI_PROCESS group
+ * (same kernels' arithmetic, up to fp32 summation order in the norm).  bf16 or fp32 (fp32, and bf16 caches outside the MFMA attention
+ * layout: RoPE and attention run per sequence, the projections once for all rows); one GPU, or -- bf16 -- the ranks of an FL_TP_MULTI_PROCESS group
  * with connected inboxes -- every rank then builds the same batch over its own caches and calls the same entry points in the same
  * order (the step's all-reduces and the gather of the ranks' logits blocks are collectives; a rank that stays away is
  * FL_ERR_RCCL after FL_AR_TIMEOUT_MS on the others).

@@ -12,6 +12,7 @@ def main():
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--batches", default="1,2,4,8")
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--dtype", default="bf16", help="bf16 | f32 (fp32 batches: RoPE / attention per sequence, the projections once for all rows)")
     args = ap.parse_args()
     import torch
     import bench
@@ -20,7 +21,7 @@ def main():
     cfg = MODEL_CONFIGS[args.model]
     dev = torch.device("cuda", 0)
     wts = bench.synth_device_weights(torch, cfg, dev)
-    gm = fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype="bf16")
+    gm = fa.Model(cfg, bench.as_fl_tensors(wts, 0), dtype=args.dtype)
     del wts
     torch.cuda.empty_cache()
     T, K = args.prompt, args.steps
