@@ -120,6 +120,7 @@ enum TuneKey {
     TK_SKF_SPLIT,   // its K slices: 0 by rule, 1..4 forced (tests)
     TK_PREFILL_DMA,   // prompts of 2-32 tokens: the wide gate/up projection on the LDS-DMA ring kernel of the decode batches (k_gemv_dma.hip); 0: the short-prompt GEMM
     TK_ONESHOT_WIDE,   // one-shot collectives of 16384 floats and more (a decode batch's deltas and logits, a short prompt's span) over up to 256 workgroups (N > 1: at most N); 0: the one-workgroup kernel
+    TK_F32_ROWS_MAX,   // fp32 mode: projections of 2 ... this many token rows (short prompts, decode batches; at most 64) as a weight stream with the x rows in LDS (gemv_f32_rows_kernel); 0: the MFMA tiles
     TK_GATEUP_ROWSPLIT,   // gate/up of a prompt 1-96 tokens past an EVEN number of 256-row tiles (513-608, 1025-1120 ...): whole rounds on the 224-column kernel + the last rows as a launch of their own; 0: one launch
     TK_COUNT
 };

@@ -195,6 +195,65 @@ static int launch_decode_t(Launcher &L, const void *q, const void *kc, const voi
                     sc.counters, (CT *)out, (int)H, (int)Hkv, (int)max_seq, scale, sc.nsplit);
 }
 
+// The same kernel body for the rows of a decode batch (caches in the plain layout: fp32 models, head shapes outside the MFMA
+// attention): grid.y = sequence x split, every pointer, the length and the split count from the sequence's SeqRef.
+template <typename CT, int D, int GMAX, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_batch_kernel(const CT *__restrict__ q, const SeqRef *__restrict__ seqs, size_t kv_layer_off,
+                                                                    CT *__restrict__ out, int H, int Hkv, float scale, int max_nsplit) {
+    __shared__ float lds[decode_lds_floats<D, GMAX, NW>()];
+    __shared__ int is_last;
+    constexpr int LPK = D / 8, KPI = 64 / LPK, UNR = 2;
+    const int hk = blockIdx.x, b = blockIdx.y / max_nsplit, split = blockIdx.y % max_nsplit;
+    const SeqRef &sq = seqs[b];
+    const int nsplit = sq.nsplit;
+    if (split >= nsplit) return;                              // (the whole workgroup: no barrier is left waiting)
+    const int Gall = H / Hkv, g0 = blockIdx.z * GMAX;
+    const int G = min(GMAX, Gall - g0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = (int)sq.st->len + 1;
+    int per = (S + nsplit - 1) / nsplit;
+    per = (per + NW * KPI - 1) / (NW * KPI) * (NW * KPI);
+    const int lo = split * per, hi = min(S, lo + per);
+    const int hq0 = hk * Gall + g0;
+    const size_t sa = (size_t)sq.seq_alloc;
+    const CT *kc = reinterpret_cast<const CT *>(sq.k) + kv_layer_off * sa, *vc = reinterpret_cast<const CT *>(sq.v) + kv_layer_off * sa;
+
+    float qv[GMAX][8];
+    load_q<CT, D, GMAX>(qv, q + (size_t)b * H * D, hq0, G, lane, scale);
+    AttnState<GMAX> s; s.init();
+    if (lo < hi)
+        attend_range<CT, D, GMAX, NW, UNR>(s, qv, G, kc + (size_t)hk * sa * D, vc + (size_t)hk * sa * D, lo, hi, wave, lane);
+    merge_to_lds<D, GMAX, NW>(s, G, lds, wave, lane);
+    decode_tail<CT, D, GMAX, NW>(lds, &is_last, G, hq0, hk * (int)gridDim.z + (int)blockIdx.z, split, nsplit, sq.part_m, sq.part_l,
+                                 sq.part_o, sq.counters, out + (size_t)b * H * D);
+}
+
+template <typename CT, int D, int GMAX, int NW>
+static int launch_decode_batch_t(Launcher &L, const void *q, const SeqRef *seqs, int B, int max_nsplit, size_t kv_layer_off, void *out,
+                                 int64_t H, int64_t Hkv, float scale) {
+    const int G = (int)(H / Hkv);
+    if (max_nsplit > 64 || (int64_t)B * max_nsplit > 65535) FL_FAIL(FL_ERR_BAD_ARGUMENT, "attention: at most 64 splits, 65535 sequence x split workgroup rows");
+    dim3 grid((unsigned)Hkv, (unsigned)(B * max_nsplit), (unsigned)((G + GMAX - 1) / GMAX));
+    return L.launch(KC_ATTN_DECODE, 0.0, 0.0, attn_decode_batch_kernel<CT, D, GMAX, NW>, grid, dim3(NW * 64), 0, (const CT *)q, seqs, kv_layer_off,
+                    (CT *)out, (int)H, (int)Hkv, scale, max_nsplit);
+}
+
+bool attn_decode_batch_supported(int64_t d) { return d == 64 || d == 128; }
+
+int launch_attn_decode_batch(Launcher &L, int dtype, const void *q, const SeqRef *seqs_dev, int B, int max_nsplit, size_t kv_layer_off, void *out,
+                             int64_t H, int64_t Hkv, int64_t d, float scale) {
+    const bool small = H / Hkv <= 4;
+#define FL_DISPATCH(CT)                                                                                                                   \
+    if (d == 128) return small ? launch_decode_batch_t<CT, 128, 4, 4>(L, q, seqs_dev, B, max_nsplit, kv_layer_off, out, H, Hkv, scale)    \
+                               : launch_decode_batch_t<CT, 128, 8, 4>(L, q, seqs_dev, B, max_nsplit, kv_layer_off, out, H, Hkv, scale);   \
+    if (d == 64) return small ? launch_decode_batch_t<CT, 64, 4, 4>(L, q, seqs_dev, B, max_nsplit, kv_layer_off, out, H, Hkv, scale)      \
+                              : launch_decode_batch_t<CT, 64, 8, 4>(L, q, seqs_dev, B, max_nsplit, kv_layer_off, out, H, Hkv, scale);
+    if (dtype == FL_DTYPE_BF16) { FL_DISPATCH(bf16_t) }
+    else { FL_DISPATCH(float) }
+#undef FL_DISPATCH
+    FL_FAIL(FL_ERR_UNSUPPORTED, "attention: head_dim %lld not supported (64 or 128)", (long long)d);
+}
+
 int launch_attn_decode(Launcher &L, int dtype, const void *q, const void *k_cache, const void *v_cache,
                        const StepState *st, void *out, const AttnScratch &sc, int64_t H, int64_t Hkv, int64_t d,
                        int64_t max_seq, float scale) {

@@ -111,6 +111,122 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float *__restr
         }
 }
 
+// ---- short prompts and decode batches in fp32 (2 ... 64 rows): a weight stream, not matrix work ----------------------------------
+// The MFMA kernel above runs N / 128 workgroups below 64 tokens -- 32 of 256 CUs for a 4096-row matrix -- and a 4-stream fp32 decode
+// step took 45 ms where one stream's takes 5.9.  Here a workgroup of eight waves owns 16 weight rows and ALL of up to TB token rows:
+// the x rows of a 1024-float K chunk are staged in LDS (TB x 4 KB), every wave streams ITS two weight rows as coalesced float4s (1 KB
+// per wave per load, eight loads in flight per lane) and every x float4 it reads from LDS serves both rows; fp32 FMAs, one butterfly
+// per (row, token) sum at the end.  More than TB tokens: one pass over the weights per block of 16 rows (the host loops).
+// gate/up: a workgroup takes 8 gate rows and their 8 up rows (16 further down the interleaved matrix), a wave holds a pair.
+template <int TB>
+__global__ __launch_bounds__(512) void gemv_f32_rows_kernel(const float *__restrict__ W, const float *__restrict__ X, const float *__restrict__ bias,
+                                                            float *__restrict__ out, int T, int t0, int N, int K, int epi,
+                                                            const float *__restrict__ row_scale) {
+    constexpr int KC = 1024;
+    __shared__ float4v xs[TB][KC / 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int rows[2];
+    if (epi == EPI_GATEUP) {
+        const int g = blockIdx.x >> 1, p = (blockIdx.x & 1) * 8 + wave;
+        rows[0] = g * 32 + p; rows[1] = g * 32 + 16 + p;
+    } else {
+        rows[0] = blockIdx.x * 16 + wave * 2; rows[1] = rows[0] + 1;
+    }
+    float acc[2][TB];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int t = 0; t < TB; t++) acc[r][t] = 0.f;
+    const float4v zero = {0.f, 0.f, 0.f, 0.f};
+    const float *wr0 = W + (size_t)min(rows[0], N - 1) * K, *wr1 = W + (size_t)min(rows[1], N - 1) * K;
+    // K is whole 256-float pieces (one float4 per lane): every bound below is wave-uniform
+    float4v w[2][4];
+    const int kl = lane * 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (j * 256 < K) {
+            w[0][j] = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(wr0 + j * 256 + kl));
+            w[1][j] = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(wr1 + j * 256 + kl));
+        } else { w[0][j] = zero; w[1][j] = zero; }
+    }
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        __syncthreads();                                      // the previous chunk has been consumed
+        const int kc = min(KC, K - k0) / 4;                   // float4s per row in this chunk
+#pragma unroll 2
+        for (int idx = tid; idx < TB * (KC / 4); idx += 512) {
+            const int t = idx / (KC / 4), c = idx % (KC / 4), row = t0 + t;
+            if (c < kc) xs[t][c] = row < T ? *reinterpret_cast<const float4v *>(X + (size_t)row * K + k0 + 4 * c) : zero;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (k0 + j * 256 < K) {
+                const float4v w0 = w[0][j], w1 = w[1][j];
+                if (k0 + KC + j * 256 < K) {                 // this slot's registers are free: the next chunk's piece goes out now
+                    w[0][j] = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(wr0 + k0 + KC + j * 256 + kl));
+                    w[1][j] = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(wr1 + k0 + KC + j * 256 + kl));
+                }
+#pragma unroll
+                for (int t = 0; t < TB; t++) {
+                    const float4v xv = xs[t][j * 64 + lane];
+                    acc[0][t] = fmaf(w0[3], xv[3], fmaf(w0[2], xv[2], fmaf(w0[1], xv[1], fmaf(w0[0], xv[0], acc[0][t]))));
+                    acc[1][t] = fmaf(w1[3], xv[3], fmaf(w1[2], xv[2], fmaf(w1[1], xv[1], fmaf(w1[0], xv[0], acc[1][t]))));
+                }
+            }
+        }
+    }
+    float res[2] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int t = 0; t < TB; t++) {
+            const float v = wave_sum(acc[r][t]);
+            if (lane == t) res[r] = v;
+        }
+    const int m = t0 + lane;
+    if (lane < TB && m < T) {
+        const float rs = row_scale ? row_scale[m] : 1.0f;
+        if (epi == EPI_GATEUP) {
+            const int n = rows[0];                            // gate row; its up row is the pair's second
+            if (n + 16 < N) {
+                const float gt = res[0] * rs, up = res[1] * rs;
+                out[(size_t)m * (N / 2) + (n >> 5) * 16 + (n & 15)] = gt / (1.0f + expf(-gt)) * up;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int n = rows[r];
+                if (n < N) out[(size_t)m * N + n] = res[r] * rs + (bias ? bias[n] : 0.f);
+            }
+        }
+    }
+}
+
+bool gemv_f32_rows_supported(int64_t T, int64_t N, int64_t K, int epi) {
+    const int64_t maxt = tune(TK_F32_ROWS_MAX);
+    return maxt > 0 && T > 1 && T <= std::min<int64_t>(maxt, 64) && K % 256 == 0 && N >= 1 && (epi == EPI_F32 || (epi == EPI_GATEUP && N % 32 == 0));
+}
+
+int launch_gemv_f32_rows(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K, int epi,
+                         const float *row_scale) {
+    if (!gemv_f32_rows_supported(T, N, K, epi)) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemv_f32_rows: 2-64 rows, K a multiple of 256");
+    if (epi == EPI_GATEUP && bias) FL_FAIL(FL_ERR_BAD_ARGUMENT, "gemv_f32_rows: gate/up has no bias");
+    char tag[40];
+    snprintf(tag, sizeof tag, "f32rows,%lldx%lld", (long long)N, (long long)K);
+    Launcher LL = L; LL.tag = tag;
+    const unsigned grid = (unsigned)((N + 15) / 16);
+    for (int64_t t0 = 0; t0 < T; t0 += 16) {
+        const int64_t tb = std::min<int64_t>(16, T - t0);
+        const double bytes = ((double)N * K + (double)tb * K) * 4.0, flops = 2.0 * tb * N * K;
+        int rc;
+        if (tb <= 4) rc = LL.launch(KC_GEMM_GENERIC, bytes, flops, gemv_f32_rows_kernel<4>, dim3(grid), dim3(512), 0, (const float *)W, (const float *)x, bias, (float *)y, (int)T, (int)t0, (int)N, (int)K, epi, row_scale);
+        else if (tb <= 8) rc = LL.launch(KC_GEMM_GENERIC, bytes, flops, gemv_f32_rows_kernel<8>, dim3(grid), dim3(512), 0, (const float *)W, (const float *)x, bias, (float *)y, (int)T, (int)t0, (int)N, (int)K, epi, row_scale);
+        else rc = LL.launch(KC_GEMM_GENERIC, bytes, flops, gemv_f32_rows_kernel<16>, dim3(grid), dim3(512), 0, (const float *)W, (const float *)x, bias, (float *)y, (int)T, (int)t0, (int)N, (int)K, epi, row_scale);
+        FL_TRY(rc);
+    }
+    return FL_OK;
+}
+
 bool gemm_f32_mfma_supported(int64_t T, int64_t N, int64_t K) {
     return tune(TK_GEMM_F32_MFMA) != 0 && T > 1 && N >= 1 && K % 16 == 0 && K >= 16;
 }

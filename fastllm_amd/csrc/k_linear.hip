@@ -175,6 +175,7 @@ int launch_linear(Launcher &L, int dtype, const void *W, const void *x, const fl
     FL_TRY(no_parts());
     if (dtype == FL_DTYPE_F32) {
         if (T == 1 && gemv_supported(dtype, N, K)) return launch_gemv(L, dtype, plain_args(W, x, bias, y, N, K, epi, row_scale));
+        if (gemv_f32_rows_supported(T, N, K, epi) && !tune(TK_FORCE_GENERIC_GEMM)) return launch_gemv_f32_rows(L, W, x, bias, y, T, N, K, epi, row_scale);
         if (gemm_f32_mfma_supported(T, N, K) && !tune(TK_FORCE_GENERIC_GEMM)) return launch_gemm_f32_mfma(L, W, x, bias, y, T, N, K, epi, row_scale);
         return launch_gemm_generic<float, float>(L, W, x, bias, y, T, N, K, epi, row_scale);
     }

@@ -268,10 +268,11 @@ int launch_rope_kv(Launcher &L, int dtype, const float *qkv, const StepState *st
 
 // ------------------------------------------------------------------------------- batched variants (row N4)
 // One row per sequence of a batch: the token, RoPE position, KV slot and caches come from its SeqRef.
-__global__ __launch_bounds__(256) void embed_batch_kernel(const bf16_t *__restrict__ E, const SeqRef *__restrict__ seqs,
+template <typename WT>
+__global__ __launch_bounds__(256) void embed_batch_kernel(const WT *__restrict__ E, const SeqRef *__restrict__ seqs,
                                                           float *__restrict__ x, int h) {
     const int b = blockIdx.x;
-    const bf16_t *row = E + (size_t)seqs[b].st->token * h;
+    const WT *row = E + (size_t)seqs[b].st->token * h;
     float *dst = x + (size_t)b * h;
     for (int c = threadIdx.x; c * 8 < h; c += 256) {
         float v[8];
@@ -280,16 +281,19 @@ __global__ __launch_bounds__(256) void embed_batch_kernel(const bf16_t *__restri
     }
 }
 
-int launch_embed_batch(Launcher &L, const void *E, const SeqRef *seqs_dev, float *x_res, int B, int64_t h) {
-    return L.launch(KC_EMBED, (double)B * h * 6, 0, embed_batch_kernel, dim3((unsigned)B), dim3(256), 0, (const bf16_t *)E, seqs_dev,
+int launch_embed_batch(Launcher &L, const void *E, const SeqRef *seqs_dev, float *x_res, int B, int64_t h, int dtype) {
+    if (dtype == FL_DTYPE_F32)
+        return L.launch(KC_EMBED, (double)B * h * 8, 0, embed_batch_kernel<float>, dim3((unsigned)B), dim3(256), 0, (const float *)E, seqs_dev, x_res, (int)h);
+    return L.launch(KC_EMBED, (double)B * h * 6, 0, embed_batch_kernel<bf16_t>, dim3((unsigned)B), dim3(256), 0, (const bf16_t *)E, seqs_dev,
                     x_res, (int)h);
 }
 
 // qkv fp32 [B][(H+2Hkv)*d] -> RoPE -> q bf16 [B][H*d], rotated k and v appended to each sequence's own cache
 // (V transposed, the MFMA attention layout); kv_layer_off = layer * Hkv * d, times the sequence's seq_alloc
+template <typename CT, bool VT>
 __global__ __launch_bounds__(256) void rope_kv_batch_kernel(const float *__restrict__ qkv, const SeqRef *__restrict__ seqs,
                                                             const float *__restrict__ cos_tab, const float *__restrict__ sin_tab,
-                                                            int max_pos, bf16_t *__restrict__ q_out, size_t kv_layer_off, int B,
+                                                            int max_pos, CT *__restrict__ q_out, size_t kv_layer_off, int B,
                                                             int H, int Hkv, int d, int n_slab, const float *__restrict__ bias) {
     const int half = d >> 1;
     const int nheads = H + 2 * Hkv;
@@ -313,21 +317,32 @@ __global__ __launch_bounds__(256) void rope_kv_batch_kernel(const float *__restr
         const float c = cos_tab[(size_t)p * half + j], s = sin_tab[(size_t)p * half + j];
         float ra, rb;
         rope_rotate(a, bb, c, s, ra, rb);
-        bf16_t *o = hd < H ? q_out + ((size_t)b * H + hd) * d
-                           : reinterpret_cast<bf16_t *>(sq.k) + kv_layer_off * sa + ((size_t)(hd - H) * sa + slot) * d;
-        elem<bf16_t>::st(o + j, ra); elem<bf16_t>::st(o + j + half, rb);
-    } else {
-        bf16_t *o = reinterpret_cast<bf16_t *>(sq.v) + kv_layer_off * sa + (size_t)(hd - H - Hkv) * d * sa + slot;
-        elem<bf16_t>::st(o + (size_t)j * sa, a); elem<bf16_t>::st(o + (size_t)(j + half) * sa, bb);
+        CT *o = hd < H ? q_out + ((size_t)b * H + hd) * d
+                       : reinterpret_cast<CT *>(sq.k) + kv_layer_off * sa + ((size_t)(hd - H) * sa + slot) * d;
+        elem<CT>::st(o + j, ra); elem<CT>::st(o + j + half, rb);
+    } else if (VT) {                                      // V transposed [Hkv][d][seq_alloc]: the MFMA attention layout
+        CT *o = reinterpret_cast<CT *>(sq.v) + kv_layer_off * sa + (size_t)(hd - H - Hkv) * d * sa + slot;
+        elem<CT>::st(o + (size_t)j * sa, a); elem<CT>::st(o + (size_t)(j + half) * sa, bb);
+    } else {                                              // V [Hkv][seq_alloc][d]
+        CT *o = reinterpret_cast<CT *>(sq.v) + kv_layer_off * sa + ((size_t)(hd - H - Hkv) * sa + slot) * d;
+        elem<CT>::st(o + j, a); elem<CT>::st(o + j + half, bb);
     }
 }
 
 int launch_rope_kv_batch(Launcher &L, const float *qkv, const SeqRef *seqs_dev, const float *cos_tab, const float *sin_tab,
                          int64_t max_pos, void *q_out, size_t kv_layer_off, int B, int64_t H, int64_t Hkv, int64_t d, int n_slab,
-                         const float *bias) {
+                         const float *bias, int dtype, bool v_transposed) {
     const int64_t total = (int64_t)B * (H + 2 * Hkv) * (d / 2);
-    return L.launch(KC_ROPE_KV, (double)B * (H + 2 * Hkv) * d * 6, 0, rope_kv_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
-                    0, qkv, seqs_dev, cos_tab, sin_tab, (int)max_pos, (bf16_t *)q_out, kv_layer_off, B, (int)H, (int)Hkv, (int)d, n_slab, bias);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    const double bytes = (double)B * (H + 2 * Hkv) * d * (dtype == FL_DTYPE_F32 ? 8 : 6);
+    if (dtype == FL_DTYPE_F32)
+        return L.launch(KC_ROPE_KV, bytes, 0, rope_kv_batch_kernel<float, false>, grid, dim3(256), 0, qkv, seqs_dev, cos_tab, sin_tab, (int)max_pos,
+                        (float *)q_out, kv_layer_off, B, (int)H, (int)Hkv, (int)d, n_slab, bias);
+    if (!v_transposed)
+        return L.launch(KC_ROPE_KV, bytes, 0, rope_kv_batch_kernel<bf16_t, false>, grid, dim3(256), 0, qkv, seqs_dev, cos_tab, sin_tab, (int)max_pos,
+                        (bf16_t *)q_out, kv_layer_off, B, (int)H, (int)Hkv, (int)d, n_slab, bias);
+    return L.launch(KC_ROPE_KV, bytes, 0, rope_kv_batch_kernel<bf16_t, true>, grid, dim3(256), 0, qkv, seqs_dev, cos_tab, sin_tab, (int)max_pos,
+                    (bf16_t *)q_out, kv_layer_off, B, (int)H, (int)Hkv, (int)d, n_slab, bias);
 }
 
 // ------------------------------------------------------------------------------- token selection + advance

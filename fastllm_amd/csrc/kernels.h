@@ -184,12 +184,16 @@ int launch_gemv_dma(Launcher &L, const GemvBatchArgs &a);
 // q / out bf16 [B][H*d]; kv_layer_off = layer * Hkv * d (times each sequence's seq_alloc inside)
 int launch_attn_decode_mfma_batch(Launcher &L, const void *q, const SeqRef *seqs_dev, int B, int max_nsplit, size_t kv_layer_off,
                                   void *out, int64_t H, int64_t Hkv, int64_t d, float scale, double kv_bytes_hint);
-int launch_embed_batch(Launcher &L, const void *E, const SeqRef *seqs_dev, float *x_res, int B, int64_t h);
+int launch_embed_batch(Launcher &L, const void *E, const SeqRef *seqs_dev, float *x_res, int B, int64_t h, int dtype = FL_DTYPE_BF16);
+// the plain-layout batch attention (k_attn.hip): fp32 models, bf16 caches outside the MFMA attention layout; head_dim 64 / 128
+bool attn_decode_batch_supported(int64_t d);
+int launch_attn_decode_batch(Launcher &L, int dtype, const void *q, const SeqRef *seqs_dev, int B, int max_nsplit, size_t kv_layer_off, void *out,
+                             int64_t H, int64_t Hkv, int64_t d, float scale);
 // n_slab: K slices of the QKV projection ([n_slab][B][(H+2Hkv)*d] fp32, summed here); bias: added here (a K-sliced
 // projection cannot add it itself) or null
 int launch_rope_kv_batch(Launcher &L, const float *qkv, const SeqRef *seqs_dev, const float *cos_tab, const float *sin_tab,
                          int64_t max_pos, void *q_out, size_t kv_layer_off, int B, int64_t H, int64_t Hkv, int64_t d, int n_slab = 1,
-                         const float *bias = nullptr);
+                         const float *bias = nullptr, int dtype = FL_DTYPE_BF16, bool v_transposed = true);
 // logits fp32 [B][V] -> every sequence's token / step state
 int launch_unshard_logits(Launcher &L, const float *in, float *out, int tp, int B, int64_t Vs);   // [tp][B][Vs] -> [B][tp * Vs]
 int launch_select_advance_batch(Launcher &L, const float *logits, int64_t V, const SeqRef *seqs_dev, int B, int advance);
@@ -249,6 +253,10 @@ int gemm_h4_plan_whole(int64_t T, int64_t N, int64_t K, int epi);   // ... for a
 // 256 x 224 four-wave tile (k_gemm_w14.hip): fp32 / gate-up epilogues, N whole 224-column tiles
 // fp32 operands on the matrix cores (k_gemm_f32.hip): the fp32 mode's prompt GEMM, bit-identical to gemm_generic_kernel's fmaf chains
 bool gemm_f32_mfma_supported(int64_t T, int64_t N, int64_t K);
+// fp32, 2-64 token rows: a weight stream with the x rows in LDS (k_gemm_f32.hip)
+bool gemv_f32_rows_supported(int64_t T, int64_t N, int64_t K, int epi);
+int launch_gemv_f32_rows(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K, int epi,
+                         const float *row_scale);
 int launch_gemm_f32_mfma(Launcher &L, const void *W, const void *x, const float *bias, void *y, int64_t T, int64_t N, int64_t K,
                          int epi, const float *row_scale);
 bool gemm_w14_plan(int64_t T, int64_t N, int64_t K, int epi);

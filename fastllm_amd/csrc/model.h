@@ -163,6 +163,7 @@ struct Batch {
     int B = 0, max_nsplit = 1, nks_o = 1, nks_down = 1;
     bool dma = false;                            // B >= 3: projections on the LDS-DMA ring kernel (k_gemv_dma.hip)
     bool unfused = false;                        // large B: norm / GEMM / RoPE as separate launches around the short-prompt GEMM
+    bool plain = false;                          // ... all caches in the plain layout and head_dim 64 / 128: the batch kernels' plain-layout forms (one RoPE and one attention launch per layer)
     bool per_seq = false;                        // fp32 models, caches without the MFMA attention layout: embedding / RoPE / attention as launches per sequence (the single-sequence kernels on row i), the projections still once for all B rows
     Scratch sc;                                  // ... with the prefill scratch layout at T = B
     SeqRef *seqs_dev = nullptr;

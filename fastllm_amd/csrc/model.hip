@@ -134,6 +134,7 @@ static const TuneEntry g_tune_table[TK_COUNT] = {
     {"skf_split", 0},
     {"prefill_dma", 1},
     {"oneshot_wide", 1},
+    {"f32_rows_max", 64},
     {"gateup_rowsplit", 1},
 };
 static_assert(sizeof(g_tune_table) / sizeof(g_tune_table[0]) == TK_COUNT, "one row per TuneKey, in the enum's order");
@@ -1582,6 +1583,10 @@ int batch_create(Model *m, Cache *const *caches, size_t B, Batch **out) {
     std::unique_ptr<Batch> b(new Batch());
     std::lock_guard<std::mutex> lock(m->mu);
     b->m = m; b->B = (int)B; b->per_seq = per_seq;
+    if (per_seq && attn_decode_batch_supported(D.d)) {
+        b->plain = true;
+        for (size_t i = 0; i < B; i++) if (caches[i]->v_transposed) b->plain = false;
+    }
     b->caches.assign(caches, caches + B);
     // B >= 3: the prefill-shaped step (separate norm / RoPE launches) with the wide projections on the LDS-DMA ring kernel
     b->dma = !per_seq && B >= (size_t)tune(TK_BATCH_DMA_MIN) && gemv_dma_supported((int)B, 2 * sh.Ip, D.h, EPI_GATEUP, 0) &&
@@ -1696,8 +1701,8 @@ static int enqueue_batch_step_unfused(Batch *b) {
     };
     const bool ps = b->per_seq;
     const size_t es = m->esize();
-    if (ps) { for (int i = 0; i < B; i++) FL_TRY(launch_embed(L, dt, sh.embed, nullptr, b->caches[i]->shards[0].st, sc.x_res + (size_t)i * D.h, 1, D.h)); }
-    else FL_TRY(launch_embed_batch(L, sh.embed, b->seqs_dev, sc.x_res, B, D.h));
+    if (ps && !b->plain) { for (int i = 0; i < B; i++) FL_TRY(launch_embed(L, dt, sh.embed, nullptr, b->caches[i]->shards[0].st, sc.x_res + (size_t)i * D.h, 1, D.h)); }
+    else FL_TRY(launch_embed_batch(L, sh.embed, b->seqs_dev, sc.x_res, B, D.h, dt));
     const int64_t nq = (sh.Hs + 2 * sh.Hkvs) * D.d;
     // per-sequence mode: row i's RoPE / KV append and attention on the single-sequence kernels (position, length and cache of sequence i)
     auto rope_attn_per_seq = [&](int64_t l, const float *bias) -> int {
@@ -1762,7 +1767,13 @@ static int enqueue_batch_step_unfused(Batch *b) {
         // K slices for the QKV stream too (96 strips of 64 rows otherwise: a third of the chip); the bias, if any, moves
         // into the RoPE launch, which sums the slabs anyway
         int qkv_slabs = 1;
-        if (ps) {
+        if (b->plain) {
+            // plain cache layout (fp32 models; bf16 outside the MFMA attention's head shapes): the batch kernels' plain forms
+            FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, nullptr, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms));
+            FL_TRY(launch_rope_kv_batch(L, sc.qkv, b->seqs_dev, sh.cos_tab, sh.sin_tab, D.max_pos, sc.q, (size_t)l * sh.Hkvs * D.d, B, sh.Hs,
+                                        sh.Hkvs, D.d, 1, ly.bqkv, dt, false));
+            FL_TRY(launch_attn_decode_batch(L, dt, sc.q, b->seqs_dev, B, b->max_nsplit, (size_t)l * sh.Hkvs * D.d, sc.ao, sh.Hs, sh.Hkvs, D.d, D.scale));
+        } else if (ps) {
             FL_TRY(launch_linear(L, dt, ly.wqkv, sc.xn, nullptr, sc.qkv, T, nq, D.h, EPI_F32, sc.inv_rms));
             FL_TRY(rope_attn_per_seq(l, ly.bqkv));
         } else {

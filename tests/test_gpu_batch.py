@@ -194,9 +194,11 @@ def test_batch_fp32_matches_single_and_oracle(fa, name, B):
     batch.close()
 
 
-def test_batch_without_the_mfma_attention_layout(fa):
+@pytest.mark.parametrize("mode", ["plain", "mixed"])
+def test_batch_without_the_mfma_attention_layout(fa, mode):
     """bf16 caches in the plain layout (FL_ATTN_MFMA=0 stands in for a head shape the MFMA attention does not take): the batch runs
-    the per-sequence attention instead of being refused."""
+    the plain-layout batch kernels -- or, when the caches of one batch differ in layout ("mixed"), RoPE / attention per sequence --
+    instead of being refused."""
     cfg = synth.CONFIGS["mistral_a"]
     w = synth.synth_weights(cfg)
     gm = fa.Model(cfg, w, dtype="bf16")
@@ -208,6 +210,12 @@ def test_batch_without_the_mfma_attention_layout(fa):
         singles, _, _ = prefilled(gm, cfg, lens)
     finally:
         fa.tune("reload_env", 0)
+    if mode == "mixed":                                    # sequences 1 and 3 on caches in the MFMA layout
+        c2, f2, _ = prefilled(gm, cfg, lens)
+        for i in (1, 3):
+            caches[i].close()
+            caches[i] = c2[i]
+            assert f2[i] == firsts[i]
     ocs = []
     for p in prompts:
         oc = om.new_cache(96)

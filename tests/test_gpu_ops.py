@@ -352,6 +352,27 @@ def test_linear_w14_epilogues(fa, T, N, K, epi, bias):
         np.testing.assert_array_equal(y, y0)
 
 
+@pytest.mark.parametrize("T,N,K,epi,bias", [(2, 4096, 4096, 0, True), (5, 1000, 512, 0, False), (16, 6144, 4096, 0, True), (17, 520, 1280, 0, True),
+                                            (40, 4096, 14336, 0, False), (64, 300, 256, 0, True), (3, 352, 256, 1, False), (16, 14336, 4096, 1, False),
+                                            (33, 1024, 2304, 1, False), (9, 2, 256, 0, True)])
+def test_linear_f32_weight_stream_for_few_rows(fa, T, N, K, epi, bias):
+    """Round 5: fp32 projections of 2-64 token rows (short prompts and decode batches of the fp32 mode) as a weight stream -- 16 weight
+    rows and all token rows of a 16-row block per workgroup, x in LDS (gemv_f32_rows_kernel) -- against fp64 numpy, and against the
+    MFMA tiles it replaces there (another order of the fp32 sums)."""
+    x, w = _rand((T, K), 301), _rand((N if not epi else 2 * N, K), 302, 0.05)
+    b = _rand((N,), 303) if bias else None
+    ref = _ref(x, w, b, epi)
+    try:
+        y = fa.op_linear(x, w, b, epilogue=epi)
+        fa.tune("f32_rows_max", 0)
+        y0 = fa.op_linear(x, w, b, epilogue=epi)
+    finally:
+        fa.tune("reload_env", 0)
+    tol = 2e-5 * np.sqrt(K) + 1e-5
+    np.testing.assert_allclose(y, ref, atol=tol, rtol=1e-5)
+    np.testing.assert_allclose(y, y0, atol=tol, rtol=1e-5)
+
+
 @pytest.mark.parametrize("T", [513, 530, 545, 577, 608, 1030, 1120])
 def test_linear_gate_up_row_split_past_an_even_tile_count(fa, T):
     """Round 5: gate/up of a prompt 1 ... 96 tokens past an EVEN number of 256-row tiles -- the even part on the 224-column kernel (whole
