@@ -269,6 +269,15 @@ def test_multiprocess_mid_prompt_kernels_at_7b_width(tmp_path, tp):
     gE.close()
 
 
+def test_stalled_peer_in_a_batch_step_is_an_error_not_a_hang(tmp_path):
+    """... and the same for the many-workgroup collective behind a batch step's o_proj ([4, 4096] = 16 384 floats): every waiting
+    workgroup gives up after FL_AR_TIMEOUT_MS, the last one still moves the epoch, the step returns FL_ERR_RCCL."""
+    res = run_group(tmp_path, "mistral_wide", "bf16", 2, env_extra={"TP_WORKER_STALLED_RANK": "1", "FL_AR_TIMEOUT_MS": "300", "TP_WORKER_BATCH": "4"})
+    msg = str(res[0]["error"])
+    assert "gave up waiting for a peer" in msg and "0xa11d" in msg, msg
+    assert float(res[0]["waited_s"]) < 30.0
+
+
 @pytest.mark.parametrize("name,tp,B", [("llama_tp4", 2, 3), ("llama_tp4", 4, 12), ("mistral_wide", 2, 32), ("llama_tp8", 8, 9),
                                        ("mistral_wide", 4, 16), ("mistral_wide", 8, 8)])     # (the last three: [B, h] of 16384 floats and more -- the many-workgroup collective)
 def test_batched_decode_on_a_multiprocess_group(tmp_path, name, tp, B):

@@ -85,10 +85,22 @@ def run_rank(rank, world, name, dtype, outdir, T, n_tf, n_greedy):
     if stalled:
         # rank `stalled` never issues the decode step (but stays mapped: nobody may push into freed memory); the others
         # must come back with an error after the bounded wait instead of hanging the GPU
+        n_batch = int(os.environ.get("TP_WORKER_BATCH", "0"))
+        bt = None
+        if n_batch:                                      # the step that stalls is a BATCH step: [B, h] all-reduces on the many-workgroup collective
+            caches, firsts = [], []
+            for i in range(n_batch):
+                ci = m.new_cache(32)
+                firsts.append(m.forward_argmax(ci, synth.prompt_ids(cfg, 4 + i, seed=70 + i), 0))
+                caches.append(ci)
+            bt = fa.Batch(m, caches)
         if rank != int(stalled):
             t0 = time.time()
             try:
-                m.decode_greedy(c, 1, T, 1)
+                if bt is not None:
+                    bt.forward(firsts, [4 + i for i in range(n_batch)])
+                else:
+                    m.decode_greedy(c, 1, T, 1)
                 msg = "no error"
             except RuntimeError as e:
                 msg = str(e)
