@@ -124,7 +124,10 @@ __global__ __launch_bounds__(kWideThreads) void oneshot_wide_kernel(const float 
     __syncthreads();
     const int fw = kWideFlag0 + g * FL_MAX_TP;
     if (tid < tp) {
-        __hip_atomic_store(tab.flags[tid] + fw + (tab.loop ? tid : rank), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (fence + relaxed store rather than a release store: the fence's write-back is WAITED for -- buffer_wbl2 sc0 sc1; s_waitcnt
+        // vmcnt(0) -- before the flag leaves; the compiler's release store issued the flag right behind the write-back)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __hip_atomic_store(tab.flags[tid] + fw + (tab.loop ? tid : rank), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const uint32_t *f = tab.flags[rank] + fw + tid;
         const long long t0 = wall_clock64();
         while ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
