@@ -127,15 +127,16 @@ def run_rank(rank, world, name, dtype, outdir, T, n_tf, n_greedy):
     n_batch = int(os.environ.get("TP_WORKER_BATCH", "0"))
     if n_batch:                                          # a batch of streams on the group: every rank builds the same batch
         lens = [3 + (2 * i) % 11 for i in range(n_batch)]
+        n_bsteps = int(os.environ.get("TP_WORKER_BATCH_STEPS", "10"))
         caches, firsts = [], []
         for i, n in enumerate(lens):
-            ci = m.new_cache(48)
+            ci = m.new_cache(38 + n_bsteps)
             firsts.append(m.forward_argmax(ci, synth.prompt_ids(cfg, n, seed=70 + i), 0))
             caches.append(ci)
         bt = fa.Batch(m, caches)
         lg, am = bt.forward(firsts, lens)
         res["batch_logits"], res["batch_first"] = lg, np.asarray(firsts, dtype=np.uint32)
-        toks = bt.decode([int(t) for t in am], [n + 1 for n in lens], 10)
+        toks = bt.decode([int(t) for t in am], [n + 1 for n in lens], n_bsteps)
         res["batch_tokens"] = np.stack([np.concatenate([[am[i]], toks[i]]).astype(np.uint32) for i in range(n_batch)])
         bt.close()
         for ci in caches:
