@@ -9,9 +9,9 @@ import torch, bench
 import fastllm_amd as fa
 from fastllm_amd.configs import MODEL_CONFIGS
 OFF = {"gemm_h4": 0, "gemm_w14": 0, "gemm_rope_4w": 0, "attn_pf32_ks2": 1, "attn_pf32_min_t": 640, "h4_nt": 0, "w14_nt": 0, "skinny_nt": 0, "rs_lazy": 0,
-       "gemm_skf": 0, "prefill_dma": 0}          # (round 5: a rank's complete outputs on k_gemm_skf.hip, short prompts' gate/up on the ring kernel)
-TS = [2, 16, 17, 32, 33, 64, 65, 128, 129, 175, 176, 191, 192, 255, 256, 257, 351, 352, 511, 512, 513, 576, 577, 639, 640, 641, 703, 704, 767, 768, 769,
-      1023, 1024, 1025, 1535, 1536, 2040, 2047]
+       "gemm_skf": 0, "prefill_dma": 0, "gateup_rowsplit": 0}   # (round 5: a rank's complete outputs on k_gemm_skf.hip, short prompts' gate/up on the ring kernel, the gate/up row split)
+TS = [2, 16, 17, 32, 33, 64, 65, 128, 129, 175, 176, 191, 192, 255, 256, 257, 351, 352, 511, 512, 513, 544, 545, 576, 577, 608, 609, 639, 640, 641, 703, 704, 767, 768, 769,
+      1023, 1024, 1025, 1120, 1121, 1535, 1536, 2040, 2047]
 worst = 0.0
 TP = int(os.environ.get("PB_TP", "1"))                  # > 1: FL_TP_EMULATED ranks (every rank's shard on this GPU: the per-rank shapes)
 if os.environ.get("PB_TS"):
