@@ -107,6 +107,7 @@ def lib():
         L.fl_profile_end.argtypes = [vp, C.POINTER(FlKernelStat), sz, C.POINTER(sz)]
         L.fl_tune.argtypes = [C.c_char_p, C.c_int]
         L.fl_comm_probe.argtypes = [vp, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
+        L.fl_comm_selftest.argtypes = [vp, C.c_int64, C.POINTER(C.c_int32)]
         L.fl_op_linear.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int32,
                                    C.POINTER(C.c_double)]
         _LIB = L
@@ -277,6 +278,13 @@ class Model:
         us = C.c_double(-1.0)
         _check(lib().fl_comm_probe(self._h, form, n, iters, C.byref(us)))
         return None if us.value < 0 else us.value
+
+    def comm_selftest(self, n):
+        """One all-reduce of n integer-valued floats over the connected inboxes, checked exactly (n >= 16384: the many-workgroup form).
+        Collective: every rank calls it.  True: this rank holds the exact sums."""
+        ok = C.c_int32(0)
+        _check(lib().fl_comm_selftest(self._h, n, C.byref(ok)))
+        return bool(ok.value)
 
     def profile_begin(self):
         _check(lib().fl_profile_begin(self._h))

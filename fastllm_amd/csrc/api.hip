@@ -248,6 +248,16 @@ int fl_comm_probe(fl_model *m, int32_t form, int64_t n, int32_t iters, double *u
     });
 }
 
+int fl_comm_selftest(fl_model *m, int64_t n, int32_t *ok) {
+    return guarded([&]() -> int {
+        if (!m || !ok) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+        int good = 0;
+        const int rc = comm_selftest(M(m), n, &good);
+        *ok = good;
+        return rc;
+    });
+}
+
 int fl_tp_slice(const fl_config *cfg, const char *tensor_name, int32_t tp_rank, int32_t tp_size, int64_t out[4]) {
     return guarded([&]() -> int {
         if (!tensor_name || !out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");

@@ -201,6 +201,53 @@ int oneshot(Model *m, Shard &sh, bool gather, const float *in, float *out, int64
     return FL_OK;
 }
 
+// One all-reduce of n integer-valued floats over the connected inboxes -- x_r[i] = (i % 251) + 1000 r: exact in fp32 whatever the
+// summation order -- checked against the closed form, with a 2 s bound on every wait (a path that does not work must fail fast).
+// n picks the form (k_comm.hip: 16 384 floats and more run on many workgroups).  Collective: every rank of the group calls it.
+// *good = 0: this rank saw a wrong sum or a wait that gave up; the error word and the abort flag are cleared again either way (a wait
+// that gave up still moved the epoch on every rank), so the group stays usable on the forms that did pass.
+int comm_prove_oneshot(Model *m, Shard &sh, int64_t n, int *good) {
+    PeerComm &pc = sh.pc;
+    *good = 0;
+    if (!pc.connected || n < 1 || n > pc.nmax) return FL_OK;
+    const int tp = m->tp;
+    FL_HIP(hipSetDevice(sh.device));
+    float *w = nullptr;
+    if (hipMalloc((void **)&w, (size_t)n * 4) != hipSuccess) { (void)hipGetLastError(); return FL_OK; }
+    std::vector<float> x((size_t)n);
+    for (int64_t i = 0; i < n; i++) x[(size_t)i] = (float)(i % 251) + 1000.f * sh.rank;
+    const long long keep = pc.timeout_ticks;
+    int ok = hipMemcpyAsync(w, x.data(), (size_t)n * 4, hipMemcpyHostToDevice, sh.stream) == hipSuccess;
+    pc.timeout_ticks = 200000000LL;
+    ok = ok && oneshot(m, sh, false, w, w, n, 0) == FL_OK;
+    pc.timeout_ticks = keep;
+    ok = ok && hipMemcpyAsync(x.data(), w, (size_t)n * 4, hipMemcpyDeviceToHost, sh.stream) == hipSuccess;
+    ok = hipStreamSynchronize(sh.stream) == hipSuccess && ok;
+    ok = ok && *pc.err == 0;
+    const float base = 1000.f * (float)(tp * (tp - 1) / 2);
+    for (int64_t i = 0; i < n && ok; i++) ok = x[(size_t)i] == (float)tp * (float)(i % 251) + base;
+    (void)hipFree(w);
+    *pc.err = 0;
+    (void)hipMemsetAsync(pc.epoch + 8, 0, 4, sh.stream);          // the abort word a failed wait left behind
+    (void)hipMemsetAsync(pc.epoch + 12, 0, 4, sh.stream);         // ... and the many-workgroup form's ticket
+    (void)hipStreamSynchronize(sh.stream);
+    (void)hipGetLastError();
+    *good = ok ? 1 : 0;
+    return FL_OK;
+}
+
+// fl_comm_selftest: the proof above on a connected group, whoever connected it (RCCL bootstrap or fl_comm_ipc_connect)
+int comm_selftest(Model *m, int64_t n, int *ok) {
+    if (!m || !ok) FL_FAIL(FL_ERR_BAD_ARGUMENT, "comm_selftest: null argument");
+    *ok = 0;
+    if (m->tp_mode != FL_TP_MULTI_PROCESS || m->shards.size() != 1) FL_FAIL(FL_ERR_UNSUPPORTED, "comm_selftest: one rank of an FL_TP_MULTI_PROCESS group");
+    std::lock_guard<std::mutex> lock(m->mu);
+    Shard &sh = m->shards[0];
+    if (!sh.pc.connected) FL_FAIL(FL_ERR_UNSUPPORTED, "comm_selftest: the peer inboxes are not connected");
+    if (n < 1 || n > sh.pc.nmax) FL_FAIL(FL_ERR_BAD_ARGUMENT, "comm_selftest: 1 ... %lld values (FL_AR_INBOX_FLOATS)", (long long)sh.pc.nmax);
+    return comm_prove_oneshot(m, sh, n, ok);
+}
+
 // Self-contained bootstrap when an RCCL communicator exists: all-gather the IPC handles through it,
 // map the peers, then prove the path on integer-valued data against ncclAllReduce.  Every decision
 // is agreed by all ranks (min over ranks), so either all use the one-shot path or none does.
@@ -280,32 +327,12 @@ int comm_bootstrap_over_rccl(Model *m) {
         if (agree(ok, &all) != FL_OK) return finish(FL_ERR_RCCL);
         if (all && tune(TK_ONESHOT_WIDE) > 0 && pc.nmax >= 16384) {
             // the many-workgroup form of the same collective (messages of 16 384 floats and more: a batch's [B, h], short prompts) is
-            // proved on its own; if it fails anywhere, every rank keeps the one-workgroup form (a wait that gave up still moves the
-            // epoch on every rank: the last workgroup's ticket does not depend on the wait's outcome)
-            const size_t wn = (size_t)std::min<int64_t>(pc.nmax, 98304) / 4 * 4;
-            float *w = nullptr;
-            int wide_good = hipMalloc((void **)&w, wn * 4) == hipSuccess;
-            if (wide_good) {
-                std::vector<float> xw(wn);
-                for (size_t i = 0; i < wn; i++) xw[i] = (float)(i % 251) + 1000.f * sh.rank;
-                FL_HIP(hipMemcpyAsync(w, xw.data(), wn * 4, hipMemcpyHostToDevice, sh.stream));
-                pc.timeout_ticks = 200000000LL;
-                wide_good = oneshot(m, sh, false, w, w, (int64_t)wn, 0) == FL_OK;
-                pc.timeout_ticks = keep;
-                FL_HIP(hipMemcpyAsync(xw.data(), w, wn * 4, hipMemcpyDeviceToHost, sh.stream));
-                FL_HIP(hipStreamSynchronize(sh.stream));
-                wide_good = wide_good && *pc.err == 0;
-                for (size_t i = 0; i < wn && wide_good; i++) wide_good = xw[i] == (float)tp * (float)(i % 251) + 1000.f * (float)(tp * (tp - 1) / 2);
-                (void)hipFree(w);
-            }
-            int wide_all = 0;
+            // proved on its own; if it fails anywhere, every rank keeps the one-workgroup form
+            int wide_good = 0, wide_all = 0;
+            if (comm_prove_oneshot(m, sh, std::min<int64_t>(pc.nmax, 98304) / 4 * 4, &wide_good) != FL_OK) wide_good = 0;
             if (agree(wide_good, &wide_all) != FL_OK) return finish(FL_ERR_RCCL);
-            if (!wide_good && verbose) fprintf(stderr, "[fastllm_mi355x] rank %d: many-workgroup all-reduce self-test failed (err 0x%x)\n", sh.rank, *pc.err);
+            if (!wide_good && verbose) fprintf(stderr, "[fastllm_mi355x] rank %d: many-workgroup all-reduce self-test failed\n", sh.rank);
             pc.wide_ok = wide_all != 0;
-            *pc.err = 0;
-            FL_HIP(hipMemsetAsync(pc.epoch + 8, 0, 4, sh.stream));
-            FL_HIP(hipMemsetAsync(pc.epoch + 12, 0, 4, sh.stream));
-            FL_HIP(hipStreamSynchronize(sh.stream));
         }
     }
     if (!all) {                                      // stay on RCCL; the epoch counters may differ now, so the path is closed for good

@@ -214,6 +214,7 @@ int comm_ll_publish(Model *m, Shard &sh);              // every entry is set: ha
 int comm_connect_loopback(Model *m);                   // TK_DEBUG_TP_LOOPBACK: every entry is this rank's own inbox (timing tool)
 int comm_bootstrap_over_rccl(Model *m);                // all-gather the handles through RCCL, connect, self-test, vote
 int comm_probe(Model *m, int form, int64_t n, int iters, double *us_per_call);   // fl_comm_probe
+int comm_selftest(Model *m, int64_t n, int *ok);                                  // fl_comm_selftest
 int comm_check(Model *m);                              // a kernel gave up waiting for a peer -> FL_ERR_RCCL
 // n floats in chunks of at most the inbox size; reduce: out = sum over ranks (in == out allowed); gather: out[r * out_stride + i] = in_r[i]
 int oneshot(Model *m, Shard &sh, bool gather, const float *in, float *out, int64_t n, int64_t out_stride, hipStream_t on = nullptr);

@@ -270,6 +270,14 @@ int fl_profile_end(fl_model *m, fl_kernel_stat *stats, size_t cap, size_t *n_sta
  * (the decode all-reduce after o_proj / down_proj; bench.py --gpus N reports the three side by side.) */
 int fl_comm_probe(fl_model *m, int32_t form, int64_t n, int32_t iters, double *us_per_call);
 
+/* Proves the one-shot collectives of a connected FL_TP_MULTI_PROCESS group on data whose sums are exact: one all-reduce of n
+ * integer-valued floats (n <= FL_AR_INBOX_FLOATS; 16 384 and more take the many-workgroup form, fewer the one-workgroup form),
+ * every wait bounded by 2 s.  Collective: every rank calls it with the same n.  *ok = 1: this rank holds the exact sums; 0: a wrong
+ * sum or a wait that gave up (the error state is cleared: the group stays usable).  A model created with a unique_id has run this
+ * itself (and fallen back by an all-ranks vote); a group wired by fl_comm_ipc_connect can ask for it here.
+ * (the all-reduce after o_proj / down_proj.) */
+int fl_comm_selftest(fl_model *m, int64_t n, int32_t *ok);
+
 /* Process-wide switches (sweeps and tests; not needed in normal use).  Every switch is an integer row of ONE table
  * (fastllm_amd/csrc/common.h, enum TuneKey, documents each; DESIGN.md's appendix lists them): key "gemm_h4" is the row read from
  * the environment variable FL_GEMM_H4.  The environment is read ONCE, on first use; afterwards only this call changes a switch.

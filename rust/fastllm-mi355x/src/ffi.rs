@@ -210,6 +210,7 @@ extern "C" {
     pub fn fl_profile_begin(m: *mut fl_model) -> c_int;
     pub fn fl_profile_end(m: *mut fl_model, stats: *mut fl_kernel_stat, cap: usize, n_stats: *mut usize) -> c_int;
     pub fn fl_comm_probe(m: *mut fl_model, form: i32, n: i64, iters: i32, us_per_call: *mut f64) -> c_int;
+    pub fn fl_comm_selftest(m: *mut fl_model, n: i64, ok: *mut i32) -> c_int;
     pub fn fl_tune(key: *const c_char, value: c_int) -> c_int;
     pub fn fl_op_linear(
         x: *const c_void,

@@ -269,6 +269,23 @@ def test_multiprocess_mid_prompt_kernels_at_7b_width(tmp_path, tp):
     gE.close()
 
 
+@pytest.mark.parametrize("name,tp", [("llama_tp4", 2), ("llama_tp4", 4), ("llama_tp8", 8)])
+def test_comm_selftest_proves_both_collective_forms(tmp_path, name, tp):
+    """fl_comm_selftest -- the proof the RCCL bootstrap runs before it trusts the inboxes (comm_prove_oneshot: integer-valued data,
+    exact sums, 2 s bounds) -- on groups wired by fl_comm_ipc_connect: 4096 floats (one workgroup), 16 384 and 98 304 (many), and
+    the model is as usable afterwards as before (same bits as the emulated group)."""
+    import fastllm_amd as fa
+    from fastllm_amd import binding
+    res = run_group(tmp_path, name, "bf16", tp, env_extra={"TP_WORKER_SELFTEST": "1", "FL_ATTN_REP": "0" if tp > 4 else "1"})
+    for r in range(tp):
+        assert res[r]["selftest"].tolist() == [True, True, True], "rank %d: %s" % (r, res[r]["selftest"])
+    cfg = synth.CONFIGS[name]
+    gE = fa.Model(cfg, synth.synth_weights(cfg), dtype="bf16", tp_mode=binding.TP_EMULATED, tp_size=tp)
+    cE = gE.new_cache(32)
+    np.testing.assert_array_equal(res[0]["prefill"], gE.forward(cE, synth.prompt_ids(cfg, 14, seed=11)[:10], 0))
+    gE.close()
+
+
 def test_stalled_peer_in_a_batch_step_is_an_error_not_a_hang(tmp_path):
     """... and the same for the many-workgroup collective behind a batch step's o_proj ([4, 4096] = 16 384 floats): every waiting
     workgroup gives up after FL_AR_TIMEOUT_MS, the last one still moves the epoch, the step returns FL_ERR_RCCL."""

@@ -72,7 +72,10 @@ def run_rank(rank, world, name, dtype, outdir, T, n_tf, n_greedy):
     m.ipc_connect(exchange(outdir, rank, world, m.ipc_export(), "handle"))
     ids = synth.prompt_ids(cfg, T + n_tf, seed=11)
     c = m.new_cache(T + n_tf + n_greedy + 8)
+    selftest = [m.comm_selftest(n) for n in (4096, 16384, 98304)] if os.environ.get("TP_WORKER_SELFTEST", "") == "1" else []
     res = {"prefill": m.forward(c, ids[:T], 0)}
+    if selftest:
+        res["selftest"] = np.array(selftest)
     if os.environ.get("TP_WORKER_PROFILE", "") == "1":
         # the same prompt again under the profiler: launches bracketed by events, which also keeps the all-reduces on the compute
         # stream -- the schedule FL_TP_EMULATED runs, so these logits are the emulated group's bits
