@@ -373,6 +373,57 @@ def test_linear_f32_weight_stream_for_few_rows(fa, T, N, K, epi, bias):
     np.testing.assert_allclose(y, y0, atol=tol, rtol=1e-5)
 
 
+def _fuzz_shapes(seed, n):
+    """Seeded projection shapes biased to the planner's edges: token counts around tile heights and policy thresholds, widths around
+    224 / 256-column tiles and chip-filling counts, K around the K-tile and slice boundaries."""
+    rs = np.random.RandomState(seed)
+    edges_t = [1, 2, 8, 16, 17, 32, 33, 64, 65, 96, 128, 129, 176, 192, 256, 257, 384, 512, 513, 545, 608, 609, 640, 768, 769, 1024, 1025, 1121]
+    out = []
+    while len(out) < n:
+        T = int(edges_t[rs.randint(len(edges_t))] + rs.randint(-1, 2)) if rs.rand() < 0.7 else int(rs.randint(1, 1300))
+        T = max(T, 1)
+        epi = int(rs.rand() < 0.35)
+        N = int(rs.choice([224, 256, 448, 1792, 2048, 3584, 4096, 6144, 7168, 8960, 11264, 14336, 28672])) if rs.rand() < 0.6 else int(rs.randint(2, 900)) * 32
+        if rs.rand() < 0.25 and not epi:
+            N += int(rs.randint(1, 31))                       # ragged widths (plain epilogue only: gate/up rows come in groups of 32)
+        K = int(rs.choice([64, 128, 256, 512, 1024, 2048, 3584, 4096, 5632])) if rs.rand() < 0.6 else int(rs.randint(2, 700)) * 8
+        if (T * N * K > 1.2e10) or (N * K > 6e7):
+            continue
+        out.append((T, N, K, epi, bool(rs.rand() < 0.3) and not epi))
+    return out
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_linear_shape_fuzz_bf16(fa, seed):
+    """Every shape goes to SOME kernel (launch_linear's plans: GEMV, ring kernel, short-prompt GEMM, 128 x 256 / 256 x 224 / 256 x 256
+    tiles, K slices, peeled columns, stream-K tails, the gate/up row split): 14 seeded shapes per seed, biased to the planner's edges,
+    each against fp64 numpy.  A hole between two plans (a shape nobody takes correctly) shows here."""
+    for T, N, K, epi, bias in _fuzz_shapes(seed, 14):
+        x, w = _rand((T, K), 1000 + seed), _rand((N, K), 2000 + seed, 0.05)
+        b = _rand((N,), 3000 + seed) if bias else None
+        xb, wb = synth.f32_to_bf16_bits(x), synth.f32_to_bf16_bits(w)
+        ref = _ref(synth.bf16_bits_to_f32(xb), synth.bf16_bits_to_f32(wb), b, epi)
+        y = fa.op_linear(xb, wb, b, epilogue=epi)
+        msg = "T=%d N=%d K=%d epi=%d bias=%s" % (T, N, K, epi, bias)
+        if epi:
+            np.testing.assert_allclose(y, ref, atol=2e-3, rtol=2 ** -7, err_msg=msg)
+        else:
+            np.testing.assert_allclose(y, ref, atol=2e-5 * np.sqrt(K) + 1e-5, rtol=1e-5, err_msg=msg)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_linear_shape_fuzz_f32(fa, seed):
+    """The fp32 mode's plans (GEMV, the weight stream for 2-64 rows, MFMA tiles, the generic kernel) over seeded shapes."""
+    for T, N, K, epi, bias in _fuzz_shapes(seed, 12):
+        if T * N * K > 3e9:
+            T = max(1, int(3e9 // (N * K)))
+        x, w = _rand((T, K), 1000 + seed), _rand((N, K), 2000 + seed, 0.05)
+        b = _rand((N,), 3000 + seed) if bias else None
+        ref = _ref(x, w, b, epi)
+        y = fa.op_linear(x, w, b, epilogue=epi)
+        np.testing.assert_allclose(y, ref, atol=2e-5 * np.sqrt(K) + 1e-5, rtol=1e-5, err_msg="T=%d N=%d K=%d epi=%d bias=%s" % (T, N, K, epi, bias))
+
+
 @pytest.mark.parametrize("T", [513, 530, 545, 577, 608, 1030, 1120])
 def test_linear_gate_up_row_split_past_an_even_tile_count(fa, T):
     """Round 5: gate/up of a prompt 1 ... 96 tokens past an EVEN number of 256-row tiles -- the even part on the 224-column kernel (whole
