@@ -99,6 +99,7 @@ def lib():
         L.fl_batch_create.argtypes = [vp, vp, sz, C.POINTER(vp)]
         L.fl_batch_destroy.argtypes = [vp]
         L.fl_batch_destroy.restype = None
+        L.fl_batch_replace.argtypes = [vp, C.c_size_t, vp]
         L.fl_batch_forward.argtypes = [vp, vp, vp, vp, vp]
         L.fl_batch_decode.argtypes = [vp, vp, vp, sz, C.c_int64, C.POINTER(FlSampling), vp, vp]
         L.fl_synchronize.argtypes = [vp]
@@ -327,6 +328,11 @@ class Batch:
         _check(lib().fl_batch_forward(self._h, tokens.ctypes.data, pos.ctypes.data, lg.ctypes.data if want_logits else None,
                                       am.ctypes.data))
         return (lg, am) if want_logits else am
+
+    def replace(self, slot, cache):
+        """Continuous batching: `cache` takes the place of sequence `slot` (the batch is not rebuilt)."""
+        _check(lib().fl_batch_replace(self._h, slot, cache._h))
+        self._caches[slot] = cache
 
     def decode(self, first_tokens, pos, n_steps, eos=-1, temperature=None, seed=0, draws_done=1):
         first = np.ascontiguousarray(first_tokens, dtype=np.uint32)

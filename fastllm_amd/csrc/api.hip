@@ -221,6 +221,11 @@ void fl_batch_destroy(fl_batch *b) {
         if (m && m->refs.fetch_sub(1) == 1) delete m;
     });
 }
+int fl_batch_replace(fl_batch *b, size_t slot, fl_cache *cache) {
+    return guarded([&]() -> int {
+        return batch_replace(reinterpret_cast<Batch *>(b), slot, reinterpret_cast<Cache *>(cache));
+    });
+}
 int fl_batch_forward(fl_batch *b, const uint32_t *tokens, const size_t *pos, float *logits_out, uint32_t *argmax_out) {
     return guarded([&]() -> int {
         return batch_forward(reinterpret_cast<Batch *>(b), tokens, pos, logits_out, argmax_out);

@@ -184,6 +184,7 @@ struct Batch {
 constexpr size_t kBatchChunk = 256;              // decode steps enqueued between two looks at the tokens
 
 int batch_create(Model *m, Cache *const *caches, size_t B, Batch **out);
+int batch_replace(Batch *b, size_t slot, Cache *c);     // fl_batch_replace: another stream's cache takes sequence `slot`'s place
 // one step for every sequence: tokens[b] at RoPE offset pos[b]; logits_out [B][V] (host) or null
 int batch_forward(Batch *b, const uint32_t *tokens, const size_t *pos, float *logits_out, uint32_t *tokens_out);
 // n_steps greedy / sampled steps; tokens_out [B][n_steps], n_out [B] (stops counting a sequence at its EOS)

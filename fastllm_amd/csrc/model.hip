@@ -1638,6 +1638,35 @@ int batch_create(Model *m, Cache *const *caches, size_t B, Batch **out) {
     return FL_OK;
 }
 
+// Continuous batching: sequence `slot` of a batch leaves (EOS, cancelled) and another stream's cache takes its place,
+// without rebuilding the batch.  Every kernel of the step reads a sequence's pointers, length and split count from its SeqRef in
+// device memory, so the step's captured graph stays valid: the swap is one 80-byte copy.  The graph is dropped (and re-captured by
+// the next step) only where launch geometry or node arguments depend on the caches: a larger attention split count than any
+// sequence had so far, or the per-sequence launches of a mixed-layout batch.
+int batch_replace(Batch *b, size_t slot, Cache *c) {
+    if (!b || !c) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+    Model *m = b->m;
+    if (slot >= (size_t)b->B) FL_FAIL(FL_ERR_BAD_ARGUMENT, "slot %zu not in 0..%d", slot, b->B - 1);
+    if (c->m != m) FL_FAIL(FL_ERR_BAD_ARGUMENT, "the cache belongs to another model");
+    for (int i = 0; i < b->B; i++)
+        if (b->caches[i] == c && (size_t)i != slot) FL_FAIL(FL_ERR_BAD_ARGUMENT, "the cache is sequence %d of this batch already", i);
+    if (b->caches[slot] == c) return FL_OK;
+    if (!b->per_seq && !c->v_transposed) FL_FAIL(FL_ERR_UNSUPPORTED, "this batch runs the MFMA batch attention: the new cache must be in that layout too");
+    if (b->plain && c->v_transposed) FL_FAIL(FL_ERR_UNSUPPORTED, "this batch runs the plain-layout batch attention: the new cache must be in that layout too");
+    std::lock_guard<std::mutex> lock(m->mu);
+    Shard &sh = m->shards[0];
+    FL_HIP(hipSetDevice(sh.device));
+    FL_HIP(hipStreamSynchronize(sh.stream));
+    CacheShard &cs = c->shards[0];
+    const SeqRef ref{cs.st, cs.ss, cs.k, cs.v, cs.part_m, cs.part_l, cs.part_o, cs.counters, cs.out_tokens, cs.sel_scratch, (int)c->seq_alloc, c->nsplit};
+    FL_HIP(hipMemcpy(b->seqs_dev + slot, &ref, sizeof(SeqRef), hipMemcpyHostToDevice));
+    b->caches[slot] = c;
+    const bool regraph = c->nsplit > b->max_nsplit || (b->per_seq && !b->plain);
+    b->max_nsplit = std::max(b->max_nsplit, c->nsplit);
+    if (regraph && b->graph) { (void)hipGraphExecDestroy(b->graph); b->graph = nullptr; }
+    return FL_OK;
+}
+
 static int enqueue_batch_step_unfused(Batch *b);
 
 // One decode step of the whole batch: the 5-launch layer of enqueue_decode_fused with B activation rows.

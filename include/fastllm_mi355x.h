@@ -233,6 +233,12 @@ int fl_decode_sample(fl_model *m, fl_cache *c, uint32_t first_token, size_t pos,
 typedef struct fl_batch fl_batch;
 int  fl_batch_create(fl_model *m, fl_cache *const *caches, size_t n, fl_batch **out);
 void fl_batch_destroy(fl_batch *b);
+/* Continuous batching: `cache` (prefilled by fl_forward*, of the same model, not in the batch yet) takes the place of sequence
+ * `slot` -- a stream that hit its EOS leaves, a waiting one joins -- without rebuilding the batch: one small copy, the step's captured
+ * graph stays valid.  The cache that leaves is untouched and stays usable on its own.  A slot with no stream to serve can hold a
+ * spare cache (its row is computed and ignored).  Not on a tensor-parallel group's batch while a step is outstanding on a peer:
+ * every rank replaces the same slot between the same two steps.  (mod.rs:137-238: streams come and go independently.) */
+int  fl_batch_replace(fl_batch *b, size_t slot, fl_cache *cache);
 /* one step: tokens[i] at RoPE offset pos[i]; logits_out [n][V] fp32 host or NULL; argmax_out [n] or NULL */
 int  fl_batch_forward(fl_batch *b, const uint32_t *tokens, const size_t *pos, float *logits_out, uint32_t *argmax_out);
 /* the loop of fl_decode_greedy / fl_decode_sample for every sequence: tokens_out [n][n_steps], n_out [n];

@@ -192,6 +192,7 @@ extern "C" {
 
     pub fn fl_batch_create(m: *mut fl_model, caches: *const *mut fl_cache, n: usize, out: *mut *mut fl_batch) -> c_int;
     pub fn fl_batch_destroy(b: *mut fl_batch);
+    pub fn fl_batch_replace(b: *mut fl_batch, slot: usize, cache: *mut fl_cache) -> c_int;
     pub fn fl_batch_forward(b: *mut fl_batch, tokens: *const u32, pos: *const usize, logits_out: *mut f32, argmax_out: *mut u32) -> c_int;
     pub fn fl_batch_decode(
         b: *mut fl_batch,

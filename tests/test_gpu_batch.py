@@ -233,6 +233,49 @@ def test_batch_without_the_mfma_attention_layout(fa, mode):
     batch.close()
 
 
+@pytest.mark.parametrize("name,dtype", [("mistral_a", "bf16"), ("qwen2_a", "bf16"), ("llama_a", "f32")])
+def test_continuous_batching_replace_a_sequence(fa, name, dtype):
+    """fl_batch_replace (mod.rs:137-238: streams come and go independently): after some steps one stream leaves and
+    another -- other prompt, other length, a larger cache (more attention splits than the batch had: the graph is re-captured) --
+    takes its slot, the batch goes on.  Every stream's greedy tokens equal the single-sequence path's on a twin cache, before and
+    after the swap; the cache that left continues on its own."""
+    cfg = synth.CONFIGS[name]
+    w = synth.synth_weights(cfg)
+    gm = fa.Model(cfg, w, dtype=dtype)
+    B, lens = 5, [6, 11, 4, 9, 15]
+    caches, firsts, _ = prefilled(gm, cfg, lens)
+    singles, _, _ = prefilled(gm, cfg, lens)
+    batch = fa.Batch(gm, caches)
+    out1 = batch.decode(firsts, lens, 7)
+    ref1 = [gm.decode_greedy(singles[i], firsts[i], lens[i], 7) for i in range(B)]
+    for i in range(B):
+        assert [int(t) for t in out1[i]] == [int(t) for t in ref1[i]], "seq %d before the swap" % i
+    # stream 2 leaves; a new one joins in its slot (a cache eight times as large; a 13-token prompt)
+    pn = synth.prompt_ids(cfg, 13, seed=977)
+    cn, cn_twin = gm.new_cache(420), gm.new_cache(420)
+    fn = gm.forward_argmax(cn, pn, 0)
+    assert gm.forward_argmax(cn_twin, pn, 0) == fn
+    left, left_twin = caches[2], singles[2]
+    batch.replace(2, cn)
+    first2 = [int(out1[i][-1]) for i in range(B)]
+    pos2 = [lens[i] + 7 for i in range(B)]
+    first2[2], pos2[2] = fn, 13
+    out2 = batch.decode(first2, pos2, 9)
+    for i in range(B):
+        ref = gm.decode_greedy(cn_twin if i == 2 else singles[i], first2[i], pos2[i], 9)
+        assert [int(t) for t in out2[i]] == [int(t) for t in ref], "seq %d after the swap" % i
+    # the stream that left goes on alone where the batch left it
+    a = gm.decode_greedy(left, int(out1[2][-1]), lens[2] + 7, 5)
+    bb = gm.decode_greedy(left_twin, int(ref1[2][-1]), lens[2] + 7, 5)
+    assert [int(t) for t in a] == [int(t) for t in bb]
+    with pytest.raises(fa.FastLLMError):
+        batch.replace(0, cn)                                     # already sequence 2 of this batch
+    with pytest.raises(fa.FastLLMError):
+        batch.replace(B, left)                                   # no such slot
+    batch.replace(4, left)                                       # ... and a stream may come back
+    batch.close()
+
+
 def test_batch_errors(fa):
     cfg = synth.CONFIGS["llama_a"]
     w = synth.synth_weights(cfg)
