@@ -100,6 +100,7 @@ def lib():
         L.fl_batch_destroy.argtypes = [vp]
         L.fl_batch_destroy.restype = None
         L.fl_batch_replace.argtypes = [vp, C.c_size_t, vp]
+        L.fl_batch_decode_each.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp, vp]
         L.fl_batch_forward.argtypes = [vp, vp, vp, vp, vp]
         L.fl_batch_decode.argtypes = [vp, vp, vp, sz, C.c_int64, C.POINTER(FlSampling), vp, vp]
         L.fl_synchronize.argtypes = [vp]
@@ -342,6 +343,21 @@ class Batch:
         sp = FlSampling(temperature, seed, draws_done) if temperature is not None else None
         _check(lib().fl_batch_decode(self._h, first.ctypes.data, pos.ctypes.data, n_steps, eos, C.byref(sp) if sp else None,
                                      out.ctypes.data, n_out.ctypes.data))
+        return [out[i, : int(n_out[i])] for i in range(self.n)]
+
+    def decode_each(self, first_tokens, pos, n_steps, eos=None, temperatures=None, seeds=None, draws_done=None):
+        """fl_batch_decode_each: per-sequence EOS ids (None / negative: none) and temperatures (None / < 1e-7: ArgMax)."""
+        first = np.ascontiguousarray(first_tokens, dtype=np.uint32)
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        out = np.zeros((self.n, max(n_steps, 1)), dtype=np.uint32)
+        n_out = np.zeros(self.n, dtype=np.uint64)
+        e = np.ascontiguousarray([-1 if x is None else int(x) for x in (eos if eos is not None else [None] * self.n)], dtype=np.int64)
+        sp = (FlSampling * self.n)()
+        for i in range(self.n):
+            t = temperatures[i] if temperatures is not None and temperatures[i] is not None else 0.0
+            sp[i] = FlSampling(t, seeds[i] if seeds is not None else 0, draws_done[i] if draws_done is not None else 1)
+        _check(lib().fl_batch_decode_each(self._h, first.ctypes.data, pos.ctypes.data, n_steps, e.ctypes.data, C.cast(sp, C.c_void_p),
+                                          out.ctypes.data, n_out.ctypes.data))
         return [out[i, : int(n_out[i])] for i in range(self.n)]
 
     def close(self):

@@ -237,6 +237,12 @@ int fl_batch_decode(fl_batch *b, const uint32_t *first_tokens, const size_t *pos
         return batch_decode(reinterpret_cast<Batch *>(b), first_tokens, pos, n_steps, eos, sampling, tokens_out, n_out);
     });
 }
+int fl_batch_decode_each(fl_batch *b, const uint32_t *first_tokens, const size_t *pos, size_t n_steps, const int64_t *eos,
+                         const fl_sampling *sampling, uint32_t *tokens_out, size_t *n_out) {
+    return guarded([&]() -> int {
+        return batch_decode_each(reinterpret_cast<Batch *>(b), first_tokens, pos, n_steps, eos, sampling, tokens_out, n_out);
+    });
+}
 
 int fl_synchronize(fl_model *m) {
     return guarded([&]() -> int {

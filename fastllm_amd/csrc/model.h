@@ -190,6 +190,8 @@ int batch_forward(Batch *b, const uint32_t *tokens, const size_t *pos, float *lo
 // n_steps greedy / sampled steps; tokens_out [B][n_steps], n_out [B] (stops counting a sequence at its EOS)
 int batch_decode(Batch *b, const uint32_t *first, const size_t *pos, size_t n_steps, int64_t eos,
                  const fl_sampling *sampling, uint32_t *tokens_out, size_t *n_out);
+int batch_decode_each(Batch *b, const uint32_t *first, const size_t *pos, size_t n_steps, const int64_t *eos_each,
+                      const fl_sampling *sampling_each, uint32_t *tokens_out, size_t *n_out);
 
 int model_create(const fl_config *cfg, const fl_tensor *tensors, size_t n, int compute_dtype,
                  const fl_parallel *par, Model **out);

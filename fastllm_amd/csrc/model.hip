@@ -1864,6 +1864,15 @@ static int batch_check(Batch *b, const size_t *pos, size_t n_steps) {
 
 int batch_decode(Batch *b, const uint32_t *first, const size_t *pos, size_t n_steps, int64_t eos,
                  const fl_sampling *sampling, uint32_t *tokens_out, size_t *n_out) {
+    if (!b) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
+    std::vector<int64_t> e((size_t)b->B, eos);
+    std::vector<fl_sampling> sp((size_t)b->B, sampling ? *sampling : fl_sampling{0.0, 0, 0});
+    return batch_decode_each(b, first, pos, n_steps, e.data(), sp.data(), tokens_out, n_out);
+}
+
+// ... with every sequence's own EOS id and sampler (a request's temperature is its own: chat.rs:24-25; temperature < 1e-7 = ArgMax)
+int batch_decode_each(Batch *b, const uint32_t *first, const size_t *pos, size_t n_steps, const int64_t *eos_each,
+                      const fl_sampling *sampling_each, uint32_t *tokens_out, size_t *n_out) {
     if (!b || !first || !tokens_out || !n_out) FL_FAIL(FL_ERR_BAD_ARGUMENT, "null argument");
     const int B = b->B;
     for (int i = 0; i < B; i++) n_out[i] = 0;
@@ -1871,7 +1880,12 @@ int batch_decode(Batch *b, const uint32_t *first, const size_t *pos, size_t n_st
     FL_TRY(batch_check(b, pos, n_steps));
     Model *m = b->m;
     for (int i = 0; i < B; i++) if ((int64_t)first[i] >= m->D.V) FL_FAIL(FL_ERR_BAD_ARGUMENT, "token id %u out of range", first[i]);
-    const SampleState sampler = make_sampler(sampling);
+    std::vector<SampleState> samplers((size_t)B);
+    std::vector<int64_t> eoss((size_t)B, -1);
+    for (int i = 0; i < B; i++) {
+        samplers[(size_t)i] = make_sampler(sampling_each ? sampling_each + i : nullptr);
+        if (eos_each) eoss[(size_t)i] = eos_each[i];
+    }
     std::lock_guard<std::mutex> lock(m->mu);
     Shard &sh = m->shards[0];
     FL_HIP(hipSetDevice(sh.device));
@@ -1885,8 +1899,8 @@ int batch_decode(Batch *b, const uint32_t *first, const size_t *pos, size_t n_st
         for (int i = 0; i < B; i++) {
             Cache *c = b->caches[i];
             hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(64), 0, sh.stream, c->shards[0].st, tok[i], (uint32_t)(pos[i] + done),
-                               (uint32_t)(len0[i] + done), (uint32_t)(len0[i] + done), 0u, (int32_t)eos, c->shards[0].heads_done, (int)(m->D.L * sh.Hkvs),
-                               c->shards[0].ss, sampler, done == 0 ? 1 : 0);
+                               (uint32_t)(len0[i] + done), (uint32_t)(len0[i] + done), 0u, (int32_t)eoss[(size_t)i], c->shards[0].heads_done, (int)(m->D.L * sh.Hkvs),
+                               c->shards[0].ss, samplers[(size_t)i], done == 0 ? 1 : 0);
             FL_HIP(hipGetLastError());
         }
         for (size_t s = 0; s < nb; s++) FL_TRY(batch_step(b));
@@ -1902,7 +1916,7 @@ int batch_decode(Batch *b, const uint32_t *first, const size_t *pos, size_t n_st
             if (!finished[i]) {
                 for (size_t s = 0; s < nb; s++) {
                     const uint32_t t = b->host_tokens[(size_t)i * kBatchChunk + s];
-                    if (eos >= 0 && (int64_t)t == eos) {             // as fl_decode_greedy: the EOS forward counts, the token does not
+                    if (eoss[(size_t)i] >= 0 && (int64_t)t == eoss[(size_t)i]) {   // as fl_decode_greedy: the EOS forward counts, the token does not
                         finished[i] = 1;
                         b->caches[i]->len = len0[i] + done + s + 1;
                         break;

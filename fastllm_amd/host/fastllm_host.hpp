@@ -28,6 +28,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <memory>
 #include <optional>
 #include <stdexcept>
@@ -572,6 +574,141 @@ struct Model {                                // mod.rs:342-361
         }
         return n_forwards;
     }
+};
+
+// ------------------------------------------------------------------------------------ concurrent streams, one batched loop
+// The reference serves concurrent requests as independent tasks (ModelWrapper::generate_stream spawns one loop per stream,
+// mod.rs:137-238), each paying for the whole weight read per token.  StreamBatcher gives the same streams ONE decode loop
+// (continuous batching): `slots` caches form an fl_batch; a request waits in a queue until a slot is free, is
+// prefilled there alone (fl_forward_sample: its first token), and from then on advances with the others, `chunk` steps per call of
+// fl_batch_decode_each -- every stream with its own temperature (a seed-0 sampler of its own, mod.rs:157-158), its own EOS id and
+// its own max_tokens.  Per stream the tokens are those of generate_stream_ids with the sampling done on the device (fl_decode_sample):
+// sampled, EOS checked before the token is emitted (mod.rs:312-316), the callback's `false` is the dropped receiver (mod.rs:323-325).
+// Steps a stream runs past its own end inside a chunk are computed and discarded (its slot's cache is reset on the next admission).
+// Not thread-safe: one thread drives submit() / step() (a server would feed it from a channel).
+class StreamBatcher {
+  public:
+    using OnToken = std::function<bool(uint32_t)>;
+    using OnDone = std::function<void(size_t)>;                  // tokens handed to on_token
+
+    // counter_positions: the RoPE offset of a stream's k-th forward is k, not its token position -- what Mistral / Qwen streams
+    // see in the reference (quirk C.1: mistral.rs:226,234, qwen.rs:142-143; PosMode::Reference); Llama streams and
+    // FASTLLM_POS_MODE=tokens pass token positions
+    StreamBatcher(std::shared_ptr<detail::ModelHandle> model, size_t slots, size_t max_seq = 0, size_t chunk = 8, bool counter_positions = false)
+        : model_(std::move(model)), chunk_(std::max<size_t>(1, chunk)), counter_(counter_positions) {
+        if (!model_ || !model_->m) throw Error(FL_ERR_BAD_ARGUMENT, "StreamBatcher: no model");
+        if (slots < 1 || slots > 64) throw Error(FL_ERR_BAD_ARGUMENT, "StreamBatcher: 1 ... 64 slots");
+        cap_ = max_seq ? max_seq : detail::default_max_seq(model_->m);
+        if (cap_ < chunk_ + 1) throw Error(FL_ERR_BAD_ARGUMENT, "StreamBatcher: the caches are shorter than one chunk");
+        slots_.resize(slots);
+        std::vector<fl_cache *> cs;
+        try {
+            for (auto &sl : slots_) { check(fl_cache_create(model_->m, cap_, &sl.cache), "fl_cache_create"); cs.push_back(sl.cache); }
+            check(fl_batch_create(model_->m, cs.data(), cs.size(), &batch_), "fl_batch_create");
+        } catch (...) { release(); throw; }
+    }
+    ~StreamBatcher() { release(); }
+    StreamBatcher(const StreamBatcher &) = delete;
+
+    // a request as generate_stream sees it (token ids in, one callback per token out); returns its id
+    uint64_t submit(std::vector<uint32_t> prompt, size_t max_tokens, float temperature, std::optional<uint32_t> eos, OnToken on_token,
+                    OnDone on_done = {}) {
+        if (prompt.empty()) throw Error(FL_ERR_BAD_ARGUMENT, "Tokenization error: empty prompt");
+        if (prompt.size() + 1 > cap_) throw Error(FL_ERR_BAD_ARGUMENT, "the prompt does not fit a slot's cache");
+        if (!on_token) throw Error(FL_ERR_BAD_ARGUMENT, "null token callback");
+        Request r;
+        r.id = ++next_id_; r.prompt = std::move(prompt); r.max_tokens = max_tokens; r.temperature = temperature; r.eos = eos;
+        r.on_token = std::move(on_token); r.on_done = std::move(on_done);
+        queue_.push_back(std::move(r));
+        return next_id_;
+    }
+
+    size_t active() const { size_t n = 0; for (auto &sl : slots_) n += sl.active ? 1 : 0; return n; }
+    size_t waiting() const { return queue_.size(); }
+    size_t batch_steps = 0;                                        // decode steps the batch has run (all slots advance together)
+    size_t prefills = 0;
+
+    // admit waiting requests into free slots, then one chunk for everybody; false: nothing active and nothing waiting
+    bool step() {
+        for (auto &sl : slots_) {
+            while (!sl.active && !queue_.empty()) { admit(sl, std::move(queue_.front())); queue_.pop_front(); }
+        }
+        if (active() == 0) return !queue_.empty();
+        const size_t B = slots_.size();
+        size_t n = chunk_, want = 0;
+        for (auto &sl : slots_)
+            if (sl.active) { n = std::min(n, cap_ - sl.pos); want = std::max(want, sl.req.max_tokens - sl.emitted); }
+        n = std::min(n, want);                                     // nobody needs more than `want` further tokens
+        std::vector<uint32_t> first(B, 0), out(B * n, 0);
+        std::vector<size_t> pos(B, 0), n_out(B, 0);
+        std::vector<int64_t> eos(B, -1);
+        std::vector<fl_sampling> sp(B, fl_sampling{0.0, 0, 0});
+        for (size_t i = 0; i < B; i++) {
+            Slot &sl = slots_[i];
+            if (!sl.active) { fl_cache_reset(sl.cache); continue; }     // an empty slot computes a throw-away row at position 0
+            first[i] = sl.tok; pos[i] = counter_ ? sl.calls : sl.pos;
+            if (sl.req.eos) eos[i] = (int64_t)*sl.req.eos;
+            sp[i] = fl_sampling{(double)sl.req.temperature, 0, sl.draws};
+        }
+        check(fl_batch_decode_each(batch_, first.data(), pos.data(), n, eos.data(), sp.data(), out.data(), n_out.data()), "Model forward pass failed");
+        batch_steps += n;
+        for (size_t i = 0; i < B; i++) {
+            Slot &sl = slots_[i];
+            if (!sl.active) continue;
+            bool done = n_out[i] < n;                              // its EOS came up inside the chunk
+            for (size_t k = 0; k < n_out[i]; k++) {
+                if (sl.emitted >= sl.req.max_tokens) { done = true; break; }
+                sl.emitted++;                                      // (tokens handed to the callback, the refused one included)
+                if (!sl.req.on_token(out[i * n + k])) { done = true; break; }
+            }
+            if (!done && sl.emitted >= sl.req.max_tokens) done = true;
+            sl.pos += n; sl.calls += n; sl.draws += n; sl.tok = out[i * n + n - 1];
+            if (!done && sl.pos >= cap_) done = true;               // the slot's cache is full: the stream ends here
+            if (done) finish(sl);
+        }
+        return true;
+    }
+    void run() { while (step()) {} }
+
+  private:
+    struct Request {
+        uint64_t id = 0; std::vector<uint32_t> prompt; size_t max_tokens = 0; float temperature = 0.f; std::optional<uint32_t> eos;
+        OnToken on_token; OnDone on_done;
+    };
+    struct Slot { fl_cache *cache = nullptr; bool active = false; Request req; size_t pos = 0, calls = 0, emitted = 0; uint32_t tok = 0; uint64_t draws = 0; };
+
+    void admit(Slot &sl, Request r) {
+        sl.req = std::move(r); sl.emitted = 0; sl.active = true;
+        fl_cache_reset(sl.cache);
+        const fl_sampling sp{(double)sl.req.temperature, 0, 0};
+        uint32_t tok = 0;
+        check(fl_forward_sample(model_->m, sl.cache, sl.req.prompt.data(), sl.req.prompt.size(), 0, &sp, &tok), "Model forward pass failed");
+        prefills++;
+        sl.pos = sl.req.prompt.size(); sl.calls = 1; sl.tok = tok; sl.draws = 1;
+        if (sl.req.max_tokens == 0 || (sl.req.eos && tok == *sl.req.eos)) { finish(sl); return; }
+        sl.emitted = 1;
+        if (!sl.req.on_token(tok)) { finish(sl); return; }
+        if (sl.emitted >= sl.req.max_tokens || sl.pos >= cap_) finish(sl);
+    }
+    void finish(Slot &sl) {
+        sl.active = false;
+        OnDone cb = std::move(sl.req.on_done);
+        const size_t n = sl.emitted;
+        sl.req = Request{};
+        if (cb) cb(n);
+    }
+    void release() {
+        if (batch_) { fl_batch_destroy(batch_); batch_ = nullptr; }
+        for (auto &sl : slots_) if (sl.cache) { fl_cache_destroy(sl.cache); sl.cache = nullptr; }
+    }
+
+    std::shared_ptr<detail::ModelHandle> model_;
+    size_t chunk_, cap_ = 0;
+    bool counter_ = false;
+    std::vector<Slot> slots_;
+    std::deque<Request> queue_;
+    fl_batch *batch_ = nullptr;
+    uint64_t next_id_ = 0;
 };
 
 }  // namespace fastllm

@@ -215,4 +215,51 @@ void flh_cache_reset(void *hv) {           // ModelCache::reset (+ a fresh cache
     else h->qwen->cache.reset();
 }
 
+// StreamBatcher (fastllm_host.hpp): the reference's concurrent streams (mod.rs:137-238) on one batched decode loop
+namespace {
+struct BatcherHandle { std::unique_ptr<StreamBatcher> b; };
+std::shared_ptr<detail::ModelHandle> model_of(Handle *h) {
+    if (h->llama) return h->llama->model.model;
+    if (h->mistral) return h->mistral->model.model;
+    return h->qwen->model.model;
+}
+}  // namespace
+int flh_batcher_create(void *hv, size_t slots, size_t max_seq, size_t chunk, void **out) {
+    return guard([&] {
+        if (!hv || !out) throw Error(FL_ERR_BAD_ARGUMENT, "null argument");
+        auto bh = std::make_unique<BatcherHandle>();
+        Handle *h = static_cast<Handle *>(hv);
+        bh->b = std::make_unique<StreamBatcher>(model_of(h), slots, max_seq, chunk, !h->llama && pos_mode() == PosMode::Reference);
+        *out = bh.release();
+        return 0;
+    });
+}
+int flh_batcher_submit(void *bv, const uint32_t *prompt, size_t T, size_t max_tokens, float temperature, int64_t eos,
+                       int (*on_token)(uint64_t id, uint32_t token, void *user), void (*on_done)(uint64_t id, size_t n_tokens, void *user),
+                       void *user, uint64_t *id_out) {
+    return guard([&] {
+        if (!bv || !on_token || (!prompt && T)) throw Error(FL_ERR_BAD_ARGUMENT, "null argument");
+        auto *bh = static_cast<BatcherHandle *>(bv);
+        auto id = std::make_shared<uint64_t>(0);
+        std::optional<uint32_t> e = eos >= 0 ? std::optional<uint32_t>((uint32_t)eos) : std::nullopt;
+        StreamBatcher::OnDone done;
+        if (on_done) done = [=](size_t n) { on_done(*id, n, user); };
+        *id = bh->b->submit(std::vector<uint32_t>(prompt, prompt + T), max_tokens, temperature, e,
+                            [=](uint32_t t) { return on_token(*id, t, user) != 0; }, done);
+        if (id_out) *id_out = *id;
+        return 0;
+    });
+}
+int flh_batcher_run(void *bv, size_t *batch_steps, size_t *prefills) {
+    return guard([&] {
+        if (!bv) throw Error(FL_ERR_BAD_ARGUMENT, "null argument");
+        auto *bh = static_cast<BatcherHandle *>(bv);
+        bh->b->run();
+        if (batch_steps) *batch_steps = bh->b->batch_steps;
+        if (prefills) *prefills = bh->b->prefills;
+        return 0;
+    });
+}
+void flh_batcher_destroy(void *bv) { delete static_cast<BatcherHandle *>(bv); }
+
 }  // extern "C"

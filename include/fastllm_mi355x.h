@@ -247,6 +247,11 @@ int  fl_batch_forward(fl_batch *b, const uint32_t *tokens, const size_t *pos, fl
  * the reference does (seed 0 per request, mod.rs:373-374) */
 int  fl_batch_decode(fl_batch *b, const uint32_t *first_tokens, const size_t *pos, size_t n_steps, int64_t eos,
                      const fl_sampling *sampling, uint32_t *tokens_out, size_t *n_out);
+/* ... with every sequence's own EOS id (eos[i] < 0: none; eos NULL: none for all) and its own sampler (sampling[i]: temperature < 1e-7
+ * is ArgMax; sampling NULL: ArgMax for all) -- a request's temperature is its own (chat.rs:24-25), and one batch serves requests that
+ * differ in it.  draws_done lets a request span several calls, as in fl_decode_sample. */
+int  fl_batch_decode_each(fl_batch *b, const uint32_t *first_tokens, const size_t *pos, size_t n_steps, const int64_t *eos,
+                          const fl_sampling *sampling, uint32_t *tokens_out, size_t *n_out);
 
 int fl_synchronize(fl_model *m);
 

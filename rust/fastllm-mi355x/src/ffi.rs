@@ -204,6 +204,16 @@ extern "C" {
         tokens_out: *mut u32,
         n_out: *mut usize,
     ) -> c_int;
+    pub fn fl_batch_decode_each(
+        b: *mut fl_batch,
+        first_tokens: *const u32,
+        pos: *const usize,
+        n_steps: usize,
+        eos: *const i64,
+        sampling: *const fl_sampling,
+        tokens_out: *mut u32,
+        n_out: *mut usize,
+    ) -> c_int;
 
     pub fn fl_synchronize(m: *mut fl_model) -> c_int;
     pub fn fl_tp_slice(cfg: *const fl_config, tensor_name: *const c_char, tp_rank: i32, tp_size: i32, out: *mut i64) -> c_int;

@@ -211,3 +211,77 @@ def test_concurrent_streams_share_one_model(host, monkeypatch):
     for a, b in zip(alone, res):
         np.testing.assert_array_equal(a, b)
     host.flh_model_destroy(h)
+
+
+BATCH_TOKEN_CB = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_uint32, C.c_void_p)
+BATCH_DONE_CB = C.CFUNCTYPE(None, C.c_uint64, C.c_size_t, C.c_void_p)
+
+
+def run_batcher(host, h, requests, slots, chunk=4, max_seq=96):
+    """requests: (prompt, max_tokens, temperature, eos, stop_after) -> per request the tokens its callback received, + (steps, prefills)"""
+    host.flh_batcher_create.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
+    host.flh_batcher_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, C.c_int64, BATCH_TOKEN_CB, BATCH_DONE_CB, C.c_void_p,
+                                        C.POINTER(C.c_uint64)]
+    host.flh_batcher_run.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    host.flh_batcher_destroy.argtypes = [C.c_void_p]
+    b = C.c_void_p()
+    assert host.flh_batcher_create(h, slots, max_seq, chunk, C.byref(b)) == 0, host.flh_last_error()
+    got, done, stop = {}, {}, {}
+
+    def on_token(rid, tok, _user):
+        got[rid].append(int(tok))
+        return 0 if stop[rid] is not None and len(got[rid]) >= stop[rid] else 1
+
+    def on_done(rid, n, _user):
+        done[rid] = int(n)
+    cb, dcb = BATCH_TOKEN_CB(on_token), BATCH_DONE_CB(on_done)
+    ids = []
+    for prompt, n, temp, eos, stop_after in requests:
+        p = np.ascontiguousarray(prompt, dtype=np.uint32)
+        rid = C.c_uint64(0)
+        # (the id is known before any callback runs: requests are admitted inside flh_batcher_run)
+        assert host.flh_batcher_submit(b, p.ctypes.data, p.size, n, temp, eos, cb, dcb, None, C.byref(rid)) == 0, host.flh_last_error()
+        got[rid.value], stop[rid.value] = [], stop_after
+        ids.append(rid.value)
+    steps, pre = C.c_size_t(0), C.c_size_t(0)
+    assert host.flh_batcher_run(b, C.byref(steps), C.byref(pre)) == 0, host.flh_last_error()
+    host.flh_batcher_destroy(b)
+    for rid in ids:
+        assert done.get(rid) == len(got[rid]), "request %d: done callback %s, tokens %d" % (rid, done.get(rid), len(got[rid]))
+    return [np.array(got[r], dtype=np.uint32) for r in ids], steps.value, pre.value
+
+
+@pytest.mark.parametrize("name,dtype,mode", [("llama_a", 0, "reference"), ("mistral_a", 0, "reference"), ("qwen2_a", 0, "tokens"), ("mistral_a", 1, "tokens")])
+def test_stream_batcher_serves_the_streams_of_generate_stream(host, name, dtype, mode, monkeypatch):
+    """StreamBatcher (continuous batching over mod.rs:137-238's concurrent streams): nine requests -- different prompts,
+    lengths, max_tokens, an EOS id, a receiver that hangs up, two with a temperature -- through THREE slots, four steps per chunk.
+    Every request's tokens are what flh_generate_stream gives it alone (greedy: exactly; the sampled ones in fp32, where the batch's
+    logits are the single stream's to 1e-6), far fewer batch steps than the streams' forwards add up to, one prefill per request."""
+    monkeypatch.setenv("FASTLLM_POS_MODE", mode)
+    monkeypatch.setenv("FASTLLM_MAX_SEQ", "96")
+    h, cfg, w = make(host, name, dtype=dtype)
+    rs = np.random.RandomState(5)
+    reqs = []
+    for i in range(9):
+        prompt = synth.prompt_ids(cfg, 3 + int(rs.randint(0, 12)), seed=40 + i)
+        reqs.append([prompt, 5 + int(rs.randint(0, 30)), 0.0, -1, None])
+    reqs[2][4] = 3                                            # the receiver hangs up after three tokens
+    alone = [generate_stream(host, h, r[0], r[1], eos=r[3], temperature=r[2], stop_after=r[4])[0] for r in reqs]
+    reqs[4][3] = int(alone[4][min(4, len(alone[4]) - 1)])      # an EOS id that comes up a few tokens in
+    alone[4] = generate_stream(host, h, reqs[4][0], reqs[4][1], eos=reqs[4][3])[0]
+    if dtype == 0:
+        for i in (6, 7):
+            reqs[i][2] = 0.8
+            alone[i] = generate_stream(host, h, reqs[i][0], reqs[i][1], temperature=0.8)[0]
+    got, steps, prefills = run_batcher(host, h, [tuple(r) for r in reqs], slots=3)
+    for i in range(9):
+        np.testing.assert_array_equal(got[i], alone[i], err_msg="request %d" % i)
+    assert prefills == 9
+    total = sum(len(a) for a in alone)
+    assert steps < total                                      # the streams shared their steps (three at a time)
+    assert steps >= total // 3
+    # a one-slot batcher is the streams one after the other
+    got1, _, _ = run_batcher(host, h, [tuple(r) for r in reqs[:3]], slots=1)
+    for i in range(3):
+        np.testing.assert_array_equal(got1[i], alone[i])
+    host.flh_model_destroy(h)
