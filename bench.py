@@ -122,6 +122,48 @@ def parity_check(torch, fa, binding, cfg, wts, local_rank, n_layers=4, T=512, n_
             "sample": "first %d of %d layers + lm_head, %d-token prefill + %d decode steps, single GPU" % (n_layers, cfg["num_hidden_layers"], T, n_decode)}
 
 
+def stream_batcher_leg(model, cfg, rs, slots=32, requests=64, prompt=128, gen=128):
+    """fastllm::StreamBatcher (fastllm_amd/host) on the bench's own model handle: wall time from the first submit to the last token."""
+    import ctypes as C
+    host = C.CDLL(os.path.join(ROOT, "fastllm_amd", "lib", "libfastllm_host.so"))
+    host.flh_last_error.restype = C.c_char_p
+    TOK = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_uint32, C.c_void_p)
+    DONE = C.CFUNCTYPE(None, C.c_uint64, C.c_size_t, C.c_void_p)
+    host.flh_batcher_create_on.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+    host.flh_batcher_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, C.c_int64, TOK, DONE, C.c_void_p, C.POINTER(C.c_uint64)]
+    host.flh_batcher_run.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    host.flh_batcher_destroy.argtypes = [C.c_void_p]
+    count = [0]
+
+    def on_token(_rid, _tok, _u):
+        count[0] += 1
+        return 1
+    cb, dcb = TOK(on_token), DONE(lambda _rid, _n, _u: None)
+    prompts = [rs.randint(0, cfg["vocab_size"], size=prompt).astype(np.uint32) for _ in range(requests)]
+    best = None
+    for _rep in range(2):                                    # (the first pass captures the step's graph)
+        b = C.c_void_p()
+        if host.flh_batcher_create_on(model._h, slots, prompt + gen + 16, 16, 0, C.byref(b)) != 0:
+            raise RuntimeError(host.flh_last_error().decode(errors="replace"))
+        count[0] = 0
+        t0 = time.perf_counter()
+        for p in prompts:
+            rid = C.c_uint64(0)
+            if host.flh_batcher_submit(b, p.ctypes.data, p.size, gen, 0.0, -1, cb, dcb, None, C.byref(rid)) != 0:
+                raise RuntimeError(host.flh_last_error().decode(errors="replace"))
+        steps, pre = C.c_size_t(0), C.c_size_t(0)
+        rc = host.flh_batcher_run(b, C.byref(steps), C.byref(pre))
+        dt = time.perf_counter() - t0
+        host.flh_batcher_destroy(b)
+        if rc != 0:
+            raise RuntimeError(host.flh_last_error().decode(errors="replace"))
+        best = {"requests": requests, "slots": slots, "prompt_tokens": prompt, "generated_per_request": gen, "tokens": count[0], "seconds": round(dt, 4),
+                "tokens_per_sec": round(count[0] / dt, 1), "batch_steps": steps.value, "prefills": pre.value,
+                "note": "fastllm::StreamBatcher (host mirror, C++): requests queue for a slot of an fl_batch, are prefilled alone and decode together "
+                        "(fl_batch_decode_each, 16 steps per call); wall time from the first submit to the last token, prefills included"}
+    return best
+
+
 def secondary_entry(torch, fa, binding, device, local_rank, name, T, gen, dtype="bf16", parity_layers=4, steps=None, with_parity=True):
     """One of the other single-GPU BASELINE configs (or the headline workload in the fp32 parity mode), measured after the headline
     with the same rules: its own parity gate against the oracle first, synthetic weights of the model's real shapes, the median of
@@ -522,7 +564,7 @@ def main():
     barrier()
 
     # ---- batched decode (scope row N4: concurrent streams share one weight read); NOT the headline metric ----
-    batch8, batch32 = None, None
+    batch8, batch32, stream_batcher = None, None, None
     if world == 1 and os.environ.get("FL_BENCH_BATCH", "1") == "1":
         try:
             nb, kb = 8, min(K, 64)
@@ -573,6 +615,14 @@ def main():
             bt.close()
             for ci in bc:
                 ci.close()
+            # continuous batching end to end (round 5): the host mirror's StreamBatcher (fastllm_host.hpp) -- 64 requests of 128 + 128
+            # tokens through 32 slots, every request prefilled alone into a free slot and decoded with the others; prefills included
+            try:
+                stream_batcher = stream_batcher_leg(model, cfg, rs)
+                log("stream batcher: %.0f tokens/s end to end" % stream_batcher["tokens_per_sec"])
+            except Exception as e:                                           # noqa: the headline line must not depend on it
+                log("stream batcher leg failed: %r" % (e,))
+                stream_batcher = {"error": repr(e)}
         except Exception as e:                                               # the headline line must not depend on it
             log("batched decode leg failed:", repr(e))
 
@@ -717,6 +767,7 @@ def main():
             "tokens_crc32": my_crc, "ranks_agree": ranks_agree,
             "batched_decode": batch8,
             "batched_decode_32": batch32,
+            "stream_batcher": stream_batcher,
             "secondary": secondary,
             "fp32_mode_tokens_per_sec": fp32_mode["tokens_per_sec"] if fp32_mode and "tokens_per_sec" in fp32_mode else None,
             "fp32_mode": fp32_mode,

@@ -234,6 +234,19 @@ int flh_batcher_create(void *hv, size_t slots, size_t max_seq, size_t chunk, voi
         return 0;
     });
 }
+// ... on an fl_model the caller already holds (a reference is taken): a host that built the model through the C ABI itself
+int flh_batcher_create_on(void *fl_model_ptr, size_t slots, size_t max_seq, size_t chunk, int counter_positions, void **out) {
+    return guard([&] {
+        if (!fl_model_ptr || !out) throw Error(FL_ERR_BAD_ARGUMENT, "null argument");
+        fl_model *m = static_cast<fl_model *>(fl_model_ptr);
+        fl_model_retain(m);
+        auto mh = std::make_shared<detail::ModelHandle>(m);          // (releases the reference)
+        auto bh = std::make_unique<BatcherHandle>();
+        bh->b = std::make_unique<StreamBatcher>(mh, slots, max_seq, chunk, counter_positions != 0);
+        *out = bh.release();
+        return 0;
+    });
+}
 int flh_batcher_submit(void *bv, const uint32_t *prompt, size_t T, size_t max_tokens, float temperature, int64_t eos,
                        int (*on_token)(uint64_t id, uint32_t token, void *user), void (*on_done)(uint64_t id, size_t n_tokens, void *user),
                        void *user, uint64_t *id_out) {
