@@ -1,4 +1,4 @@
-// k_gemv_dma.hip -- the WIDE projections of a batched decode step or a very short prompt (3 <= B <= 16 rows; gate/up and lm_head: thousands
+// k_gemv_dma.hip -- the WIDE projections of a batched decode step or a very short prompt (3 <= B <= 32 rows; gate/up and lm_head: thousands
 // of 16-row tiles): Y[b] = W[N,K] . x[b] on the matrix cores with the weights streamed by LDS-DMA into wave-private
 // rings.  Row N4 of the scope table (mod.rs:137-238: the reference runs every stream as its own loop and pays for the
 // whole weight read per stream; here one read serves the batch).

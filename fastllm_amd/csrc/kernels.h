@@ -177,7 +177,7 @@ struct GemvBatchArgs {
 };
 int gemv_batch_ksplit(int B, int64_t K, int64_t N, int epi);
 int launch_gemv_batch(Launcher &L, const GemvBatchArgs &a);
-// the same projections with the weights streamed by LDS-DMA into wave-private rings (k_gemv_dma.hip; 3 <= B <= 8)
+// the same projections with the weights streamed by LDS-DMA into wave-private rings (k_gemv_dma.hip; 3 <= B <= 32 rows: a batch's streams or a short prompt's tokens)
 bool gemv_dma_supported(int B, int64_t N, int64_t K, int epi, int d);
 int gemv_dma_ksplit(int64_t K, int64_t N, int epi);
 int launch_gemv_dma(Launcher &L, const GemvBatchArgs &a);
