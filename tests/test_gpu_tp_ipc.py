@@ -286,6 +286,28 @@ def test_comm_selftest_proves_both_collective_forms(tmp_path, name, tp):
     gE.close()
 
 
+def test_continuous_batching_on_a_multiprocess_group(tmp_path):
+    """fl_batch_replace on the ranks of a group: every rank swaps the same slot between the same two steps (a newcomer prefilled on the
+    group), the batch goes on, every rank holds the same tokens -- and the newcomer's stream is what the group decodes for it alone."""
+    import fastllm_amd as fa
+    from fastllm_amd import binding
+    name, tp, B = "llama_tp4", 4, 6
+    res = run_group(tmp_path, name, "bf16", tp, env_extra={"TP_WORKER_BATCH": str(B), "TP_WORKER_BATCH_REPLACE": "1"})
+    for r in range(1, tp):
+        for k in ("batch_tokens", "batch_tokens_after_replace", "batch_replaced_first"):
+            np.testing.assert_array_equal(res[r][k], res[0][k], err_msg="rank %d vs 0: %s" % (r, k))
+    assert res[0]["batch_tokens_after_replace"].shape == (B, 6)
+    cfg = synth.CONFIGS[name]
+    gE = fa.Model(cfg, synth.synth_weights(cfg), dtype="bf16", tp_mode=binding.TP_EMULATED, tp_size=tp)
+    cE = gE.new_cache(64)
+    fE = gE.forward_argmax(cE, synth.prompt_ids(cfg, 9, seed=333), 0)
+    assert int(res[0]["batch_replaced_first"]) == fE                       # the prefill is the group's single-sequence path: same bits
+    alone = gE.decode_greedy(cE, fE, 9, 6)
+    same = int(np.sum(res[0]["batch_tokens_after_replace"][1] == np.asarray(alone)))
+    assert same >= 4, (res[0]["batch_tokens_after_replace"][1], alone)    # (batch step vs single step: another order of the fp32 sums; near-ties may flip late tokens)
+    gE.close()
+
+
 def test_stalled_peer_in_a_batch_step_is_an_error_not_a_hang(tmp_path):
     """... and the same for the many-workgroup collective behind a batch step's o_proj ([4, 4096] = 16 384 floats): every waiting
     workgroup gives up after FL_AR_TIMEOUT_MS, the last one still moves the epoch, the step returns FL_ERR_RCCL."""

@@ -141,6 +141,17 @@ def run_rank(rank, world, name, dtype, outdir, T, n_tf, n_greedy):
         res["batch_logits"], res["batch_first"] = lg, np.asarray(firsts, dtype=np.uint32)
         toks = bt.decode([int(t) for t in am], [n + 1 for n in lens], n_bsteps)
         res["batch_tokens"] = np.stack([np.concatenate([[am[i]], toks[i]]).astype(np.uint32) for i in range(n_batch)])
+        if os.environ.get("TP_WORKER_BATCH_REPLACE", "") == "1":      # continuous batching on the group: every rank swaps the same slot
+            cn = m.new_cache(38 + n_bsteps)
+            fn = m.forward_argmax(cn, synth.prompt_ids(cfg, 9, seed=333), 0)
+            bt.replace(1, cn)
+            first2 = [int(toks[i][-1]) for i in range(n_batch)]
+            pos2 = [lens[i] + 1 + n_bsteps for i in range(n_batch)]
+            first2[1], pos2[1] = fn, 9
+            t2 = bt.decode(first2, pos2, 6)
+            res["batch_tokens_after_replace"] = np.stack([np.asarray(t2[i], dtype=np.uint32) for i in range(n_batch)])
+            res["batch_replaced_first"] = np.array(fn, dtype=np.uint32)
+            caches.append(cn)
         bt.close()
         for ci in caches:
             ci.close()
